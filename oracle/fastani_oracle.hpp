@@ -1,0 +1,679 @@
+// oracle/fastani_oracle.hpp
+//
+// TEST INFRASTRUCTURE ONLY.  CPU restatement of the FastANI fragment-mapping
+// path as driven by pyfastani.  Nothing under oracle/ may be imported, linked
+// or executed by the product path (pyfastani_amd/); only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, and there
+// only as the checker / the timed CPU baseline.
+//
+// Provenance.  pyfastani's hot path lives partly in-tree (Cython adaptations
+// of four FastANI functions) and partly in the un-vendored git submodule
+// vendor/FastANI (github.com/ParBLiSS/FastANI, pinned revision unrecoverable:
+// /root/reference/.gitmodules:1-3 names no tag and the directory is empty;
+// header list at /root/reference/src/FastANI/CMakeLists.txt:1-18 matches the
+// v1.3x layout).  Functions below cite the in-tree file:line they follow
+// ([TREE]) or the upstream function they restate from its published
+// algorithm ([UPSTREAM]).  Boost.Math (vendor/boost-math, also absent) is
+// replaced by an exact binomial CDF summation.
+//
+// PARITY STATUS: pinned by (a) the reference's protein golden
+// (src/pyfastani/tests/test_ani.py:96-115: matches=130, fragments=176, x2),
+// (b) window_size == 24 (test_ani.py:60,80) and (c) the self-query invariant
+// implied by test_ani.py:66-71 (identity exactly 100.0, every fragment
+// matched).  The nucleotide goldens (test_ani.py:47-51,62-71,82-91) need two
+// FASTA files that are dangling symlinks in the reference checkout, so
+// nucleotide-mode parity beyond (b)/(c) is UNPINNED; tests/test_reference_goldens.py
+// checks the seven constants as soon as the files are supplied.
+//
+// Data structures deliberately mirror the reference (std::deque winnowing,
+// std::unordered_map index, std::map sliding window) so that timing this
+// code on host cores is a fair stand-in for the reference CPU path.
+#pragma once
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <atomic>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace fo {
+
+typedef uint32_t hash_t;    // include/fastani/map/base_types.pxd:10
+typedef int32_t offset_t;   // base_types.pxd:11
+typedef int32_t seqno_t;    // base_types.pxd:12
+
+// ---------------------------------------------------------------------------
+// S3  k-mer hash: MurmurHash3_x64_128(seq, k, seed=42), low 32 bits of h1.
+// [UPSTREAM] skch::CommonFunc::getHash (declared common_func.pxd:9,12);
+// algorithm restated from Appleby's public-domain description.
+// ---------------------------------------------------------------------------
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+static inline uint64_t fmix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return k;
+}
+
+static inline void murmur3_x64_128(const uint8_t *data, int len, uint32_t seed, uint64_t out[2]) {
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  const int nblocks = len / 16;
+  uint64_t h1 = seed, h2 = seed;
+  for (int i = 0; i < nblocks; i++) {
+    uint64_t k1, k2;
+    std::memcpy(&k1, data + 16 * i, 8);
+    std::memcpy(&k2, data + 16 * i + 8, 8);
+    k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const uint8_t *tail = data + nblocks * 16;
+  uint64_t k1 = 0, k2 = 0;
+  const int rem = len & 15;
+  for (int j = rem - 1; j >= 8; j--) k2 ^= (uint64_t)tail[j] << (8 * (j - 8));
+  if (rem > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+  for (int j = std::min(rem, 8) - 1; j >= 0; j--) k1 ^= (uint64_t)tail[j] << (8 * j);
+  if (rem > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+  h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+  h1 += h2; h2 += h1;
+  h1 = fmix64(h1); h2 = fmix64(h2);
+  h1 += h2; h2 += h1;
+  out[0] = h1; out[1] = h2;
+}
+
+static const uint32_t SEED = 42;  // common_func.pxd:9 (value [UPSTREAM], confirmed by the protein golden)
+
+static inline hash_t get_hash(const uint8_t *seq, int length) {
+  uint64_t out[2];
+  murmur3_x64_128(seq, length, SEED, out);
+  return (hash_t)(out[0] & 0xffffffffu);
+}
+
+// ---------------------------------------------------------------------------
+// S1  upper-casing and complement.  [TREE] _fastani.pyx:116-153,
+// _sequtils/sequtils.cpp:22-35 (toupper), _sequtils/complement.h (scalar
+// table: A<->T, C<->G, IUPAC pairs, everything else unchanged, case kept).
+// Parity is defined for ASCII letters; the reference's SSSE3 path differs
+// from its own scalar path on letters with no complement.
+// ---------------------------------------------------------------------------
+static inline uint8_t up(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+static inline uint8_t complement_upper(uint8_t c) {
+  switch (c) {
+    case 'A': return 'T'; case 'T': return 'A';
+    case 'C': return 'G'; case 'G': return 'C';
+    case 'R': return 'Y'; case 'Y': return 'R';
+    case 'K': return 'M'; case 'M': return 'K';
+    case 'B': return 'V'; case 'V': return 'B';
+    case 'D': return 'H'; case 'H': return 'D';
+    default: return c;  // N, S, W, U and non-nucleotide bytes map to themselves
+  }
+}
+
+// MinimizerInfo, base_types.pxd:16-28
+struct MinimizerInfo {
+  hash_t hash;
+  seqno_t seqId;
+  offset_t wpos;
+  bool operator==(const MinimizerInfo &x) const { return hash == x.hash && seqId == x.seqId && wpos == x.wpos; }
+  bool operator!=(const MinimizerInfo &x) const { return !(*this == x); }
+};
+// MinimizerMetaData, base_types.pxd:31-33
+struct MinimizerMetaData {
+  seqno_t seqId;
+  offset_t wpos;
+  bool operator<(const MinimizerMetaData &x) const {
+    return seqId != x.seqId ? seqId < x.seqId : wpos < x.wpos;
+  }
+};
+
+// read one character of a contig given as 1/2/4-byte code units
+// ([TREE] _fastani.pyx:144-148: UCS1 goes through copy_upper, wider kinds
+// through toupper(PyUnicode_READ)); code points >= 256 are truncated to
+// their low byte exactly as the C cast `fwd[...] = toupper(<int> ...)` does
+// for values toupper leaves alone.
+static inline uint8_t read_char(const void *data, int width, int64_t i) {
+  switch (width) {
+    case 1: return ((const uint8_t *)data)[i];
+    case 2: return (uint8_t)((const uint16_t *)data)[i];
+    default: return (uint8_t)((const uint32_t *)data)[i];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// S2 / S2p  winnowed minimizers of one contig or one query fragment.
+// [TREE] _fastani.pyx:156-222 (nucleotide) and :252-309 (protein).  The
+// reference streams through a 2x2048-byte window; indexing the upper-cased
+// sequence directly is equivalent for k <= 2048 (_fastani.pyx:533-534).
+// ---------------------------------------------------------------------------
+static inline void add_minimizers(std::vector<MinimizerInfo> &out, const void *data, int width,
+                                  int64_t slen, int k, int w, seqno_t seq_counter, bool protein) {
+  if (slen < k) return;
+  std::vector<uint8_t> fwd((size_t)slen), bwd;
+  for (int64_t i = 0; i < slen; i++) fwd[i] = up(read_char(data, width, i));
+  if (!protein) {
+    bwd.resize((size_t)slen);
+    for (int64_t i = 0; i < slen; i++) bwd[slen - 1 - i] = complement_upper(fwd[i]);
+  }
+  std::deque<std::pair<MinimizerInfo, int64_t>> q;               // :171
+  for (int64_t i = 0; i < slen - k + 1; i++) {                    // :190
+    hash_t hf = get_hash(&fwd[i], k);                             // :198
+    hash_t cur;
+    if (!protein) {
+      hash_t hb = get_hash(&bwd[slen - i - k], k);                // :199
+      if (hb == hf) continue;                                     // :202 symmetric k-mers skipped entirely
+      cur = std::min(hf, hb);                                     // :206
+    } else {
+      cur = hf;                                                   // :290
+    }
+    int64_t win = i - w + 1;                                      // :204
+    while (!q.empty() && q.front().second <= i - w) q.pop_front();          // :208-209
+    while (!q.empty() && q.back().first.hash >= cur) q.pop_back();          // :211-212
+    q.push_back(std::make_pair(MinimizerInfo{cur, seq_counter, 0}, i));     // :214-217
+    if (win >= 0) {                                                         // :219
+      if (out.empty() || out.back() != q.front().first) {                   // :220
+        q.front().first.wpos = (offset_t)win;                               // :221
+        out.push_back(q.front().first);                                     // :222
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// S9  Stat::j2md / md2j / md_lower_bound.  [UPSTREAM] map_stats.hpp, declared
+// map_stats.pxd:6-8.  Float/double promotions follow the C++ expressions:
+//   j2md:  float r = (-1.0 / k) * log(2.0 * j / (1 + j));      (1 + j) is float
+//   md2j:  float r = 1.0 / (2.0 * exp(k * d) - 1.0);           k*d is float and, in the
+//          pyfastani translation unit (Python.h pulls in <math.h>, whose libstdc++
+//          wrapper exposes the float overload), exp(float) is expf  -- OPEN item.
+// ---------------------------------------------------------------------------
+static inline float j2md(float j, int k) {
+  if (j == 0) return 1.0f;
+  if (j == 1) return 0.0f;
+  float onepj = 1 + j;
+  double v = (-1.0 / k) * std::log(2.0 * (double)j / (double)onepj);
+  return (float)v;
+}
+
+static inline float md2j(float d, int k) {
+  float kd = (float)k * d;
+  float e = std::exp(kd);  // float overload
+  double v = 1.0 / (2.0 * (double)e - 1.0);
+  return (float)v;
+}
+
+// smallest integer x with BinomCDF(x; n, p) >= 1 - q.  Restates
+// boost::math::quantile(complement(binomial(n, p), q)) under Boost's default
+// integer_round_outwards policy for an upper quantile (1-q > 0.5), including
+// its special cases (success_fraction == 1 -> n; 1-q <= pdf(0) -> 0).
+static inline int binomial_upper_quantile(int n, double p, double q) {
+  const double target = 1.0 - q;
+  if (n <= 0) return 0;
+  if (p >= 1.0) return n;
+  if (p <= 0.0) return 0;
+  const double lp = std::log(p), lq = std::log1p(-p);
+  if (target <= std::exp(n * lq)) return 0;
+  double cdf = 0.0;
+  const double lgn = std::lgamma((double)n + 1.0);
+  for (int x = 0; x < n; x++) {
+    double lpmf = lgn - std::lgamma((double)x + 1.0) - std::lgamma((double)(n - x) + 1.0) + x * lp + (n - x) * lq;
+    cdf += std::exp(lpmf);
+    if (cdf >= target) return x;
+  }
+  return n;
+}
+
+static inline float md_lower_bound(float d, int s, int k, float ci) {
+  double q2 = (1.0 - (double)ci) / 2.0;
+  int x = binomial_upper_quantile(s, (double)md2j(d, k), q2);
+  float jaccard = (float)x / (float)s;
+  return j2md(jaccard, k);
+}
+
+static const float CONFIDENCE_INTERVAL = 0.9f;  // [UPSTREAM]; 0.75 would give window 30, not the asserted 24
+
+// S6b  [UPSTREAM] Stat::estimateMinimumHits / estimateMinimumHitsRelaxed (map_stats.pxd:10-11)
+static inline int estimate_minimum_hits(int s, int k, float perc_identity) {
+  float mash_dist = (float)(1.0 - (double)perc_identity / 100.0);
+  float jaccard = md2j(mash_dist, k);
+  return (int)std::ceil(1.0 * s * (double)jaccard);
+}
+
+static inline int estimate_minimum_hits_relaxed(int s, int k, float perc_identity) {
+  int first = estimate_minimum_hits(s, k, perc_identity);
+  int relaxed = first;
+  for (int i = first; i >= 0; i--) {
+    float jaccard = (float)(1.0 * i / s);
+    float d = j2md(jaccard, k);
+    float d_lower = md_lower_bound(d, s, k, CONFIDENCE_INTERVAL);
+    float id_upper = (float)(100.0 * (1.0 - (double)d_lower));
+    if (id_upper >= perc_identity) relaxed = i; else break;
+  }
+  return relaxed;
+}
+
+// P[X >= x] for X ~ Binom(n, r), x >= 1  (Boost cdf(complement(binomial, x-1)))
+static inline double binomial_sf_ge(int n, double r, int x) {
+  if (x <= 0) return 1.0;
+  if (x > n) return 0.0;
+  if (r <= 0.0) return 0.0;
+  if (r >= 1.0) return 1.0;
+  const double lp = std::log(r), lq = std::log1p(-r), lgn = std::lgamma((double)n + 1.0);
+  double s = 0.0;
+  for (int i = x; i <= n; i++) {
+    double lpmf = lgn - std::lgamma((double)i + 1.0) - std::lgamma((double)(n - i) + 1.0) + i * lp + (n - i) * lq;
+    double t = std::exp(lpmf);
+    s += t;
+    if (t < s * 1e-18 && i > n * r) break;
+  }
+  return s;
+}
+
+// S12  [UPSTREAM] Stat::estimate_pvalue / recommendedWindowSize (map_stats.pxd:13-29)
+static inline double estimate_pvalue(int s, int k, int alphabet, float identity, int len_query, uint64_t len_ref) {
+  double kmer_space = std::pow((double)alphabet, (double)k);
+  double pX = 1.0 / (1.0 + kmer_space / len_query), pY = pX;
+  double r = pX * pY / (pX + pY - pX * pY);
+  int x = estimate_minimum_hits_relaxed(s, k, identity);
+  double sf = (x == 0) ? 1.0 : binomial_sf_ge(s, r, x);
+  return (double)len_ref * sf;
+}
+
+// Returns -1 when no candidate sketch size reaches the cut-off (upstream then
+// reads an uninitialised variable); callers clamp.
+static inline int recommended_window_size(double pvalue_cutoff, int k, int alphabet, float identity,
+                                          int len_query, uint64_t len_ref) {
+  std::vector<int> cand{1, 2, 5};
+  for (int i = 10; i < len_query; i += 10) cand.push_back(i);
+  int optimal = -1;
+  for (int e : cand) {
+    if (estimate_pvalue(e, k, alphabet, identity, len_query, len_ref) <= pvalue_cutoff) { optimal = e; break; }
+  }
+  if (optimal < 0) return -1;
+  int w = (int)(2.0 * len_query / optimal);
+  return std::min(std::max(w, 1), len_query);
+}
+
+// ---------------------------------------------------------------------------
+// Parameters (map_parameters.pxd:9-24) and the reference sketch (win_sketch.pxd:17-42)
+// ---------------------------------------------------------------------------
+struct Parameters {
+  int kmerSize = 16;
+  int windowSize = 24;
+  int minReadLength = 3000;
+  float minFraction = 0.2f;
+  int alphabetSize = 4;
+  uint64_t referenceSize = 5000000;
+  float percentageIdentity = 80.0f;
+  double p_value = 1e-3;
+};
+
+struct Sketch {
+  Parameters param;
+  std::vector<MinimizerInfo> minimizerIndex;
+  std::vector<seqno_t> sequencesByFileInfo;
+  std::unordered_map<hash_t, std::vector<MinimizerMetaData>> minimizerPosLookupIndex;
+  std::map<int, int> minimizerFreqHistogram;
+  int freqThreshold = INT_MAX;                      // _fastani.pyx:760
+  const float percentageThreshold = 0.001f;         // [UPSTREAM] winSketch.hpp
+  // pyfastani-side bookkeeping (_fastani.pyx:465-468)
+  size_t counter = 0;
+  std::vector<uint64_t> lengths;
+  size_t cur_total = 0;
+
+  // S4  [TREE] Sketch._add_draft body for one contig, _fastani.pyx:629-683.
+  // returns 1 if minimizers were computed, 0 if the contig was too short (warning case).
+  int add_contig(const void *data, int width, int64_t slen) {
+    int added = 0;
+    if (slen >= param.windowSize && slen >= param.kmerSize) {   // :648
+      add_minimizers(minimizerIndex, data, width, slen, param.kmerSize, param.windowSize,
+                     (seqno_t)counter, param.alphabetSize != 4);
+      added = 1;
+    }
+    cur_total += (size_t)(slen / param.minReadLength) * param.minReadLength;  // :680
+    counter += 1;                                                              // :683
+    return added;
+  }
+  void end_genome() {                                  // :686-690
+    lengths.push_back(cur_total);
+    cur_total = 0;
+    sequencesByFileInfo.push_back((seqno_t)counter);
+  }
+
+  // S5  [UPSTREAM] Sketch::index(): hash -> positions, in insertion order
+  void index() {
+    minimizerPosLookupIndex.clear();
+    for (const auto &e : minimizerIndex)
+      minimizerPosLookupIndex[e.hash].push_back(MinimizerMetaData{e.seqId, e.wpos});
+  }
+  // S5  [UPSTREAM] Sketch::computeFreqHist()
+  void compute_freq_hist() {
+    minimizerFreqHistogram.clear();
+    for (const auto &e : minimizerPosLookupIndex) minimizerFreqHistogram[(int)e.second.size()] += 1;
+    int64_t total_unique = (int64_t)minimizerPosLookupIndex.size();
+    int64_t to_ignore = (int64_t)((float)total_unique * percentageThreshold / 100);
+    int64_t sum = 0;
+    for (auto it = minimizerFreqHistogram.rbegin(); it != minimizerFreqHistogram.rend(); ++it) {
+      sum += it->second;
+      if (sum < to_ignore) { freqThreshold = it->first; }
+      else if (sum == to_ignore) { freqThreshold = it->first; break; }
+      else break;
+    }
+  }
+  // [UPSTREAM] Sketch::searchIndex: lower_bound on (seqId, wpos)
+  size_t search_index(seqno_t seqId, offset_t winpos) const {
+    size_t lo = 0, hi = minimizerIndex.size();
+    while (lo < hi) {
+      size_t mid = (lo + hi) / 2;
+      const MinimizerInfo &m = minimizerIndex[mid];
+      bool less = m.seqId != seqId ? m.seqId < seqId : m.wpos < winpos;
+      if (less) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+};
+
+// compute_map.pxd:41-51
+struct L1Candidate { seqno_t seqId; offset_t rangeStartPos; offset_t rangeEndPos; };
+struct L2Locus { seqno_t seqId; offset_t meanOptimalPos; size_t optimalStart; size_t optimalEnd; int sharedSketchSize; };
+// base_types.pxd:52-63 (only the fields consumed downstream, plus the two counts)
+struct MappingResult {
+  offset_t refStartPos; seqno_t refSeqId; seqno_t querySeqId;
+  float nucIdentity; float nucIdentityUpperBound; int sketchSize; int conservedSketches;
+};
+
+struct Query {
+  std::vector<MinimizerInfo> minimizerTableQuery;
+  int sketchSize = 0;
+  seqno_t seqCounter = 0;
+  offset_t len = 0;
+};
+
+// ---------------------------------------------------------------------------
+// S8  [UPSTREAM] skch::SlideMapper (slidingMap.hpp): ordered map over the
+// union of query sketch and reference window, pivot at the s-th smallest,
+// counter of entries <= pivot present in both.
+// ---------------------------------------------------------------------------
+struct SlideMapper {
+  static const offset_t NA = INT_MAX;
+  struct Val { offset_t wposQ, wposR; };
+  typedef std::map<hash_t, Val> Map;
+  Map m;
+  Map::iterator pivot;
+  int shared = 0;
+  explicit SlideMapper(const Query &Q) {
+    for (int i = 0; i < Q.sketchSize; i++)
+      m.emplace_hint(m.end(), Q.minimizerTableQuery[i].hash, Val{Q.minimizerTableQuery[i].wpos, NA});
+    pivot = std::prev(m.end());
+  }
+  void insert_ref(const MinimizerInfo &mi) {
+    enum { UNIQ = 1, CPLD = 2, REV = 3 } status;
+    auto it = m.find(mi.hash);
+    if (it == m.end()) { m[mi.hash] = Val{NA, mi.wpos}; status = UNIQ; }
+    else { status = (it->second.wposR == NA) ? CPLD : REV; it->second.wposR = mi.wpos; }
+    if (mi.hash <= pivot->first) {
+      if (status == CPLD) shared += 1;
+      else if (status == UNIQ) {
+        if (pivot->second.wposR != NA && pivot->second.wposQ != NA) shared -= 1;
+        --pivot;
+      }
+    }
+  }
+  void delete_ref(const MinimizerInfo &mi) {
+    enum { DEL = 1, UPD = 2, NOOP = 3 } status;
+    bool pivot_deleted = false;
+    auto it = m.find(mi.hash);
+    if (it == m.end()) return;
+    if (it->second.wposR != mi.wpos) status = NOOP;
+    else if (it->second.wposQ == NA) {
+      if (pivot->first == mi.hash) { ++pivot; pivot_deleted = true; }
+      m.erase(it);
+      status = DEL;
+    } else { status = UPD; it->second.wposR = NA; }
+    if (mi.hash <= pivot->first || pivot_deleted) {
+      if (status == UPD) shared -= 1;
+      else if (status == DEL) {
+        if (!pivot_deleted) ++pivot;
+        if (pivot->second.wposR != NA && pivot->second.wposQ != NA) shared += 1;
+      }
+    }
+  }
+};
+
+struct Mapper {
+  const Sketch &ref;
+  const Parameters &param;
+  explicit Mapper(const Sketch &s) : ref(s), param(s.param) {}
+
+  // S6  [TREE] Mapper._do_l1_mappings, _fastani.pyx:885-954
+  void do_l1(const void *frag, int width, int64_t flen, Query &Q, std::vector<L1Candidate> &l1) const {
+    add_minimizers(Q.minimizerTableQuery, frag, width, flen, param.kmerSize, param.windowSize, 0,
+                   param.alphabetSize != 4);                                           // :907-926
+    std::sort(Q.minimizerTableQuery.begin(), Q.minimizerTableQuery.end(),
+              [](const MinimizerInfo &a, const MinimizerInfo &b) { return a.hash < b.hash; });   // :929
+    auto uniq_end = std::unique(Q.minimizerTableQuery.begin(), Q.minimizerTableQuery.end(),
+                                [](const MinimizerInfo &a, const MinimizerInfo &b) { return a.hash == b.hash; });  // :933
+    Q.sketchSize = (int)std::distance(Q.minimizerTableQuery.begin(), uniq_end);        // :936
+    if (Q.sketchSize == 0) return;                                                     // :937
+    std::vector<MinimizerMetaData> seeds;
+    for (auto it = Q.minimizerTableQuery.begin(); it != uniq_end; ++it) {              // :941-948
+      auto f = ref.minimizerPosLookupIndex.find(it->hash);
+      if (f != ref.minimizerPosLookupIndex.end()) {
+        if ((int64_t)f->second.size() < (int64_t)ref.freqThreshold)                    // :946 strict
+          seeds.insert(seeds.end(), f->second.begin(), f->second.end());
+      }
+    }
+    int minimum_hits = estimate_minimum_hits_relaxed(Q.sketchSize, param.kmerSize, param.percentageIdentity);  // :951
+    compute_l1_candidates(Q, seeds, minimum_hits, l1);                                 // :952
+  }
+
+  // S7  [UPSTREAM] Map::computeL1CandidateRegions
+  static void compute_l1_candidates(const Query &Q, std::vector<MinimizerMetaData> &seeds, int minimum_hits,
+                                    std::vector<L1Candidate> &l1) {
+    if (minimum_hits < 1) minimum_hits = 1;
+    std::sort(seeds.begin(), seeds.end());
+    for (size_t i = 0; i < seeds.size(); i++) {
+      if (seeds.size() - i >= (size_t)minimum_hits) {
+        const MinimizerMetaData &a = seeds[i], &b = seeds[i + minimum_hits - 1];
+        if (b.seqId == a.seqId && b.wpos - a.wpos < Q.len) {
+          L1Candidate c{a.seqId, std::max(0, b.wpos - Q.len + 1), a.wpos};
+          if (!l1.empty() && c.seqId == l1.back().seqId && l1.back().rangeEndPos >= c.rangeStartPos)
+            l1.back().rangeEndPos = std::max(c.rangeEndPos, l1.back().rangeEndPos);
+          else
+            l1.push_back(c);
+        }
+      }
+    }
+  }
+
+  // S8  [UPSTREAM] Map::computeL2MappedRegions + MIIteratorL2.  The
+  // super-window at window position p holds the minimizers of the cmw
+  // minimizer-windows p .. p+cmw-1: the record active at p (last wpos <= p)
+  // through the last record with wpos <= p+cmw-1; it slides one window
+  // position at a time until the last admissible record has been admitted.
+  void compute_l2(const Query &Q, const L1Candidate &c, L2Locus &out) const {
+    const std::vector<MinimizerInfo> &mi = ref.minimizerIndex;
+    const offset_t cmw = Q.len - (param.windowSize - 1) - (param.kmerSize - 1);
+    size_t beg = ref.search_index(c.seqId, c.rangeStartPos);
+    offset_t p = mi[beg].wpos;
+    size_t end = ref.search_index(c.seqId, p + cmw);
+    size_t last = ref.search_index(c.seqId, c.rangeEndPos + cmw);
+    SlideMapper sm(Q);
+    for (size_t i = beg; i < end; i++) sm.insert_ref(mi[i]);
+    out.sharedSketchSize = 0; out.optimalStart = beg; out.optimalEnd = beg;
+    bool first = true;
+    while (true) {
+      if (first || sm.shared > out.sharedSketchSize) {
+        out.sharedSketchSize = sm.shared; out.optimalStart = beg; out.optimalEnd = beg;
+        first = false;
+      } else if (sm.shared == out.sharedSketchSize) {
+        out.optimalEnd = beg;
+      }
+      if (end >= last) break;
+      p += 1;
+      if (beg + 1 < mi.size() && mi[beg + 1].seqId == c.seqId && mi[beg + 1].wpos <= p) { sm.delete_ref(mi[beg]); beg++; }
+      if (end < last && mi[end].wpos <= p + cmw - 1) { sm.insert_ref(mi[end]); end++; }
+    }
+    out.meanOptimalPos = (mi[out.optimalStart].wpos + mi[out.optimalEnd].wpos) / 2;
+    out.seqId = c.seqId;
+  }
+
+  // S8  [UPSTREAM] Map::doL2Mapping (called _fastani.pyx:998-1002)
+  void do_l2(const Query &Q, const std::vector<L1Candidate> &l1, std::vector<MappingResult> &outv) const {
+    for (const auto &c : l1) {
+      L2Locus l2;
+      compute_l2(Q, c, l2);
+      float mash_dist = j2md((float)(1.0 * l2.sharedSketchSize / Q.sketchSize), param.kmerSize);
+      float lower = md_lower_bound(mash_dist, Q.sketchSize, param.kmerSize, CONFIDENCE_INTERVAL);
+      float nucIdentity = 100 * (1 - mash_dist);
+      float upper = 100 * (1 - lower);
+      if (upper >= param.percentageIdentity) {
+        MappingResult r;
+        r.refStartPos = l2.meanOptimalPos; r.refSeqId = l2.seqId; r.querySeqId = Q.seqCounter;
+        r.nucIdentity = nucIdentity; r.nucIdentityUpperBound = upper;
+        r.sketchSize = Q.sketchSize; r.conservedSketches = l2.sharedSketchSize;
+        outv.push_back(r);
+      }
+    }
+  }
+};
+
+// cgid_types.pxd:19-27
+struct CGIResult { seqno_t refGenomeId, qryGenomeId, countSeq, totalQueryFragments; float identity; };
+
+// ---------------------------------------------------------------------------
+// S10  [UPSTREAM] cgi::computeCGI (declared compute_core_identity.pxd:28-37,
+// called _fastani.pyx:1108-1118).  Best mapping per (genome, query fragment),
+// then best per (reference contig, reference bin), then mean per genome.
+// The reference's tie-breaks depend on thread timing and an unstable sort
+// (SURVEY.md H4); this restatement fixes the canonical order documented in
+// ties on identity go to the smallest (refSeqId, refStartPos) in
+// step 1 and to the smallest querySeqId in step 2.
+// ---------------------------------------------------------------------------
+static inline void compute_cgi(const Parameters &param, const std::vector<MappingResult> &results, const Sketch &ref,
+                               uint64_t total_query_fragments, std::vector<CGIResult> &out) {
+  struct R { seqno_t refSeq, genome, qseq, refStart, bin; float id; };
+  std::vector<R> v; v.reserve(results.size());
+  const int bin_len = param.minReadLength - 20;
+  for (const auto &e : results) {
+    R r; r.refSeq = e.refSeqId; r.qseq = e.querySeqId; r.refStart = e.refStartPos; r.id = e.nucIdentity;
+    r.bin = bin_len != 0 ? e.refStartPos / bin_len : 0;
+    r.genome = (seqno_t)(std::upper_bound(ref.sequencesByFileInfo.begin(), ref.sequencesByFileInfo.end(), e.refSeqId) -
+                         ref.sequencesByFileInfo.begin());
+    v.push_back(r);
+  }
+  std::vector<R> one, two;
+  std::sort(v.begin(), v.end(), [](const R &a, const R &b) {
+    if (a.genome != b.genome) return a.genome < b.genome;
+    if (a.qseq != b.qseq) return a.qseq < b.qseq;
+    if (a.id != b.id) return a.id > b.id;
+    if (a.refSeq != b.refSeq) return a.refSeq < b.refSeq;
+    return a.refStart < b.refStart;
+  });
+  for (const auto &e : v)
+    if (one.empty() || !(e.genome == one.back().genome && e.qseq == one.back().qseq)) one.push_back(e);
+  std::sort(one.begin(), one.end(), [](const R &a, const R &b) {
+    if (a.genome != b.genome) return a.genome < b.genome;
+    if (a.refSeq != b.refSeq) return a.refSeq < b.refSeq;
+    if (a.bin != b.bin) return a.bin < b.bin;
+    if (a.id != b.id) return a.id > b.id;
+    return a.qseq < b.qseq;
+  });
+  for (const auto &e : one)
+    if (two.empty() || !(e.refSeq == two.back().refSeq && e.bin == two.back().bin)) two.push_back(e);
+  for (size_t i = 0; i < two.size();) {
+    size_t j = i; float sum = 0.0f;
+    while (j < two.size() && two[j].genome == two[i].genome) { sum += two[j].id; j++; }
+    CGIResult c; c.qryGenomeId = 0; c.refGenomeId = two[i].genome; c.countSeq = (seqno_t)(j - i);
+    c.totalQueryFragments = (seqno_t)total_query_fragments; c.identity = sum / c.countSeq;
+    out.push_back(c);
+    i = j;
+  }
+}
+
+struct Hit { int32_t refGenomeId; float identity; int32_t matches; int32_t fragments; };
+
+struct ContigView { const void *data; int width; int64_t len; };
+
+// ---------------------------------------------------------------------------
+// S11  [TREE] Mapper._query_draft, _fastani.pyx:1006-1136.  `threads` mirrors
+// the reference's ThreadPool over the fragments of each contig (:1099-1102).
+// n_short receives the number of contigs skipped with a warning (:1061-1070).
+// When `mappings` is non-null it receives every L2 result, in the canonical
+// (querySeqId, refSeqId, refStartPos) order, for stage-by-stage parity tests.
+// ---------------------------------------------------------------------------
+static inline void query_draft(const Sketch &sk, const std::vector<uint64_t> &lengths, const std::vector<ContigView> &contigs,
+                               int threads, std::vector<Hit> &hits, int *n_short, std::vector<MappingResult> *mappings,
+                               std::vector<CGIResult> *raw_rows = nullptr, uint64_t *total_frag_out = nullptr,
+                               uint64_t *total_len_out = nullptr) {
+  const Parameters &param = sk.param;
+  Mapper map(sk);
+  std::vector<MappingResult> final_mappings;
+  std::mutex mtx;
+  uint64_t total_fragments = 0, total_length = 0;
+  int shorts = 0;
+  if (threads < 1) threads = 1;
+  for (const auto &c : contigs) {
+    int64_t slen = c.len;
+    if (slen < std::min<int64_t>(std::min(param.windowSize, param.kmerSize), param.minReadLength)) { shorts++; continue; }  // :1062
+    int64_t fragment_count = slen / param.minReadLength;                                   // :1097
+    std::atomic<int64_t> next(0);
+    auto worker = [&]() {
+      std::vector<MappingResult> local;
+      while (true) {
+        int64_t i = next.fetch_add(1);
+        if (i >= fragment_count) break;
+        Query Q;
+        Q.len = param.minReadLength;                                                       // :984
+        Q.seqCounter = (seqno_t)(total_fragments + i);                                     // :985
+        const uint8_t *frag = (const uint8_t *)c.data + (size_t)i * param.minReadLength * c.width;   // :980
+        std::vector<L1Candidate> l1;
+        map.do_l1(frag, c.width, param.minReadLength, Q, l1);                              // :987-996
+        map.do_l2(Q, l1, local);                                                           // :998-1002
+      }
+      std::lock_guard<std::mutex> g(mtx);
+      final_mappings.insert(final_mappings.end(), local.begin(), local.end());
+    };
+    if (threads == 1) worker();
+    else {
+      std::vector<std::thread> pool;
+      for (int t = 0; t < threads; t++) pool.emplace_back(worker);
+      for (auto &t : pool) t.join();
+    }
+    total_fragments += (uint64_t)fragment_count;                                           // :1104
+    total_length += (uint64_t)slen;                                                        // :1105
+  }
+  std::sort(final_mappings.begin(), final_mappings.end(), [](const MappingResult &a, const MappingResult &b) {
+    if (a.querySeqId != b.querySeqId) return a.querySeqId < b.querySeqId;
+    if (a.refSeqId != b.refSeqId) return a.refSeqId < b.refSeqId;
+    return a.refStartPos < b.refStartPos;
+  });
+  std::vector<CGIResult> results;
+  compute_cgi(param, final_mappings, sk, total_fragments, results);                        // :1108-1118
+  for (const auto &r : results) {                                                          // :1121-1132
+    uint64_t min_length = std::min<uint64_t>(total_length, lengths[r.refGenomeId]);
+    uint64_t shared_length = (uint64_t)r.countSeq * (uint64_t)param.minReadLength;
+    if ((float)shared_length >= (float)min_length * param.minFraction)
+      hits.push_back(Hit{r.refGenomeId, r.identity, r.countSeq, r.totalQueryFragments});
+  }
+  std::stable_sort(hits.begin(), hits.end(), [](const Hit &a, const Hit &b) { return a.identity > b.identity; });  // :1135
+  if (n_short) *n_short = shorts;
+  if (mappings) *mappings = std::move(final_mappings);
+  if (raw_rows) *raw_rows = results;
+  if (total_frag_out) *total_frag_out = total_fragments;
+  if (total_len_out) *total_len_out = total_length;
+}
+
+}  // namespace fo
