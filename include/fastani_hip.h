@@ -1,0 +1,175 @@
+/* include/fastani_hip.h
+ *
+ * C ABI of libfastani_hip.so: the MI355X-native FastANI fragment-mapping
+ * engine that stands in for the C++ symbols pyfastani's Cython module
+ * cimports (there is no plugin registry in the reference; the boundary IS
+ * that cimport surface).  Every entry point names the reference
+ * interface it replaces (paths relative to the pyfastani checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; opaque handles own all device memory;
+ *   - every function returns 0 on success, non-zero on failure; the message
+ *     is available from fa_last_error() (thread-local); nothing throws
+ *     across the boundary (reference: `except +` / `except 1 nogil`,
+ *     include/fastani/map/compute_map.pxd:31-36, src/pyfastani/_fastani.pyx:164,893);
+ *   - input buffers are borrowed for the duration of the call
+ *     (_fastani.pyx:1095 memoryview over caller memory);
+ *   - contigs are passed as (pointer, length, char_width) with char_width
+ *     1, 2 or 4 = the PyUnicode kind (_fastani.pyx:633-645,1073-1092);
+ *   - there is NO CPU fallback: without a HIP device the compute entry points
+ *     fail with FA_ERR_NO_DEVICE.
+ */
+#ifndef FASTANI_HIP_H
+#define FASTANI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FA_OK 0
+#define FA_ERR_INVALID 1     /* bad argument (maps to ValueError)              */
+#define FA_ERR_NO_DEVICE 2   /* no HIP device / HIP runtime error (RuntimeError) */
+#define FA_ERR_NOMEM 3       /* host or device allocation failed (MemoryError)  */
+#define FA_ERR_UNSUPPORTED 4 /* parameter regime outside the HIP path           */
+#define FA_ERR_INTERNAL 5
+
+typedef struct fa_sketch fa_sketch;   /* skch::Sketch under construction + pyfastani bookkeeping */
+typedef struct fa_mapper fa_mapper;   /* indexed reference, resident in HBM (skch::Sketch after index() + skch::Map) */
+typedef struct fa_genomes fa_genomes; /* a batch of query genomes packed 2-bit and resident in HBM */
+
+/* skch::Parameters, include/fastani/map/map_parameters.pxd:9-24 (fields the path reads) */
+typedef struct fa_params {
+  int32_t kmer_size;            /* kmerSize            */
+  int32_t window_size;          /* windowSize          */
+  int32_t fragment_length;      /* minReadLength       */
+  int32_t alphabet_size;        /* alphabetSize: 4 nucleotide, 20 protein */
+  float min_fraction;           /* minFraction         */
+  float percentage_identity;    /* percentageIdentity  */
+  double p_value;               /* p_value             */
+  uint64_t reference_size;      /* referenceSize       */
+} fa_params;
+
+/* cgi::CGI_Results, include/fastani/cgi/cgid_types.pxd:19-27, plus the query index of a batch */
+typedef struct fa_cgi_row {
+  int32_t query_id;               /* position of the query genome in the batch (qryGenomeId) */
+  int32_t ref_genome_id;          /* refGenomeId          */
+  int32_t count_seq;              /* countSeq  -> Hit.matches   */
+  int32_t total_query_fragments;  /* totalQueryFragments -> Hit.fragments */
+  float identity;                 /* identity  -> Hit.identity  */
+} fa_cgi_row;
+
+/* one L2 mapping, include/fastani/map/base_types.pxd:52-63 (fields consumed downstream) */
+typedef struct fa_mapping {
+  int32_t query_seq_id;     /* querySeqId: fragment number inside its query genome */
+  int32_t ref_seq_id;       /* refSeqId   */
+  int32_t ref_start_pos;    /* refStartPos (= meanOptimalPos) */
+  int32_t sketch_size;      /* sketchSize */
+  int32_t conserved;        /* conservedSketches */
+  int32_t query_id;
+} fa_mapping;
+
+/* ---- library ---------------------------------------------------------- */
+const char *fa_last_error(void);
+int fa_version(void);
+int fa_device_count(int *count);
+int fa_set_device(int device);            /* one process per GPU: call once per rank */
+
+/* ---- parameter statistics (host) -------------------------------------- */
+/* skch::Stat::recommendedWindowSize, include/fastani/map/map_stats.pxd:22-29, called _fastani.pyx:553-560.
+ * *window = -1 when no sketch size reaches the p-value cut-off (upstream reads an uninitialised value there). */
+int fa_recommended_window_size(double p_value, int k, int alphabet_size, float identity, int fragment_length,
+                               uint64_t reference_size, int *window);
+/* skch::Stat::estimateMinimumHitsRelaxed, map_stats.pxd:11, called _fastani.pyx:951 */
+int fa_estimate_minimum_hits_relaxed(int sketch_size, int k, float identity, int *hits);
+/* nucIdentity / nucIdentityUpperBound of skch::Map::doL2Mapping for (shared, sketch_size) */
+int fa_mapping_identity(int shared, int sketch_size, int k, float *identity, float *upper_bound);
+/* skch::CommonFunc::getHash, include/fastani/map/common_func.pxd:12 (host twin of the device function) */
+uint32_t fa_hash(const void *kmer, int length);
+
+/* ---- Sketch: reference side ------------------------------------------- */
+/* `new Sketch_t(param)`, _fastani.pyx:476 */
+int fa_sketch_new(const fa_params *params, fa_sketch **out);
+void fa_sketch_free(fa_sketch *s);
+/* one iteration of the contig loop of Sketch._add_draft, _fastani.pyx:629-683 (addMinimizers on device, lazily).
+ * *added = 0 when the contig is shorter than the window or k-mer size (the UserWarning case, :670-677). */
+int fa_sketch_add_contig(fa_sketch *s, const void *data, int64_t length, int char_width, int *added);
+/* tail of Sketch._add_draft, _fastani.pyx:686-690: closes the genome, records its fragment-rounded length */
+int fa_sketch_end_genome(fa_sketch *s);
+/* Sketch.clear, _fastani.pyx:746-767 */
+int fa_sketch_clear(fa_sketch *s);
+/* len(Sketch.minimizers) / Minimizers.__getitem__, _fastani.pyx:1222-1235 (device -> host read-back) */
+int fa_sketch_num_minimizers(fa_sketch *s, int64_t *n);
+int fa_sketch_get_minimizers(fa_sketch *s, uint32_t *hash, int32_t *seq_id, int32_t *wpos);
+/* Sketch.__getstate__/__setstate__, _fastani.pyx:572-591 */
+int fa_sketch_num_genomes(fa_sketch *s, int64_t *n);
+int fa_sketch_get_state(fa_sketch *s, uint64_t *lengths, int32_t *sequences_by_file, int64_t *counter);
+int fa_sketch_set_state(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths, const int32_t *sequences_by_file,
+                        int64_t counter, int64_t n_minimizers, const uint32_t *hash, const int32_t *seq_id,
+                        const int32_t *wpos);
+/* Sketch.index, _fastani.pyx:769-806: Sketch_t::index() + computeFreqHist(); ownership of the data moves to the
+ * mapper and the sketch is left cleared but usable. */
+int fa_sketch_index(fa_sketch *s, fa_mapper **out);
+
+/* ---- Mapper: query side ------------------------------------------------ */
+void fa_mapper_free(fa_mapper *m);
+/* Sketch_t::getFreqThreshold, include/fastani/map/win_sketch.pxd:40 */
+int fa_mapper_freq_threshold(fa_mapper *m, int *threshold);
+/* len(Mapper.lookup_index) = minimizerPosLookupIndex.size(), _fastani.pyx:1454-1456 */
+int fa_mapper_lookup_size(fa_mapper *m, int64_t *n);
+/* MinimizerIndex.__iter__/__getitem__, _fastani.pyx:1458-1475 */
+int fa_mapper_lookup_keys(fa_mapper *m, uint32_t *keys);
+int fa_mapper_lookup_count(fa_mapper *m, uint32_t hash, int64_t *count); /* -1 when absent */
+int fa_mapper_lookup_get(fa_mapper *m, uint32_t hash, int32_t *seq_id, int32_t *wpos, int64_t cap);
+int fa_mapper_num_minimizers(fa_mapper *m, int64_t *n);
+int fa_mapper_get_minimizers(fa_mapper *m, uint32_t *hash, int32_t *seq_id, int32_t *wpos);
+int fa_mapper_num_genomes(fa_mapper *m, int64_t *n);
+int fa_mapper_get_state(fa_mapper *m, uint64_t *lengths, int32_t *sequences_by_file);
+
+/* Mapper._query_draft up to and including computeCGI, _fastani.pyx:1006-1118, for ONE query genome given as
+ * host buffers.  rows receive one cgi::CGI_Results per reference genome with at least one mapping, in
+ * refGenomeId order; the minimum_fraction filter and the sort (_fastani.pyx:1121-1136) stay with the caller,
+ * which owns the names.  *n_short = contigs skipped with the short-sequence warning (:1061-1070). */
+int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *lengths, int n_contigs, int char_width,
+                    fa_cgi_row *rows, int64_t cap, int64_t *n_rows, int *n_short, uint64_t *total_fragments,
+                    uint64_t *total_length);
+
+/* ---- resident batches (many-to-many; inputs stay in HBM) -------------- */
+/* Pack + upload a batch of query genomes.  contig_genome[i] is the genome (0..n_genomes-1, non-decreasing)
+ * contig i belongs to.  Short contigs are skipped exactly as _fastani.pyx:1061-1070 does. */
+int fa_genomes_upload(fa_mapper *m, const void *const *contigs, const int64_t *lengths, const int32_t *contig_genome,
+                      int64_t n_contigs, int32_t n_genomes, int char_width, fa_genomes **out);
+void fa_genomes_free(fa_genomes *g);
+int fa_genomes_info(fa_genomes *g, int32_t *n_genomes, uint64_t *total_fragments, uint64_t *total_length,
+                    int32_t *n_short); /* arrays of n_genomes entries, may be NULL */
+/* Map genomes [first, first+count) of a resident batch against the resident index: the hot path
+ * (K1 sketch -> lookup -> L1 -> L2 -> CGI), everything on device.  rows as fa_mapper_query, query_id = index in
+ * the batch.  If rows_device is non-zero, `rows` is a DEVICE pointer (e.g. a torch tensor feeding an RCCL
+ * all-gather) with room for `cap` rows. */
+int fa_mapper_query_genomes(fa_mapper *m, fa_genomes *g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap,
+                            int64_t *n_rows, int rows_device);
+
+/* stage-level introspection used by the parity tests */
+int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t *n); /* L2 results of the last query call */
+int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *range_start, int32_t *range_end,
+                       int64_t cap, int64_t *n);
+int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashes, int32_t cap, int32_t *sketch_size);
+/* winnowed minimizers of one stand-alone sequence in query-fragment mode (seqId 0, fresh output vector) */
+int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t length, int char_width,
+                             uint32_t *hash, int32_t *wpos, int64_t cap, int64_t *n);
+
+/* last-call device timings in milliseconds, measured with HIP events on the library's stream:
+ * [0] sketch (K1+sort/unique) [1] lookup+L1 [2] L2 [3] CGI [4] total; and the number of K1 launches/bases */
+int fa_mapper_last_timings(fa_mapper *m, float *ms, int n);
+/* the HIP stream the library launches on (so callers can bracket it with their own events) */
+int fa_mapper_stream(fa_mapper *m, void **stream);
+/* run only the minimizer-extraction kernel (K1) over a resident batch `repeat` times and report the mean
+ * kernel time; used by bench.py for the roofline line. */
+int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_per_launch, uint64_t *bases,
+                           uint64_t *minimizers);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTANI_HIP_H */

@@ -1,0 +1,1011 @@
+// fa_engine.hip -- host side of libfastani_hip.so: owns the HIP stream and all HBM allocations, drives the
+// kernels of fa_sketch.hip.h / fa_map.hip.h, and exports the C ABI declared in include/fastani_hip.h.
+// There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <memory>
+#include <mutex>
+
+#include "fa_common.h"
+#include "fa_map.hip.h"
+#include "fa_sketch.hip.h"
+#include "fa_stats.h"
+
+using namespace fa;
+
+// ------------------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+template <typename F>
+static int guarded(F &&fn) {
+  try {
+    fn();
+    return FA_OK;
+  } catch (const Error &e) {
+    g_last_error = e.what();
+    return e.code;
+  } catch (const std::bad_alloc &) {
+    g_last_error = "host allocation failed";
+    return FA_ERR_NOMEM;
+  } catch (const std::exception &e) {
+    g_last_error = e.what();
+    return FA_ERR_INTERNAL;
+  }
+}
+
+static void require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    throw Error(FA_ERR_NO_DEVICE, "no HIP device available: libfastani_hip has no CPU fallback");
+  }
+}
+
+static void validate_params(const fa_params &p) {
+  FA_REQUIRE(p.kmer_size >= 1 && p.kmer_size <= 2048, FA_ERR_INVALID, "kmer_size must be in [1, 2048]");
+  FA_REQUIRE(p.fragment_length >= 1, FA_ERR_INVALID, "fragment_length must be strictly positive");
+  FA_REQUIRE(p.window_size >= 1, FA_ERR_INVALID, "window_size must be strictly positive");
+  FA_REQUIRE(p.alphabet_size == 4 || p.alphabet_size == 20, FA_ERR_INVALID, "alphabet_size must be 4 or 20");
+  size_t lds = sketch_lds_bytes(p.kmer_size, p.window_size);
+  FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED,
+             "window_size/kmer_size too large for the LDS-staged sketch kernel (tile + 2w + k must fit 160 KiB)");
+}
+
+static int floor_log2(int v) {
+  int l = 0;
+  while ((2 << l) <= v) l++;
+  return l;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K1 launcher shared by the reference and the query side
+// ------------------------------------------------------------------------------------------------------------
+struct SketchWork {
+  DevBuf<Tile> tiles;
+  DevBuf<uint32_t> stage_hash;
+  DevBuf<int32_t> stage_wpos;
+  DevBuf<int32_t> tile_count;   // ntiles + 1
+  DevBuf<int32_t> tile_off;     // ntiles + 1
+  DevBuf<unsigned char> cub_temp;
+};
+
+static void launch_sketch_tiles(const fa_params &P, const DevStore &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
+                                int32_t *stage_wpos, int32_t *tile_count, hipStream_t st) {
+  if (ntiles <= 0) return;
+  SketchArgs a;
+  a.tiles = d_tiles;
+  a.packed = store.packed.p; a.bytes = store.bytes.p; a.exc_pos = store.exc_pos.p; a.exc_val = store.exc_val.p;
+  a.stage_hash = stage_hash; a.stage_wpos = stage_wpos; a.tile_count = tile_count;
+  a.k = P.kmer_size; a.w = P.window_size; a.levels = floor_log2(P.window_size);
+  a.protein = P.alphabet_size != 4;
+  a.npos_cap = TILE + 2 * P.window_size - 2;
+  size_t lds = sketch_lds_bytes(P.kmer_size, P.window_size);
+  size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16);
+  a.code_words = (int32_t)(image / 4);
+  if (P.kmer_size == 16) {
+    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_sketch_tiles<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_sketch_tiles<16>, dim3(ntiles), dim3(SK_THREADS), lds, st, a);
+  } else {
+    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_sketch_tiles<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_sketch_tiles<0>, dim3(ntiles), dim3(SK_THREADS), lds, st, a);
+  }
+  FA_HIP(hipGetLastError());
+}
+
+static void exclusive_sum_i32(DevBuf<unsigned char> &temp, const int32_t *in, int32_t *out, int n, hipStream_t st) {
+  size_t bytes = 0;
+  FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n, st));
+  temp.ensure(bytes + 16);
+  FA_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, in, out, n, st));
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// fa_sketch: reference genomes being collected (skch::Sketch + pyfastani's counters)
+// ------------------------------------------------------------------------------------------------------------
+struct fa_sketch {
+  fa_params P;
+  hipStream_t stream = nullptr;
+  HostStore pending;                      // packed contigs not yet sketched
+  std::vector<int32_t> pending_contig;    // contig id of each pending sequence
+  int64_t counter = 0;                    // contigs seen (Sketch._counter)
+  uint64_t cur_total = 0;
+  std::vector<uint64_t> lengths;          // per genome, rounded to whole fragments
+  std::vector<int32_t> seqs_by_file;      // sequencesByFileInfo
+  DevBuf<uint32_t> rec_hash;
+  DevBuf<int32_t> rec_seq, rec_wpos;
+  int64_t nrec = 0;
+  SketchWork work;
+  std::mutex mtx;
+
+  void reset_data() {
+    pending.clear(); pending.protein = P.alphabet_size != 4;
+    pending_contig.clear();
+    counter = 0; cur_total = 0; lengths.clear(); seqs_by_file.clear(); nrec = 0;
+  }
+
+  // sketch every pending contig on the device and append the records
+  void flush() {
+    if (pending.seq_off.empty()) return;
+    require_device();
+    if (!stream) FA_HIP(hipStreamCreate(&stream));
+    DevStore store;
+    store.upload(pending, stream);
+    const int64_t nseq_all = (int64_t)pending.seq_off.size();
+    const int64_t chunk_positions = 96LL << 20;   // staging is 8 B per k-mer position: <= 768 MiB per chunk
+    int64_t s0 = 0;
+    DevBuf<int32_t> d_seq_tile_lo, d_drop, d_drop_off, d_seq_ids;
+    while (s0 < nseq_all) {
+      std::vector<Tile> tiles;
+      std::vector<int32_t> seq_tile_lo, seq_ids;
+      int64_t s1 = s0, positions = 0;
+      while (s1 < nseq_all && (s1 == s0 || positions + pending.seq_len[s1] <= chunk_positions)) {
+        seq_tile_lo.push_back((int32_t)tiles.size());
+        make_tiles(tiles, pending, pending.seq_off[s1], pending.seq_len[s1], (int)(s1 - s0), P.kmer_size, P.window_size);
+        seq_ids.push_back(pending_contig[s1]);
+        positions += pending.seq_len[s1];
+        s1++;
+      }
+      seq_tile_lo.push_back((int32_t)tiles.size());
+      const int nseq = (int)(s1 - s0), ntiles = (int)tiles.size();
+      if (ntiles > 0) {
+        work.tiles.upload(tiles, stream);
+        work.stage_hash.ensure((size_t)ntiles * TILE);
+        work.stage_wpos.ensure((size_t)ntiles * TILE);
+        work.tile_count.ensure(ntiles + 1);
+        work.tile_off.ensure(ntiles + 1);
+        FA_HIP(hipMemsetAsync(work.tile_count.p + ntiles, 0, sizeof(int32_t), stream));
+        launch_sketch_tiles(P, store, work.tiles.p, ntiles, work.stage_hash.p, work.stage_wpos.p, work.tile_count.p, stream);
+        d_seq_tile_lo.upload(seq_tile_lo, stream);
+        d_seq_ids.upload(seq_ids, stream);
+        d_drop.ensure(nseq + 1);
+        d_drop_off.ensure(nseq + 1);
+        FA_HIP(hipMemsetAsync(d_drop.p + nseq, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_suppress_runs, dim3(ceil_div(nseq, 128)), dim3(128), 0, stream, d_seq_tile_lo.p, nseq,
+                           work.tile_count.p, work.stage_hash.p, work.stage_wpos.p, d_drop.p);
+        exclusive_sum_i32(work.cub_temp, work.tile_count.p, work.tile_off.p, ntiles + 1, stream);
+        exclusive_sum_i32(work.cub_temp, d_drop.p, d_drop_off.p, nseq + 1, stream);
+        int32_t total = 0, dropped = 0;
+        FA_HIP(hipMemcpyAsync(&total, work.tile_off.p + ntiles, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        FA_HIP(hipMemcpyAsync(&dropped, d_drop_off.p + nseq, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        FA_HIP(hipStreamSynchronize(stream));
+        const int64_t nout = (int64_t)total - dropped;
+        rec_hash.ensure((size_t)(nrec + nout), true, stream, (size_t)nrec);
+        rec_seq.ensure((size_t)(nrec + nout), true, stream, (size_t)nrec);
+        rec_wpos.ensure((size_t)(nrec + nout), true, stream, (size_t)nrec);
+        hipLaunchKernelGGL(k_compact_records, dim3(ntiles), dim3(256), 0, stream, work.tiles.p, work.tile_count.p,
+                           work.tile_off.p, d_seq_tile_lo.p, d_drop.p, d_drop_off.p, work.stage_hash.p, work.stage_wpos.p,
+                           d_seq_ids.p, nrec, rec_hash.p, rec_seq.p, rec_wpos.p);
+        FA_HIP(hipGetLastError());
+        FA_HIP(hipStreamSynchronize(stream));
+        nrec += nout;
+      }
+      s0 = s1;
+    }
+    pending.clear();
+    pending.protein = P.alphabet_size != 4;
+    pending_contig.clear();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// fa_genomes: packed query genomes resident in HBM, cut into fragments and tiles
+// ------------------------------------------------------------------------------------------------------------
+struct fa_genomes {
+  fa_params P;
+  DevStore store;
+  int32_t n_genomes = 0;
+  std::vector<int64_t> genome_frag_lo;      // [n_genomes + 1] fragment range of each genome
+  std::vector<int32_t> frag_tile_lo;        // [F + 1]
+  std::vector<uint64_t> total_fragments, total_length;
+  std::vector<int32_t> n_short;
+  int64_t F = 0, ntiles = 0;
+  uint64_t total_bases = 0;                 // bases inside fragments
+  DevBuf<Tile> tiles;
+  DevBuf<int32_t> d_frag_tile_lo, d_frag_query, d_frag_qseq, d_total_frag;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// fa_mapper: the indexed reference + the workspace of the query pipeline
+// ------------------------------------------------------------------------------------------------------------
+struct fa_mapper {
+  fa_params P;
+  hipStream_t stream = nullptr;
+  std::mutex mtx;
+  // reference records and index (see fa_map.hip.h for the layout)
+  DevBuf<uint32_t> rec_hash, uniq_hash, uniq_off, pos_ridx, dir;
+  DevBuf<int32_t> rec_seq, rec_wpos, rec_prev, contig_rec, contig_genome, contig_bin, genome_bin;
+  DevBuf<uint8_t> rec_flags;
+  int64_t N = 0, U = 0;
+  int32_t C = 0, G = 0, dir_shift = 0, freq_threshold = INT_MAX, total_bins = 0;
+  std::vector<uint64_t> lengths;
+  std::vector<int32_t> seqs_by_file;
+  int32_t cmw = 0, qcap = 1;
+  // LUTs
+  StatTables stats;
+  DevBuf<int32_t> d_min_hits, d_pass;
+  DevBuf<float> d_ident;
+  // workspace
+  SketchWork sk;
+  DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
+  DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
+  DevBuf<uint64_t> totals;
+  DevBuf<unsigned long long> group_best, bins;
+  DevBuf<float> row_ident;
+  DevBuf<fa_cgi_row> rows_dev;
+  // last-pass bookkeeping for the debug getters
+  int64_t last_F = 0, last_f0 = 0;
+  uint32_t last_loci = 0;
+  const fa_genomes *last_genomes = nullptr;
+  float last_ms[8] = {0};
+  hipEvent_t ev[6] = {nullptr};
+
+  IndexView view() const {
+    IndexView v;
+    v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_flags = rec_flags.p;
+    v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.dir = dir.p;
+    v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
+    v.N = N; v.U = U; v.C = C; v.G = G; v.dir_shift = dir_shift; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
+    return v;
+  }
+};
+
+__global__ void k_contig_bins(const int32_t *contig_rec, const int32_t *rec_wpos, int C, int bin_len, int32_t *nbins) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  int n = 0;
+  if (c < C) {
+    int lo = contig_rec[c], hi = contig_rec[c + 1];
+    if (hi > lo) n = rec_wpos[hi - 1] / bin_len + 1;
+  }
+  nbins[c] = n;
+}
+
+// Sketch_t::index() + computeFreqHist() on the device
+static void build_index(fa_mapper &m) {
+  hipStream_t st = m.stream;
+  const int64_t N = m.N;
+  FA_REQUIRE(N < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "more than 2^31 minimizers in one index");
+  m.C = m.seqs_by_file.empty() ? 0 : m.seqs_by_file.back();
+  m.G = (int32_t)m.seqs_by_file.size();
+  m.cmw = m.P.fragment_length - (m.P.window_size - 1) - (m.P.kmer_size - 1);
+  m.qcap = std::max(1, m.P.fragment_length - m.P.kmer_size + 1 - (m.P.window_size - 1));
+  const int bin_len = m.P.fragment_length - 20;
+  DevBuf<unsigned char> temp;
+  // contig tables
+  std::vector<int32_t> cg((size_t)m.C + 1, 0);
+  {
+    int g = 0;
+    for (int c = 0; c < m.C; c++) {
+      while (g < m.G && m.seqs_by_file[g] <= c) g++;
+      cg[c] = g;
+    }
+  }
+  m.contig_genome.upload(cg, st);
+  m.contig_rec.ensure((size_t)m.C + 2);
+  hipLaunchKernelGGL(k_contig_ranges, dim3(ceil_div(m.C + 1, 256)), dim3(256), 0, st, m.rec_seq.p, N, m.C, m.contig_rec.p);
+  DevBuf<int32_t> nbins;
+  nbins.ensure((size_t)m.C + 2);
+  m.contig_bin.ensure((size_t)m.C + 2);
+  hipLaunchKernelGGL(k_contig_bins, dim3(ceil_div(m.C + 1, 256)), dim3(256), 0, st, m.contig_rec.p, m.rec_wpos.p, m.C,
+                     bin_len > 0 ? bin_len : 1, nbins.p);
+  exclusive_sum_i32(temp, nbins.p, m.contig_bin.p, m.C + 1, st);
+  std::vector<int32_t> cb((size_t)m.C + 1);
+  m.contig_bin.download(cb.data(), (size_t)m.C + 1, st);
+  FA_HIP(hipStreamSynchronize(st));
+  m.total_bins = cb[m.C];
+  std::vector<int32_t> gb((size_t)m.G + 1);
+  for (int g = 0; g <= m.G; g++) {
+    int c = g == 0 ? 0 : m.seqs_by_file[g - 1];
+    gb[g] = cb[std::min(c, m.C)];
+  }
+  m.genome_bin.upload(gb, st);
+
+  // hash-grouped order (stable radix sort keeps record order inside a hash group)
+  m.pos_ridx.ensure((size_t)N + 4);
+  m.rec_prev.ensure((size_t)N + 4);
+  m.rec_flags.ensure(((size_t)N + 7) / 4 * 4);
+  FA_HIP(hipMemsetAsync(m.rec_flags.p, 0, ((size_t)N + 7) / 4 * 4, st));
+  m.U = 0;
+  m.freq_threshold = INT_MAX;
+  if (N > 0) {
+    DevBuf<uint32_t> iota, sorted_hash, counts, counts_sorted;
+    DevBuf<int32_t> num_runs;
+    iota.ensure((size_t)N); sorted_hash.ensure((size_t)N); counts.ensure((size_t)N + 1); num_runs.ensure(1);
+    hipLaunchKernelGGL(k_iota, dim3(ceil_div(N, 256)), dim3(256), 0, st, iota.p, N);
+    size_t bytes = 0;
+    FA_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (int)N, 0, 32, st));
+    temp.ensure(bytes + 16);
+    FA_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (int)N, 0, 32, st));
+    m.uniq_hash.ensure((size_t)N + 1);
+    bytes = 0;
+    FA_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, sorted_hash.p, m.uniq_hash.p, counts.p, num_runs.p, (int)N, st));
+    temp.ensure(bytes + 16);
+    FA_HIP(hipcub::DeviceRunLengthEncode::Encode(temp.p, bytes, sorted_hash.p, m.uniq_hash.p, counts.p, num_runs.p, (int)N, st));
+    int32_t U = 0;
+    num_runs.download(&U, 1, st);
+    FA_HIP(hipStreamSynchronize(st));
+    m.U = U;
+    FA_HIP(hipMemsetAsync(counts.p + U, 0, sizeof(uint32_t), st));
+    m.uniq_off.ensure((size_t)U + 2);
+    bytes = 0;
+    FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, counts.p, m.uniq_off.p, U + 1, st));
+    temp.ensure(bytes + 16);
+    FA_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, counts.p, m.uniq_off.p, U + 1, st));
+    // frequency threshold (computeFreqHist): walk the distinct list lengths from the most frequent down
+    int64_t to_ignore = (int64_t)((float)(int64_t)U * 0.001f / 100);
+    int64_t M = std::min<int64_t>(U, to_ignore + 1);
+    counts_sorted.ensure((size_t)U);
+    bytes = 0;
+    FA_HIP(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, bytes, counts.p, counts_sorted.p, U, 0, 32, st));
+    temp.ensure(bytes + 16);
+    FA_HIP(hipcub::DeviceRadixSort::SortKeysDescending(temp.p, bytes, counts.p, counts_sorted.p, U, 0, 32, st));
+    std::vector<uint32_t> top((size_t)M);
+    counts_sorted.download(top.data(), (size_t)M, st);
+    FA_HIP(hipStreamSynchronize(st));
+    for (int64_t i = 0; i < M;) {
+      int64_t j = i;
+      while (j < M && top[j] == top[i]) j++;
+      if (j == M && M < U) break;   // the run continues past the prefix: sum would exceed to_ignore
+      if (j < to_ignore) { m.freq_threshold = (int)top[i]; i = j; }
+      else if (j == to_ignore) { m.freq_threshold = (int)top[i]; break; }
+      else break;
+    }
+    // directory over the top bits
+    int db = std::min(24, std::max(4, floor_log2(std::max(U, 1)) - 2));
+    m.dir_shift = 32 - db;
+    const int nb = 1 << db;
+    m.dir.ensure((size_t)nb + 2);
+    hipLaunchKernelGGL(k_build_dir, dim3(ceil_div(nb + 1, 256)), dim3(256), 0, st, m.uniq_hash.p, (int64_t)U, m.dir_shift, nb, m.dir.p);
+    hipLaunchKernelGGL(k_link_duplicates, dim3(ceil_div(N, 256)), dim3(256), 0, st, sorted_hash.p, m.pos_ridx.p, N, m.rec_seq.p,
+                       m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
+    FA_HIP(hipGetLastError());
+    FA_HIP(hipStreamSynchronize(st));
+  } else {
+    m.dir_shift = 28;
+    m.dir.ensure(18);
+    FA_HIP(hipMemsetAsync(m.dir.p, 0, 18 * sizeof(uint32_t), st));
+    m.uniq_hash.ensure(2); m.uniq_off.ensure(2);
+    FA_HIP(hipMemsetAsync(m.uniq_off.p, 0, 2 * sizeof(uint32_t), st));
+    FA_HIP(hipStreamSynchronize(st));
+  }
+  m.stats.k = m.P.kmer_size;
+  m.stats.pid = m.P.percentage_identity;
+  m.stats.smax = -1;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// query pipeline over the fragment range [f0, f1) of a resident batch
+// ------------------------------------------------------------------------------------------------------------
+static void ensure_luts(fa_mapper &m, int smax) {
+  if (m.stats.extend(std::max(smax, 1))) {
+    m.d_min_hits.upload(m.stats.min_hits, m.stream);
+    m.d_pass.upload(m.stats.pass_shared, m.stream);
+    m.d_ident.upload(m.stats.ident, m.stream);
+  }
+}
+
+static const uint32_t LDS_SEED_CAP = 32768;   // 128 KiB of seed indices per workgroup at most
+
+// returns the number of rows written at rows_dev[row_base ...]
+static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
+                              int64_t row_base) {
+  hipStream_t st = m.stream;
+  const int64_t f0 = g.genome_frag_lo[g0], f1 = g.genome_frag_lo[g1];
+  const int64_t F = f1 - f0;
+  const int NQ = g1 - g0;
+  m.last_F = F; m.last_f0 = f0; m.last_loci = 0; m.last_genomes = &g;
+  for (int i = 0; i < 6; i++) if (!m.ev[i]) FA_HIP(hipEventCreate(&m.ev[i]));
+  FA_HIP(hipEventRecord(m.ev[0], st));
+  if (F == 0) {
+    for (int i = 1; i < 6; i++) FA_HIP(hipEventRecord(m.ev[i], st));
+    return 0;
+  }
+  FA_REQUIRE(m.P.fragment_length > 20, FA_ERR_UNSUPPORTED, "fragment_length must exceed 20 (the reference bins by fragment_length - 20)");
+  const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
+  const int ntiles = t1 - t0;
+  const int qcap = m.qcap;
+  // ---- K1 + per-fragment sort/unique ----
+  m.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
+  m.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
+  m.sk.tile_count.ensure((size_t)ntiles + 1);
+  launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, m.sk.stage_hash.p, m.sk.stage_wpos.p, m.sk.tile_count.p, st);
+  m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
+  m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
+  m.stats_dev.ensure(4); m.totals.ensure(4); m.counters.ensure(4);
+  FA_HIP(hipMemsetAsync(m.stats_dev.p, 0, 4 * sizeof(int32_t), st));
+  FA_HIP(hipMemsetAsync(m.totals.p, 0, 4 * sizeof(uint64_t), st));
+  FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
+  {
+    QuerySketchArgs a;
+    a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
+    a.tile_count = m.sk.tile_count.p - t0;       // indexed by global tile number
+    a.stage_hash = m.sk.stage_hash.p - (size_t)t0 * TILE;
+    a.stage_wpos = m.sk.stage_wpos.p - (size_t)t0 * TILE;
+    a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = m.stats_dev.p; a.qcap = qcap;
+    a.sort_cap = (int32_t)next_pow2((uint32_t)std::max(qcap, 2));
+    size_t lds = (size_t)a.sort_cap * 4;
+    FA_REQUIRE(lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
+    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), lds, st, a);
+    FA_HIP(hipGetLastError());
+  }
+  FA_HIP(hipEventRecord(m.ev[1], st));
+  // ---- lookup ----
+  const IndexView ix = m.view();
+  {
+    LookupArgs a;
+    a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
+    a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = LDS_SEED_CAP;
+    hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
+    FA_HIP(hipGetLastError());
+  }
+  int32_t h_stats[4];
+  uint64_t h_totals[4];
+  m.stats_dev.download(h_stats, 4, st);
+  m.totals.download(h_totals, 4, st);
+  FA_HIP(hipStreamSynchronize(st));
+  const int smax = h_stats[0];
+  ensure_luts(m, smax);
+  const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1], ovf_words = h_totals[2];
+  FA_REQUIRE(total_seeds < (1ULL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 seed hits in one pass; query fewer genomes per call");
+  m.ovf_buf.ensure((size_t)ovf_words + 4);
+  // ---- L1 (retry with a larger loci capacity if the first guess overflows) ----
+  int64_t l_cap = (int64_t)std::min<uint64_t>(total_seeds, std::max<uint64_t>(1u << 18, total_seeds / 8));
+  uint32_t h_counters[4] = {0, 0, 0, 0};
+  for (int attempt = 0; attempt < 2 && total_seeds > 0; attempt++) {
+    m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap);
+    m.l_group.ensure((size_t)l_cap); m.l_shared.ensure((size_t)l_cap); m.l_pos.ensure((size_t)l_cap);
+    m.group_best.ensure((size_t)l_cap);
+    FA_HIP(hipMemsetAsync(m.l_end.p, 0, (size_t)l_cap * sizeof(int32_t), st));
+    FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
+    L1Args a;
+    a.ix = ix; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p; a.n_seeds = m.n_seeds.p;
+    a.ovf_off = m.ovf_off.p; a.ovf_buf = m.ovf_buf.p; a.min_hits_lut = m.d_min_hits.p;
+    a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+    a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
+    a.lds_seed_cap = LDS_SEED_CAP;
+    uint32_t seed_slots = std::min<uint32_t>(LDS_SEED_CAP, next_pow2((uint32_t)std::max<uint64_t>(max_seeds, 2)));
+    size_t lds = (size_t)seed_slots * 4;
+    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_l1, dim3((unsigned)F), dim3(MAP_THREADS), lds, st, a);
+    FA_HIP(hipGetLastError());
+    m.counters.download(h_counters, 4, st);
+    FA_HIP(hipStreamSynchronize(st));
+    if (!h_counters[2]) break;
+    FA_REQUIRE(attempt == 0, FA_ERR_INTERNAL, "L1 loci capacity overflow after resize");
+    l_cap = (int64_t)total_seeds;
+  }
+  FA_HIP(hipEventRecord(m.ev[2], st));
+  const uint32_t nloci = h_counters[0], ngroups = h_counters[1];
+  m.last_loci = nloci;
+  // ---- L2 ----
+  if (nloci > 0) {
+    FA_HIP(hipMemsetAsync(m.group_best.p, 0, (size_t)ngroups * sizeof(unsigned long long), st));
+    L2Args a;
+    a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
+    a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+    a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
+    a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
+    a.cnt_slots = smax + 1;
+    a.smax_words = (smax + 32) / 32;
+    size_t lds = (size_t)a.cnt_slots * L2_THREADS * 2 + (size_t)a.smax_words * L2_THREADS * 4;
+    lds = (lds + 15) / 16 * 16;
+    FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state (window_size too small for this fragment_length)");
+    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_l2, dim3(ceil_div(nloci, L2_THREADS)), dim3(L2_THREADS), lds, st, a);
+    FA_HIP(hipGetLastError());
+  }
+  FA_HIP(hipEventRecord(m.ev[3], st));
+  // ---- core-genome identity ----
+  const int64_t npairs = (int64_t)NQ * m.G;
+  int64_t nrows = 0;
+  if (nloci > 0 && npairs > 0) {
+    m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1));
+    FA_HIP(hipMemsetAsync(m.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
+    CgiArgs a;
+    a.ix = ix; a.group_best = m.group_best.p; a.counters = m.counters.p; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
+    a.l_pos = m.l_pos.p; a.q_size = m.q_size.p; a.ident_lut = m.d_ident.p;
+    a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = m.bins.p;
+    a.bin_len = m.P.fragment_length - 20;
+    a.query_base = g0;
+    // frag_query holds batch-wide genome numbers; rebase to this pass
+    hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(std::max<uint32_t>(ngroups, 1), 256)), dim3(256), 0, st, a);
+    m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
+    m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
+    hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 128)), dim3(128), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
+                       m.row_count.p, m.row_ident.p);
+    hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
+    FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
+    exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
+    int32_t total_rows = 0;
+    FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
+                       npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
+    FA_HIP(hipGetLastError());
+    FA_HIP(hipEventRecord(m.ev[4], st));
+    FA_HIP(hipStreamSynchronize(st));
+    nrows = total_rows;
+  } else {
+    FA_HIP(hipEventRecord(m.ev[4], st));
+    FA_HIP(hipStreamSynchronize(st));
+  }
+  FA_HIP(hipEventRecord(m.ev[5], st));
+  FA_HIP(hipEventSynchronize(m.ev[5]));
+  float ms;
+  for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, m.ev[i], m.ev[i + 1])); m.last_ms[i] += ms; }
+  FA_HIP(hipEventElapsedTime(&ms, m.ev[0], m.ev[5]));
+  m.last_ms[4] += ms;
+  FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
+  return nrows;
+}
+
+static const int64_t PASS_FRAGMENTS = 48 * 1024;   // fragments mapped per pass (bounds the workspace)
+
+static int64_t run_query(fa_mapper &m, const fa_genomes &g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap, bool rows_device) {
+  require_device();
+  FA_REQUIRE(first >= 0 && count >= 0 && first + count <= g.n_genomes, FA_ERR_INVALID, "genome range out of bounds");
+  for (float &x : m.last_ms) x = 0;
+  fa_cgi_row *dst = rows;
+  if (!rows_device) { m.rows_dev.ensure((size_t)std::max<int64_t>(cap, 1)); dst = m.rows_dev.p; }
+  int64_t nrows = 0;
+  int32_t g0 = first;
+  while (g0 < first + count) {
+    int32_t g1 = g0 + 1;
+    while (g1 < first + count && g.genome_frag_lo[g1 + 1] - g.genome_frag_lo[g0] <= PASS_FRAGMENTS) g1++;
+    // frag_query is batch-wide: the bins of a pass are indexed by (genome - g0), handled through the pointer offset below
+    nrows += run_query_pass(m, g, g0, g1, dst, cap, nrows);
+    g0 = g1;
+  }
+  if (!rows_device && nrows) {
+    FA_HIP(hipMemcpyAsync(rows, m.rows_dev.p, (size_t)nrows * sizeof(fa_cgi_row), hipMemcpyDeviceToHost, m.stream));
+    FA_HIP(hipStreamSynchronize(m.stream));
+  }
+  return nrows;
+}
+
+// pack + cut into fragments + tiles + upload
+static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
+                                                  const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width) {
+  require_device();
+  FA_REQUIRE(width == 1 || width == 2 || width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
+  std::unique_ptr<fa_genomes> g(new fa_genomes());
+  g->P = P;
+  g->n_genomes = n_genomes;
+  g->total_fragments.assign(n_genomes, 0); g->total_length.assign(n_genomes, 0); g->n_short.assign(n_genomes, 0);
+  HostStore hs;
+  hs.protein = P.alphabet_size != 4;
+  std::vector<Tile> tiles;
+  std::vector<int32_t> frag_query, frag_qseq;
+  g->genome_frag_lo.assign((size_t)n_genomes + 1, 0);
+  g->frag_tile_lo.clear();
+  const int frag = P.fragment_length;
+  const int64_t min_len = std::min<int64_t>(std::min(P.window_size, P.kmer_size), frag);
+  int32_t cur = 0;
+  for (int64_t c = 0; c < n_contigs; c++) {
+    int32_t gi = contig_genome ? contig_genome[c] : 0;
+    FA_REQUIRE(gi >= cur && gi < n_genomes, FA_ERR_INVALID, "contig_genome must be non-decreasing and < n_genomes");
+    while (cur < gi) { cur++; g->genome_frag_lo[cur] = (int64_t)frag_query.size(); }
+    const int64_t len = lengths[c];
+    if (len < min_len) { g->n_short[gi]++; continue; }               // _fastani.pyx:1061-1070
+    const int64_t nfrag = len / frag;                                 // :1097
+    if (nfrag > 0) {
+      int64_t si = hs.append(contigs[c], width, nfrag * frag);        // the tail past the last whole fragment is never read
+      for (int64_t i = 0; i < nfrag; i++) {
+        g->frag_tile_lo.push_back((int32_t)tiles.size());
+        make_tiles(tiles, hs, hs.seq_off[si] + i * frag, frag, (int)frag_query.size(), P.kmer_size, P.window_size);
+        frag_qseq.push_back((int32_t)(g->total_fragments[gi] + i));   // :985
+        frag_query.push_back(gi);
+      }
+    }
+    g->total_fragments[gi] += (uint64_t)nfrag;                        // :1104
+    g->total_length[gi] += (uint64_t)len;                             // :1105
+    g->total_bases += (uint64_t)(nfrag * frag);
+  }
+  while (cur < n_genomes) { cur++; g->genome_frag_lo[cur] = (int64_t)frag_query.size(); }
+  g->F = (int64_t)frag_query.size();
+  g->frag_tile_lo.push_back((int32_t)tiles.size());
+  g->ntiles = (int64_t)tiles.size();
+  g->store.upload(hs, st);
+  g->tiles.upload(tiles, st);
+  g->d_frag_tile_lo.upload(g->frag_tile_lo, st);
+  // the CGI bins of a pass are indexed by the genome number relative to the first genome of the pass; passes start at
+  // genome boundaries, so store per-fragment genome numbers and let the kernel subtract via the bins pointer offset
+  g->d_frag_query.upload(frag_query, st);
+  g->d_frag_qseq.upload(frag_qseq, st);
+  std::vector<int32_t> tf(n_genomes);
+  for (int i = 0; i < n_genomes; i++) tf[i] = (int32_t)g->total_fragments[i];
+  g->d_total_frag.upload(tf, st);
+  FA_HIP(hipStreamSynchronize(st));
+  return g;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char *fa_last_error(void) { return g_last_error.c_str(); }
+int fa_version(void) { return 100; }
+
+int fa_device_count(int *count) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+  *count = n;
+  return FA_OK;
+}
+int fa_set_device(int device) {
+  return guarded([&] { require_device(); FA_HIP(hipSetDevice(device)); });
+}
+
+int fa_recommended_window_size(double p_value, int k, int alphabet_size, float identity, int fragment_length,
+                               uint64_t reference_size, int *window) {
+  return guarded([&] { *window = stat_recommended_window(p_value, k, alphabet_size, identity, fragment_length, reference_size); });
+}
+int fa_estimate_minimum_hits_relaxed(int s, int k, float identity, int *hits) {
+  return guarded([&] { *hits = stat_min_hits_relaxed(s, k, identity); });
+}
+int fa_mapping_identity(int shared, int s, int k, float *identity, float *upper) {
+  return guarded([&] { FA_REQUIRE(s > 0, FA_ERR_INVALID, "sketch_size must be positive"); stat_identity(shared, s, k, identity, upper); });
+}
+
+// host twin of the device hash (same published algorithm as fa_sketch.hip.h's Murmur)
+uint32_t fa_hash(const void *kmer, int len) {
+  const uint8_t *d = (const uint8_t *)kmer;
+  auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+  auto fmix = [](uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k; };
+  const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+  uint64_t h1 = 42, h2 = 42;
+  int nb = len / 16;
+  for (int i = 0; i < nb; i++) {
+    uint64_t k1, k2;
+    memcpy(&k1, d + 16 * i, 8); memcpy(&k2, d + 16 * i + 8, 8);
+    k1 *= c1; k1 = rotl(k1, 31); k1 *= c2; h1 ^= k1; h1 = rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= c2; k2 = rotl(k2, 33); k2 *= c1; h2 ^= k2; h2 = rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  const uint8_t *t = d + 16 * nb;
+  int rem = len & 15;
+  uint64_t k1 = 0, k2 = 0;
+  for (int j = 0; j < rem; j++) { if (j < 8) k1 |= (uint64_t)t[j] << (8 * j); else k2 |= (uint64_t)t[j] << (8 * (j - 8)); }
+  if (rem > 8) { k2 *= c2; k2 = rotl(k2, 33); k2 *= c1; h2 ^= k2; }
+  if (rem > 0) { k1 *= c1; k1 = rotl(k1, 31); k1 *= c2; h1 ^= k1; }
+  h1 ^= (uint64_t)len; h2 ^= (uint64_t)len; h1 += h2; h2 += h1; h1 = fmix(h1); h2 = fmix(h2);
+  return (uint32_t)(h1 + h2);
+}
+
+int fa_sketch_new(const fa_params *params, fa_sketch **out) {
+  return guarded([&] {
+    validate_params(*params);
+    std::unique_ptr<fa_sketch> s(new fa_sketch());
+    s->P = *params;
+    s->reset_data();
+    *out = s.release();
+  });
+}
+void fa_sketch_free(fa_sketch *s) {
+  if (!s) return;
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+int fa_sketch_add_contig(fa_sketch *s, const void *data, int64_t length, int char_width, int *added) {
+  return guarded([&] {
+    FA_REQUIRE(char_width == 1 || char_width == 2 || char_width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
+    FA_REQUIRE(length >= 0 && length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
+    std::lock_guard<std::mutex> lock(s->mtx);
+    int ok = 0;
+    if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
+      s->pending.append(data, char_width, length);
+      s->pending_contig.push_back((int32_t)s->counter);
+      ok = 1;
+    }
+    s->cur_total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
+    s->counter += 1;                                                                     // :683
+    if (added) *added = ok;
+  });
+}
+int fa_sketch_end_genome(fa_sketch *s) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    s->lengths.push_back(s->cur_total);                  // :687
+    s->cur_total = 0;
+    s->seqs_by_file.push_back((int32_t)s->counter);      // :690
+  });
+}
+int fa_sketch_clear(fa_sketch *s) {
+  return guarded([&] { std::lock_guard<std::mutex> lock(s->mtx); s->reset_data(); });
+}
+int fa_sketch_num_minimizers(fa_sketch *s, int64_t *n) {
+  return guarded([&] { std::lock_guard<std::mutex> lock(s->mtx); s->flush(); *n = s->nrec; });
+}
+int fa_sketch_get_minimizers(fa_sketch *s, uint32_t *hash, int32_t *seq_id, int32_t *wpos) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    s->flush();
+    if (s->nrec == 0) return;
+    s->rec_hash.download(hash, (size_t)s->nrec, s->stream);
+    s->rec_seq.download(seq_id, (size_t)s->nrec, s->stream);
+    s->rec_wpos.download(wpos, (size_t)s->nrec, s->stream);
+    FA_HIP(hipStreamSynchronize(s->stream));
+  });
+}
+int fa_sketch_num_genomes(fa_sketch *s, int64_t *n) {
+  return guarded([&] { *n = (int64_t)s->lengths.size(); });
+}
+int fa_sketch_get_state(fa_sketch *s, uint64_t *lengths, int32_t *sbf, int64_t *counter) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    for (size_t i = 0; i < s->lengths.size(); i++) { lengths[i] = s->lengths[i]; sbf[i] = s->seqs_by_file[i]; }
+    *counter = s->counter;
+  });
+}
+int fa_sketch_set_state(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths, const int32_t *sbf, int64_t counter,
+                        int64_t n_min, const uint32_t *hash, const int32_t *seq_id, const int32_t *wpos) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    s->reset_data();
+    s->lengths.assign(lengths, lengths + n_genomes);
+    s->seqs_by_file.assign(sbf, sbf + n_genomes);
+    s->counter = counter;
+    if (n_min > 0) {
+      require_device();
+      if (!s->stream) FA_HIP(hipStreamCreate(&s->stream));
+      s->rec_hash.upload(hash, (size_t)n_min, s->stream);
+      s->rec_seq.upload(seq_id, (size_t)n_min, s->stream);
+      s->rec_wpos.upload(wpos, (size_t)n_min, s->stream);
+      FA_HIP(hipStreamSynchronize(s->stream));
+    }
+    s->nrec = n_min;
+  });
+}
+
+int fa_sketch_index(fa_sketch *s, fa_mapper **out) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    require_device();
+    s->flush();
+    std::unique_ptr<fa_mapper> m(new fa_mapper());
+    m->P = s->P;
+    FA_HIP(hipStreamCreate(&m->stream));
+    m->rec_hash = std::move(s->rec_hash);
+    m->rec_seq = std::move(s->rec_seq);
+    m->rec_wpos = std::move(s->rec_wpos);
+    m->N = s->nrec;
+    m->rec_hash.ensure((size_t)m->N + 4, true, m->stream, (size_t)m->N);
+    m->rec_seq.ensure((size_t)m->N + 4, true, m->stream, (size_t)m->N);
+    m->rec_wpos.ensure((size_t)m->N + 4, true, m->stream, (size_t)m->N);
+    m->lengths = s->lengths;
+    m->seqs_by_file = s->seqs_by_file;
+    if (!m->seqs_by_file.empty() && m->seqs_by_file.back() < (int32_t)s->counter) {
+      // contigs added after the last end_genome belong to no genome; keep the tables consistent
+      m->seqs_by_file.back() = (int32_t)s->counter;
+    }
+    build_index(*m);
+    s->reset_data();                                     // _fastani.pyx:803-804
+    *out = m.release();
+  });
+}
+
+void fa_mapper_free(fa_mapper *m) {
+  if (!m) return;
+  for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  delete m;
+}
+int fa_mapper_freq_threshold(fa_mapper *m, int *thr) { *thr = m->freq_threshold; return FA_OK; }
+int fa_mapper_lookup_size(fa_mapper *m, int64_t *n) { *n = m->U; return FA_OK; }
+int fa_mapper_lookup_keys(fa_mapper *m, uint32_t *keys) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    m->uniq_hash.download(keys, (size_t)m->U, m->stream);
+    FA_HIP(hipStreamSynchronize(m->stream));
+  });
+}
+static int64_t host_find(fa_mapper *m, uint32_t hash, uint32_t *off, uint32_t *cnt) {
+  // binary search with single-element reads (introspection path, not performance critical)
+  int64_t lo = 0, hi = m->U;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) / 2;
+    uint32_t v;
+    FA_HIP(hipMemcpy(&v, m->uniq_hash.p + mid, 4, hipMemcpyDeviceToHost));
+    if (v < hash) lo = mid + 1; else hi = mid;
+  }
+  if (lo >= m->U) return -1;
+  uint32_t v, o[2];
+  FA_HIP(hipMemcpy(&v, m->uniq_hash.p + lo, 4, hipMemcpyDeviceToHost));
+  if (v != hash) return -1;
+  FA_HIP(hipMemcpy(o, m->uniq_off.p + lo, 8, hipMemcpyDeviceToHost));
+  *off = o[0]; *cnt = o[1] - o[0];
+  return lo;
+}
+int fa_mapper_lookup_count(fa_mapper *m, uint32_t hash, int64_t *count) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    uint32_t off, cnt;
+    *count = host_find(m, hash, &off, &cnt) < 0 ? -1 : (int64_t)cnt;
+  });
+}
+int fa_mapper_lookup_get(fa_mapper *m, uint32_t hash, int32_t *seq_id, int32_t *wpos, int64_t cap) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    uint32_t off, cnt;
+    FA_REQUIRE(host_find(m, hash, &off, &cnt) >= 0, FA_ERR_INVALID, "hash not in the lookup index");
+    std::vector<uint32_t> ridx(cnt);
+    FA_HIP(hipMemcpy(ridx.data(), m->pos_ridx.p + off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < cnt && (int64_t)i < cap; i++) {
+      FA_HIP(hipMemcpy(&seq_id[i], m->rec_seq.p + ridx[i], 4, hipMemcpyDeviceToHost));
+      FA_HIP(hipMemcpy(&wpos[i], m->rec_wpos.p + ridx[i], 4, hipMemcpyDeviceToHost));
+    }
+  });
+}
+int fa_mapper_num_minimizers(fa_mapper *m, int64_t *n) { *n = m->N; return FA_OK; }
+int fa_mapper_get_minimizers(fa_mapper *m, uint32_t *hash, int32_t *seq_id, int32_t *wpos) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    if (m->N == 0) return;
+    m->rec_hash.download(hash, (size_t)m->N, m->stream);
+    m->rec_seq.download(seq_id, (size_t)m->N, m->stream);
+    m->rec_wpos.download(wpos, (size_t)m->N, m->stream);
+    FA_HIP(hipStreamSynchronize(m->stream));
+  });
+}
+int fa_mapper_num_genomes(fa_mapper *m, int64_t *n) { *n = (int64_t)m->lengths.size(); return FA_OK; }
+int fa_mapper_get_state(fa_mapper *m, uint64_t *lengths, int32_t *sbf) {
+  for (size_t i = 0; i < m->lengths.size(); i++) { lengths[i] = m->lengths[i]; sbf[i] = m->seqs_by_file[i]; }
+  return FA_OK;
+}
+
+int fa_genomes_upload(fa_mapper *m, const void *const *contigs, const int64_t *lengths, const int32_t *contig_genome,
+                      int64_t n_contigs, int32_t n_genomes, int char_width, fa_genomes **out) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    *out = upload_genomes(m->P, m->stream, contigs, lengths, contig_genome, n_contigs, n_genomes, char_width).release();
+  });
+}
+void fa_genomes_free(fa_genomes *g) { delete g; }
+int fa_genomes_info(fa_genomes *g, int32_t *n_genomes, uint64_t *tf, uint64_t *tl, int32_t *ns) {
+  if (n_genomes) *n_genomes = g->n_genomes;
+  for (int i = 0; i < g->n_genomes; i++) {
+    if (tf) tf[i] = g->total_fragments[i];
+    if (tl) tl[i] = g->total_length[i];
+    if (ns) ns[i] = g->n_short[i];
+  }
+  return FA_OK;
+}
+int fa_mapper_query_genomes(fa_mapper *m, fa_genomes *g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap,
+                            int64_t *n_rows, int rows_device) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    *n_rows = run_query(*m, *g, first, count, rows, cap, rows_device != 0);
+  });
+}
+int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *lengths, int n_contigs, int char_width,
+                    fa_cgi_row *rows, int64_t cap, int64_t *n_rows, int *n_short, uint64_t *total_fragments,
+                    uint64_t *total_length) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    std::vector<int32_t> cg((size_t)std::max(n_contigs, 1), 0);
+    auto g = upload_genomes(m->P, m->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width);
+    if (n_short) *n_short = g->n_short[0];
+    if (total_fragments) *total_fragments = g->total_fragments[0];
+    if (total_length) *total_length = g->total_length[0];
+    *n_rows = run_query(*m, *g, 0, 1, rows, cap, false);
+    m->last_genomes = nullptr;
+  });
+}
+
+int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t *n) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    const uint32_t L = m->last_loci;
+    std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)m->last_F);
+    if (L) {
+      m->l_frag.download(lf.data(), L, m->stream); m->l_seq.download(ls.data(), L, m->stream);
+      m->l_pos.download(lp.data(), L, m->stream); m->l_shared.download(lsh.data(), L, m->stream);
+    }
+    if (m->last_F) m->q_size.download(qs.data(), (size_t)m->last_F, m->stream);
+    FA_HIP(hipStreamSynchronize(m->stream));
+    ensure_luts(*m, 1);
+    int64_t k = 0;
+    for (uint32_t i = 0; i < L; i++) {
+      int s = qs[lf[i]];
+      if (lsh[i] < m->stats.pass_shared[s]) continue;
+      if (k < cap) {
+        fa_mapping r;
+        r.query_seq_id = lf[i]; r.ref_seq_id = ls[i]; r.ref_start_pos = lp[i]; r.sketch_size = s; r.conserved = lsh[i]; r.query_id = 0;
+        out[k] = r;
+      }
+      k++;
+    }
+    *n = k;
+  });
+}
+int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *rs, int32_t *re, int64_t cap, int64_t *n) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    const uint32_t L = m->last_loci;
+    *n = L;
+    size_t c = (size_t)std::min<int64_t>(L, cap);
+    if (c) {
+      m->l_frag.download(frag, c, m->stream); m->l_seq.download(seq_id, c, m->stream);
+      m->l_start.download(rs, c, m->stream); m->l_end.download(re, c, m->stream);
+      FA_HIP(hipStreamSynchronize(m->stream));
+    }
+  });
+}
+int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashes, int32_t cap, int32_t *sketch_size) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    FA_REQUIRE(fragment >= 0 && fragment < m->last_F, FA_ERR_INVALID, "fragment out of range");
+    int32_t s = 0;
+    FA_HIP(hipMemcpy(&s, m->q_size.p + fragment, 4, hipMemcpyDeviceToHost));
+    *sketch_size = s;
+    int c = std::min(s, cap);
+    if (c > 0) FA_HIP(hipMemcpy(hashes, m->q_hash.p + (size_t)fragment * m->qcap, (size_t)c * 4, hipMemcpyDeviceToHost));
+  });
+}
+int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t length, int char_width, uint32_t *hash,
+                             int32_t *wpos, int64_t cap, int64_t *n) {
+  return guarded([&] {
+    validate_params(*params);
+    fa_sketch s;
+    s.P = *params;
+    s.reset_data();
+    if (length >= params->kmer_size) {
+      s.pending.append(data, char_width, length);
+      s.pending_contig.push_back(0);
+    }
+    s.flush();
+    *n = s.nrec;
+    size_t c = (size_t)std::min<int64_t>(s.nrec, cap);
+    if (c) {
+      s.rec_hash.download(hash, c, s.stream);
+      s.rec_wpos.download(wpos, c, s.stream);
+      FA_HIP(hipStreamSynchronize(s.stream));
+    }
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+  });
+}
+
+int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {
+  for (int i = 0; i < n && i < 8; i++) ms[i] = m->last_ms[i];
+  return FA_OK;
+}
+int fa_mapper_stream(fa_mapper *m, void **stream) { *stream = (void *)m->stream; return FA_OK; }
+
+int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_per_launch, uint64_t *bases, uint64_t *minimizers) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    require_device();
+    const int ntiles = (int)g->ntiles;
+    FA_REQUIRE(ntiles > 0 && repeat > 0, FA_ERR_INVALID, "nothing to sketch");
+    m->sk.stage_hash.ensure((size_t)ntiles * TILE);
+    m->sk.stage_wpos.ensure((size_t)ntiles * TILE);
+    m->sk.tile_count.ensure((size_t)ntiles + 1);
+    hipEvent_t e0, e1;
+    FA_HIP(hipEventCreate(&e0)); FA_HIP(hipEventCreate(&e1));
+    launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, m->sk.stage_hash.p, m->sk.stage_wpos.p, m->sk.tile_count.p, m->stream);
+    FA_HIP(hipEventRecord(e0, m->stream));
+    for (int i = 0; i < repeat; i++)
+      launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, m->sk.stage_hash.p, m->sk.stage_wpos.p, m->sk.tile_count.p, m->stream);
+    FA_HIP(hipEventRecord(e1, m->stream));
+    FA_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    FA_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / repeat;
+    std::vector<int32_t> counts((size_t)ntiles);
+    m->sk.tile_count.download(counts.data(), (size_t)ntiles, m->stream);
+    FA_HIP(hipStreamSynchronize(m->stream));
+    uint64_t tot = 0;
+    for (int c : counts) tot += (uint64_t)c;
+    *minimizers = tot;
+    *bases = g->total_bases;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,622 @@
+// fa_map.hip.h -- index construction and the fragment mapper (lookup, L1, L2, core-genome identity) on gfx950.
+//
+// What it replaces (reference = pyfastani + the FastANI C++ it links):
+//   skch::Sketch::index / computeFreqHist / searchIndex   include/fastani/map/win_sketch.pxd:38-41
+//   Mapper._do_l1_mappings                                src/pyfastani/_fastani.pyx:885-954
+//   skch::Map::computeL1CandidateRegions                  include/fastani/map/compute_map.pxd:33
+//   skch::Map::doL2Mapping / computeL2MappedRegions       compute_map.pxd:34-35 (+ slidingMap.hpp, MIIteratorL2.hpp)
+//   cgi::computeCGI                                       include/fastani/cgi/compute_core_identity.pxd:28-37
+//
+// HBM layout of an indexed reference (all SoA, resident for the life of the mapper)
+//   rec_hash/rec_seq/rec_wpos[N]   the minimizer records in (contig, window) order  = skch::Sketch::minimizerIndex
+//   rec_prev[N]                    index of the previous record of the same contig with the same hash, or -1
+//   rec_flags[N]                   bit0: the previous same-hash record is still inside the L2 super-window when this one
+//                                  is admitted; bit1: the next same-hash record is admitted before this one is dropped
+//   uniq_hash[U], uniq_off[U+1]    sorted distinct hashes and CSR offsets into pos_ridx = minimizerPosLookupIndex
+//   pos_ridx[N]                    record indices grouped by hash, ascending inside a group
+//   dir[2^DB + 1]                  first entry of uniq_hash per top-DB-bits bucket (shortens the binary search)
+//   contig_rec[C+1], contig_genome[C], contig_bin[C+1], genome_bin[G+1]
+//
+// Query side, per batch of fragments: q_hash[F*QCAP] sorted distinct query minimizers, q_size[F] = sketchSize.
+#pragma once
+
+#include "fa_common.h"
+#include "fa_sketch.hip.h"
+
+namespace fa {
+
+constexpr int MAP_THREADS = 256;
+constexpr uint32_t SEED_PAD = 0xFFFFFFFFu;
+
+// ----------------------------------------------------------------------------------------------------------
+// in-place bitonic sort of n32 (power of two) uint32 keys by one workgroup; works on LDS or global memory
+// ----------------------------------------------------------------------------------------------------------
+__device__ inline void block_bitonic_sort(uint32_t *a, uint32_t n32) {
+  for (uint32_t size = 2; size <= n32; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < n32 / 2; t += blockDim.x) {
+        uint32_t lo = 2 * t - (t & (stride - 1));
+        uint32_t hi = lo + stride;
+        bool up = (lo & size) == 0;
+        uint32_t x = a[lo], y = a[hi];
+        if ((x > y) == up) { a[lo] = y; a[hi] = x; }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// query fragments: gather the staged records of a fragment's tiles, apply the leading-run rule, sort by hash,
+// drop duplicates (std::sort + std::unique of _fastani.pyx:929-936).  One workgroup per fragment.
+// ----------------------------------------------------------------------------------------------------------
+struct QuerySketchArgs {
+  const int32_t *frag_tile_lo;  // [F+1]
+  const int32_t *tile_count;
+  const uint32_t *stage_hash;
+  const int32_t *stage_wpos;
+  uint32_t *q_hash;             // [F * qcap]
+  int32_t *q_size;              // [F]
+  int32_t *stats;               // [0] max sketch size
+  int32_t qcap;
+  int32_t sort_cap;             // power of two >= max records of a fragment
+};
+
+__global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  uint32_t *buf = (uint32_t *)lds;                 // [sort_cap]
+  __shared__ int sh_n, sh_drop, sh_total;
+  __shared__ uint32_t sh_h0;
+  __shared__ int sh_wpos0;
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int t0 = a.frag_tile_lo[f], t1 = a.frag_tile_lo[f + 1];
+  // gather in order
+  int n = 0;
+  for (int t = t0; t < t1; t++) {
+    int c = a.tile_count[t];
+    for (int i = tid; i < c; i += blockDim.x) buf[n + i] = a.stage_hash[(size_t)t * TILE + i];
+    if (n == 0 && c > 0 && tid == 0) { sh_h0 = a.stage_hash[(size_t)t * TILE]; sh_wpos0 = a.stage_wpos[(size_t)t * TILE]; }
+    n += c;
+  }
+  if (tid == 0) { sh_drop = n; }
+  __syncthreads();
+  // leading run: records 1..d equal to record 0's hash are dropped when record 0 sits at window 0
+  if (n > 1 && sh_wpos0 == 0) {
+    uint32_t h0 = sh_h0;
+    int first_diff = n;
+    for (int i = 1 + tid; i < n; i += blockDim.x) if (buf[i] != h0) { first_diff = i; break; }
+    atomicMin(&sh_drop, first_diff);
+    __syncthreads();
+    int d = sh_drop - 1;
+    __syncthreads();
+    if (d > 0) {
+      // overwrite the dropped records with copies of record 0 (duplicates vanish in the unique step)
+      for (int i = 1 + tid; i <= d; i += blockDim.x) buf[i] = h0;
+    }
+  }
+  __syncthreads();
+  uint32_t n32 = 1;
+  while (n32 < (uint32_t)n) n32 <<= 1;
+  if (n32 < 2) n32 = 2;
+  for (uint32_t i = n + tid; i < n32; i += blockDim.x) buf[i] = SEED_PAD;
+  __syncthreads();
+  // NOTE: a real hash may equal SEED_PAD (protein mode); count how many real entries carry that value
+  block_bitonic_sort(buf, n32);
+  // unique: keep buf[i] if i == 0 or differs from predecessor, among the first n sorted entries
+  if (tid == 0) { sh_n = 0; sh_total = 0; }
+  __syncthreads();
+  uint32_t *out = a.q_hash + (size_t)f * a.qcap;
+  for (int base = 0; base < n; base += blockDim.x) {
+    int i = base + tid;
+    bool keep = i < n && (i == 0 || buf[i] != buf[i - 1]);
+    uint64_t bal = __ballot(keep);
+    __shared__ int wave_cnt[MAP_THREADS / 64];
+    int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = sh_total;
+    for (int q = 0; q < wv; q++) off += wave_cnt[q];
+    if (keep) out[off + __popcll(bal & ((1ULL << lane) - 1ULL))] = buf[i];
+    __syncthreads();
+    if (tid == 0) { int tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += wave_cnt[q]; sh_total += tot; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.q_size[f] = sh_total;
+    atomicMax(&a.stats[0], sh_total);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// index construction helpers (the radix sort / run-length / scan primitives come from hipCUB)
+// ----------------------------------------------------------------------------------------------------------
+__global__ void k_iota(uint32_t *a, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (uint32_t)i;
+}
+
+// dir[b] = first u with (uniq_hash[u] >> shift) >= b, for b in 0..nb (dir[nb] = U)
+__global__ void k_build_dir(const uint32_t *uniq_hash, int64_t U, int shift, int nb, uint32_t *dir) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb) return;
+  if (b == nb) { dir[b] = (uint32_t)U; return; }
+  uint64_t key = (uint64_t)b << shift;
+  int64_t lo = 0, hi = U;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((uint64_t)uniq_hash[mid] < key) lo = mid + 1; else hi = mid; }
+  dir[b] = (uint32_t)lo;
+}
+
+// contig_rec[c] = first record with rec_seq >= c
+__global__ void k_contig_ranges(const int32_t *rec_seq, int64_t N, int C, int32_t *contig_rec) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  int64_t lo = 0, hi = N;
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (rec_seq[mid] < c) lo = mid + 1; else hi = mid; }
+  contig_rec[c] = (int32_t)lo;
+}
+
+// rec_prev / rec_flags from the hash-grouped order.  A record i of contig q is inside the L2 super-window at window
+// position p for p in [a_i, b_i], a_i = wpos_i - cmw + 1, b_i = wpos_{i+1} - 1 (next record of the contig; +inf for
+// the last one).  Two consecutive same-hash records (j, i) are `linked` when b_j >= a_i - 1: the hash never leaves
+// the window between them, so admitting i / dropping j must not change the set (slidingMap.hpp REV / NOOP cases).
+constexpr uint8_t FLAG_INS_LINKED = 1, FLAG_DEL_LINKED = 2;
+__global__ void k_link_duplicates(const uint32_t *sorted_hash, const uint32_t *pos_ridx, int64_t N, const int32_t *rec_seq,
+                                  const int32_t *rec_wpos, int cmw, int32_t *rec_prev, uint8_t *rec_flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  uint32_t cur = pos_ridx[i];
+  int32_t prev = -1;
+  if (i > 0 && sorted_hash[i - 1] == sorted_hash[i]) {
+    uint32_t p = pos_ridx[i - 1];
+    if (rec_seq[p] == rec_seq[cur]) prev = (int32_t)p;
+  }
+  rec_prev[cur] = prev;
+  if (prev >= 0) {
+    // prev + 1 <= cur exists and lies in the same contig (records of a contig are contiguous)
+    int64_t b_prev = (int64_t)rec_wpos[prev + 1] - 1;
+    int64_t a_cur = (int64_t)rec_wpos[cur] - cmw + 1;
+    if (b_prev >= a_cur - 1) {
+      atomicOr((unsigned int *)(rec_flags + (cur & ~3u)), (unsigned int)FLAG_INS_LINKED << (8 * (cur & 3u)));
+      atomicOr((unsigned int *)(rec_flags + ((uint32_t)prev & ~3u)), (unsigned int)FLAG_DEL_LINKED << (8 * ((uint32_t)prev & 3u)));
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// resident index view passed to the mapping kernels
+// ----------------------------------------------------------------------------------------------------------
+struct IndexView {
+  const uint32_t *rec_hash;
+  const int32_t *rec_seq;
+  const int32_t *rec_wpos;
+  const int32_t *rec_prev;
+  const uint8_t *rec_flags;
+  const uint32_t *uniq_hash;
+  const uint32_t *uniq_off;
+  const uint32_t *pos_ridx;
+  const uint32_t *dir;
+  const int32_t *contig_rec;
+  const int32_t *contig_genome;
+  const int32_t *contig_bin;
+  const int32_t *genome_bin;
+  int64_t N, U;
+  int32_t C, G;
+  int32_t dir_shift;
+  int32_t freq_threshold;
+  int32_t total_bins;
+};
+
+__device__ __forceinline__ int64_t index_find(const IndexView &ix, uint32_t h) {
+  uint32_t b = h >> ix.dir_shift;
+  int64_t lo = ix.dir[b], hi = ix.dir[b + 1];
+  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ix.uniq_hash[mid] < h) lo = mid + 1; else hi = mid; }
+  return (lo < ix.U && ix.uniq_hash[lo] == h) ? lo : -1;
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// lookup: for every query minimizer its position list in the index, frequency-filtered (_fastani.pyx:941-948)
+// ----------------------------------------------------------------------------------------------------------
+struct LookupArgs {
+  IndexView ix;
+  const uint32_t *q_hash;
+  const int32_t *q_size;
+  uint32_t *q_off;       // [F*qcap] start of the list in pos_ridx
+  uint32_t *q_cnt;       // [F*qcap] list length (0 when absent or too frequent)
+  uint32_t *n_seeds;     // [F]
+  uint64_t *totals;      // [0] sum of seeds, [1] max seeds of a fragment, [2] overflow scratch words
+  uint32_t *ovf_off;     // [F] offset into the overflow scratch for fragments whose seeds do not fit LDS
+  int32_t qcap;
+  uint32_t lds_seed_cap;
+};
+
+__global__ __launch_bounds__(MAP_THREADS) void k_lookup(LookupArgs a) {
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int s = a.q_size[f];
+  __shared__ uint32_t red[MAP_THREADS / 64];
+  uint32_t mine = 0;
+  for (int j = tid; j < s; j += blockDim.x) {
+    uint32_t h = a.q_hash[(size_t)f * a.qcap + j];
+    int64_t u = index_find(a.ix, h);
+    uint32_t off = 0, cnt = 0;
+    if (u >= 0) {
+      off = a.ix.uniq_off[u];
+      cnt = a.ix.uniq_off[u + 1] - off;
+      if ((int64_t)cnt >= (int64_t)a.ix.freq_threshold) cnt = 0;   // strict `size < threshold` keeps the list
+    }
+    a.q_off[(size_t)f * a.qcap + j] = off;
+    a.q_cnt[(size_t)f * a.qcap + j] = cnt;
+    mine += cnt;
+  }
+  for (int d = 32; d > 0; d >>= 1) mine += __shfl_down(mine, d);
+  if ((tid & 63) == 0) red[tid >> 6] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t n = 0;
+    for (int q = 0; q < MAP_THREADS / 64; q++) n += red[q];
+    a.n_seeds[f] = n;
+    atomicAdd((unsigned long long *)&a.totals[0], (unsigned long long)n);
+    atomicMax((unsigned long long *)&a.totals[1], (unsigned long long)n);
+    uint32_t off = 0;
+    if (n > a.lds_seed_cap) {
+      uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
+      off = (uint32_t)atomicAdd((unsigned long long *)&a.totals[2], (unsigned long long)n32);
+    }
+    a.ovf_off[f] = off;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// L1: gather + sort the seed hits of a fragment, scan for >= minHits hits inside one fragment length, merge
+// overlapping candidates (computeL1CandidateRegions).  One workgroup per fragment; loci are appended to global
+// arrays in (fragment-local) order, and consecutive loci on the same reference genome share a `group`.
+// ----------------------------------------------------------------------------------------------------------
+struct L1Args {
+  IndexView ix;
+  const int32_t *q_size;
+  const uint32_t *q_off;
+  const uint32_t *q_cnt;
+  const uint32_t *n_seeds;
+  const uint32_t *ovf_off;
+  uint32_t *ovf_buf;
+  const int32_t *min_hits_lut;   // [smax+1]
+  int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
+  uint32_t *counters;            // [0] loci, [1] groups, [2] loci overflow flag
+  int32_t qcap, frag_len, l_cap;
+  uint32_t lds_seed_cap;
+};
+
+__global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  __shared__ uint32_t sh_scan[MAP_THREADS / 64];
+  __shared__ uint32_t sh_run;       // running offset (gather) / running head count
+  __shared__ int sh_prev_seq, sh_prev_wa, sh_has_prev;
+  __shared__ uint32_t sh_base, sh_gbase;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = a.q_size[f];
+  const uint32_t n = a.n_seeds[f];
+  if (s == 0 || n == 0) return;
+  uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
+  if (n32 < 2) n32 = 2;
+  uint32_t *seeds = (n <= a.lds_seed_cap) ? (uint32_t *)lds : a.ovf_buf + a.ovf_off[f];
+
+  // ---- gather the position lists (ordered by query hash; order is irrelevant before the sort) ----
+  if (tid == 0) sh_run = 0;
+  __syncthreads();
+  for (int j0 = 0; j0 < s; j0 += blockDim.x) {
+    int j = j0 + tid;
+    uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
+    uint32_t incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) sh_scan[wv] = incl;
+    __syncthreads();
+    uint32_t off = sh_run + incl - cnt;
+    for (int q = 0; q < wv; q++) off += sh_scan[q];
+    if (cnt) {
+      uint32_t src = a.q_off[(size_t)f * a.qcap + j];
+      for (uint32_t t = 0; t < cnt; t++) seeds[off + t] = a.ix.pos_ridx[src + t];
+    }
+    __syncthreads();
+    if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+    __syncthreads();
+  }
+  for (uint32_t i = n + tid; i < n32; i += blockDim.x) seeds[i] = SEED_PAD;
+  __syncthreads();
+  // a record index identifies (seqId, wpos) and the record array is ordered by it: sorting indices == std::sort of hits
+  block_bitonic_sort(seeds, n32);
+
+  int m = a.min_hits_lut[s];
+  if (m < 1) m = 1;
+  if ((uint32_t)m > n) return;
+  const uint32_t ncand = n - (uint32_t)m + 1;
+  const int len = a.frag_len;
+
+  // ---- two ordered passes over the candidates: 0 = count merged loci, 1 = write them ----
+  for (int pass = 0; pass < 2; pass++) {
+    if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < ncand; i0 += blockDim.x) {
+      uint32_t i = i0 + tid;
+      bool flag = false;
+      int seq = -1, wa = 0, start = 0;
+      if (i < ncand) {
+        uint32_t ra = seeds[i], rb = seeds[i + m - 1];
+        seq = a.ix.rec_seq[ra];
+        int seqb = a.ix.rec_seq[rb];
+        wa = a.ix.rec_wpos[ra];
+        int wb = a.ix.rec_wpos[rb];
+        if (seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
+      }
+      // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
+      uint64_t bal = __ballot(flag);
+      __shared__ int w_last_seq[MAP_THREADS / 64], w_last_wa[MAP_THREADS / 64], w_any[MAP_THREADS / 64];
+      uint64_t below = bal & ((1ULL << lane) - 1ULL);
+      int src_lane = below ? 63 - __clzll(below) : -1;
+      int p_seq = __shfl(seq, src_lane < 0 ? 0 : src_lane), p_wa = __shfl(wa, src_lane < 0 ? 0 : src_lane);
+      if (lane == 0) w_any[wv] = bal != 0;
+      if (bal && lane == 63 - __clzll(bal)) { w_last_seq[wv] = seq; w_last_wa[wv] = wa; }
+      __syncthreads();
+      bool has_prev = src_lane >= 0;
+      if (!has_prev) {
+        for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[q]) { has_prev = true; p_seq = w_last_seq[q]; p_wa = w_last_wa[q]; }
+        if (!has_prev && sh_has_prev) { has_prev = true; p_seq = sh_prev_seq; p_wa = sh_prev_wa; }
+      }
+      bool head = flag && !(has_prev && p_seq == seq && p_wa >= start);
+      // inclusive scan of heads -> slot of the locus every flagged candidate belongs to
+      uint64_t hb = __ballot(head);
+      __shared__ uint32_t w_heads[MAP_THREADS / 64];
+      if (lane == 0) w_heads[wv] = __popcll(hb);
+      __syncthreads();
+      uint32_t slot = sh_run + __popcll(hb & ((2ULL << lane) - 1ULL));
+      for (int q = 0; q < wv; q++) slot += w_heads[q];
+      if (pass == 1 && flag) {
+        uint32_t li = sh_base + slot - 1;
+        if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; }
+        atomicMax(&a.l_end[li], wa);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t tot = 0;
+        for (int q = 0; q < MAP_THREADS / 64; q++) tot += w_heads[q];
+        sh_run += tot;
+        for (int q = MAP_THREADS / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_seq = w_last_seq[q]; sh_prev_wa = w_last_wa[q]; break; }
+      }
+      __syncthreads();
+    }
+    if (pass == 0) {
+      if (tid == 0) {
+        uint32_t cnt = sh_run;
+        uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
+        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); cnt = 0; }
+        sh_base = base;
+        sh_gbase = cnt;   // reuse: number of loci (0 => skip)
+      }
+      __syncthreads();
+      if (sh_gbase == 0) return;
+    }
+  }
+  // ---- groups: consecutive loci of this fragment on the same reference genome ----
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t nl = sh_gbase, base = sh_base;
+  if (wv == 0) {
+    uint32_t run = 0, gbase = 0;
+    // count groups first
+    for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+      uint32_t i = i0 + lane;
+      bool gh = false;
+      if (i < nl) {
+        int g = a.ix.contig_genome[a.l_seq[base + i]];
+        gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
+      }
+      run += __popcll(__ballot(gh));
+    }
+    if (lane == 0) gbase = atomicAdd(&a.counters[1], run);
+    gbase = __shfl(gbase, 0);
+    run = 0;
+    for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+      uint32_t i = i0 + lane;
+      bool gh = false;
+      if (i < nl) {
+        int g = a.ix.contig_genome[a.l_seq[base + i]];
+        gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
+      }
+      uint64_t gb = __ballot(gh);
+      if (i < nl) a.l_group[base + i] = (int32_t)(gbase + run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1);
+      run += __popcll(gb);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// L2: slide the fragment-long super-window over one candidate locus and keep the best winnowed-MinHash
+// intersection (computeL2MappedRegions + SlideMapper + MIIteratorL2).  One lane per locus.
+//
+// The reference keeps an ordered map over Q u W with a pivot at the s-th smallest hash.  Here the same quantity
+// lives in rank space: every reference hash is reduced (binary search in the sorted query sketch) to either the
+// rank r of the query hash it matches, or -- for a hash absent from Q -- the number c of query hashes below it.
+// With cnt[c] = distinct window-only hashes of insertion rank c and f(r) = r + sum_{c<=r} cnt[c], query rank r is
+// among the s smallest of the union iff f(r) < s, so shared = #{matched r < r*}, r* = min{r : f(r) >= s}.
+// r* moves by at most one per inserted / deleted hash, exactly like the reference's pivot.
+// ----------------------------------------------------------------------------------------------------------
+struct L2Args {
+  IndexView ix;
+  const uint32_t *q_hash;
+  const int32_t *q_size;
+  const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;
+  int32_t *l_shared, *l_pos;
+  const int32_t *pass_lut;           // [smax+1]
+  unsigned long long *group_best;    // [groups] (shared<<32 | ~locus)
+  const uint32_t *counters;          // [0] number of loci
+  int32_t qcap, cmw, smax_words;     // smax_words = ceil((smax+1)/32)
+  int32_t cnt_slots;                 // smax + 1
+};
+
+constexpr int L2_THREADS = 64;
+
+__global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  // per-lane arrays, lane-interleaved so that a lane's own element never collides with another lane's bank
+  uint16_t *cnt = (uint16_t *)lds;                                         // [cnt_slots][64]
+  uint32_t *mbit = (uint32_t *)(lds + (size_t)a.cnt_slots * L2_THREADS * 2);   // [smax_words][64]
+  const int lane = threadIdx.x;
+  const uint32_t l = blockIdx.x * L2_THREADS + lane;
+  const uint32_t nloci = min(a.counters[0], 0x7FFFFFFFu);
+  if (l >= nloci) return;
+  const int f = a.l_frag[l];
+  const int s = a.q_size[f];
+  const uint32_t *Q = a.q_hash + (size_t)f * a.qcap;
+  const int seq = a.l_seq[l];
+  const int lo = a.ix.contig_rec[seq], hi = a.ix.contig_rec[seq + 1];
+  const int32_t *wpos = a.ix.rec_wpos;
+  auto lower = [&](int target) {
+    int x = lo, y = hi;
+    while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+    return x;
+  };
+  int beg = lower(a.l_start[l]);
+  int p = wpos[beg];
+  int end = lower(p + a.cmw);
+  const int last = lower(a.l_end[l] + a.cmw);
+  for (int i = 0; i <= s; i++) cnt[i * L2_THREADS + lane] = 0;
+  for (int i = 0; i < (s + 32) / 32; i++) mbit[i * L2_THREADS + lane] = 0;
+
+  int rstar = s, P = 0, shared = 0;
+  auto rank_of = [&](uint32_t h, bool &found) {
+    int x = 0, y = s;
+    while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
+    found = x < s && Q[x] == h;
+    return x;
+  };
+  auto test = [&](int r) { return (mbit[(r >> 5) * L2_THREADS + lane] >> (r & 31)) & 1u; };
+  auto insert = [&](int i) {
+    bool found; int r = rank_of(a.ix.rec_hash[i], found);
+    if (found) {
+      mbit[(r >> 5) * L2_THREADS + lane] |= 1u << (r & 31);
+      if (r < rstar) shared++;
+    } else {
+      cnt[r * L2_THREADS + lane] += 1;
+      if (r < rstar) {
+        P++;
+        if (rstar - 1 + P >= s) {            // f(r*-1) reached s: the largest query rank falls out of the first s
+          rstar--;
+          P -= cnt[rstar * L2_THREADS + lane];
+          if (test(rstar)) shared--;
+        }
+      }
+    }
+  };
+  auto remove = [&](int i) {
+    bool found; int r = rank_of(a.ix.rec_hash[i], found);
+    if (found) {
+      mbit[(r >> 5) * L2_THREADS + lane] &= ~(1u << (r & 31));
+      if (r < rstar) shared--;
+    } else {
+      cnt[r * L2_THREADS + lane] -= 1;
+      if (r < rstar) P--;
+      if (rstar < s && rstar + P + (int)cnt[rstar * L2_THREADS + lane] < s) {
+        P += cnt[rstar * L2_THREADS + lane];
+        if (test(rstar)) shared++;
+        rstar++;
+      }
+    }
+  };
+
+  // first super-window: distinct hashes among records [beg, end)
+  for (int i = beg; i < end; i++) if (a.ix.rec_prev[i] < beg) insert(i);
+  int best = shared, opt_s = wpos[beg], opt_e = opt_s;
+  while (end < last) {
+    // next window position at which a record is dropped or admitted
+    int next_drop = (beg + 1 < hi) ? wpos[beg + 1] : 0x7FFFFFFF;
+    int next_admit = wpos[end] - a.cmw + 1;
+    p = max(p + 1, min(next_drop, next_admit));
+    if (next_drop <= p) { if (!(a.ix.rec_flags[beg] & FLAG_DEL_LINKED)) remove(beg); beg++; }
+    if (wpos[end] <= p + a.cmw - 1) { if (!(a.ix.rec_flags[end] & FLAG_INS_LINKED)) insert(end); end++; }
+    if (shared > best) { best = shared; opt_s = opt_e = wpos[beg]; }
+    else if (shared == best) opt_e = wpos[beg];
+  }
+  a.l_shared[l] = best;
+  a.l_pos[l] = (opt_s + opt_e) / 2;
+  if (best >= a.pass_lut[s]) {
+    unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)(0xFFFFFFFFu - l);
+    atomicMax(&a.group_best[a.l_group[l]], key);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// computeCGI.  Step 1 (best mapping per reference genome and query fragment) is the group maximum taken by
+// k_l2.  Step 2 (best mapping per reference bin) is an atomicMax into a dense table of bins; step 3 walks the
+// bins of every (query genome, reference genome) pair in order and averages in float32, as the reference does.
+// Tie-breaks are the canonical ones of DESIGN.md: equal identity -> smaller (refSeqId, refStartPos) in step 1,
+// smaller querySeqId in step 2.
+// ----------------------------------------------------------------------------------------------------------
+struct CgiArgs {
+  IndexView ix;
+  const unsigned long long *group_best;
+  const uint32_t *counters;     // [1] number of groups
+  const int32_t *l_frag, *l_seq, *l_pos;
+  const int32_t *q_size;
+  const float *ident_lut;       // triangular
+  const int32_t *frag_query;    // [F] query genome (batch-local) of a fragment
+  const int32_t *frag_qseq;     // [F] fragment number inside its query genome (querySeqId)
+  unsigned long long *bins;     // [NQ * total_bins]
+  int32_t bin_len;              // fragment_length - 20
+  int32_t query_base;           // first query genome of this pass (frag_query is batch-wide)
+};
+
+__global__ void k_cgi_bins(CgiArgs a) {
+  uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= a.counters[1]) return;
+  unsigned long long best = a.group_best[g];
+  if (best == 0) return;
+  uint32_t l = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);
+  int shared = (int)(best >> 32);
+  int f = a.l_frag[l];
+  int s = a.q_size[f];
+  float ident = a.ident_lut[(size_t)s * (size_t)(s + 1) / 2 + shared];
+  int seq = a.l_seq[l];
+  int bin = a.ix.contig_bin[seq] + a.l_pos[l] / a.bin_len;
+  unsigned long long key = ((unsigned long long)__float_as_uint(ident) << 32) |
+                           (unsigned long long)(0xFFFFFFFFu - (uint32_t)a.frag_qseq[f]);
+  atomicMax(&a.bins[(size_t)(a.frag_query[f] - a.query_base) * a.ix.total_bins + bin], key);
+}
+
+__global__ void k_cgi_rows(const unsigned long long *bins, const int32_t *genome_bin, int total_bins, int G, int NQ,
+                           int32_t *row_count, float *row_ident) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)NQ * G) return;
+  int q = (int)(i / G), g = (int)(i % G);
+  const unsigned long long *b = bins + (size_t)q * total_bins;
+  int cnt = 0;
+  float sum = 0.0f;
+  for (int x = genome_bin[g]; x < genome_bin[g + 1]; x++) {
+    unsigned long long v = b[x];
+    if (v) { cnt++; sum += __uint_as_float((uint32_t)(v >> 32)); }
+  }
+  row_count[i] = cnt;
+  row_ident[i] = cnt ? sum / (float)cnt : 0.0f;
+}
+
+// ordered compaction of the non-empty (query, genome) pairs into fa_cgi_row records
+__global__ void k_emit_rows(const int32_t *row_count, const float *row_ident, const int32_t *row_off, int G, int64_t n,
+                            const int32_t *query_total_frag, int32_t query_id_base, fa_cgi_row *rows, int64_t cap) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || row_count[i] == 0) return;
+  int64_t o = row_off[i];
+  if (o >= cap) return;
+  int q = (int)(i / G);
+  fa_cgi_row r;
+  r.query_id = query_id_base + q;
+  r.ref_genome_id = (int32_t)(i % G);
+  r.count_seq = row_count[i];
+  r.total_query_fragments = query_total_frag[q];
+  r.identity = row_ident[i];
+  rows[o] = r;
+}
+
+__global__ void k_flag_nonzero(const int32_t *row_count, int64_t n, int32_t *flag) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = row_count[i] != 0;
+}
+
+}  // namespace fa

@@ -1,0 +1,500 @@
+// fa_sketch.hip.h -- K1: winnowed-minimizer extraction on gfx950, plus the host packer that feeds it.
+//
+// What it replaces: skch::CommonFunc::addMinimizers as adapted by pyfastani
+// (src/pyfastani/_fastani.pyx:156-222 nucleotide, :252-309 protein) together with getHash
+// (include/fastani/map/common_func.pxd:12) and the upper-case / reverse-complement helpers
+// (src/pyfastani/_sequtils/sequtils.cpp:22-90).
+//
+// HBM layout of a sequence store
+//   packed[]   2-bit codes (A=0 C=1 G=2 T=3), 16 bases per uint32, little-end first; every sequence starts on a
+//              64-base (16-byte) boundary.  Bytes that are not ACGT (after upper-casing) are stored as code 0 and
+//              listed in exc_pos[] / exc_val[] (sorted store offsets + the upper-cased byte).
+//   bytes[]    protein mode only: the upper-cased residues, 1 byte each.
+//   A *tile* is up to TILE consecutive k-mer positions of one sequence (a reference contig, or one query
+//   fragment); one workgroup sketches one tile.
+//
+// Algorithm per tile (all in LDS, no atomics, no MFMA -- this is integer hashing):
+//   1. stage the packed words of the tile (+ halo of 2w-2 k-mer positions + k-1 bases) with coalesced loads;
+//   2. every lane rebuilds the k ASCII bytes of its k-mer from the 2-bit codes in registers
+//      (spread + v_perm_b32), hashes both strands with MurmurHash3_x64_128(seed 42), takes the canonical minimum
+//      and flags strand-symmetric k-mers as invalid (_fastani.pyx:202);
+//   3. keys (hash<<32 | ~position) go to LDS; log2(w) doubling passes build a sparse table so that the minimum of
+//      any length-w window is two LDS reads -- the argmin is the right-most minimum, as the reference's deque
+//      keeps (_fastani.pyx:211-212 pops on >=);
+//   4. a record is emitted where the window argmin differs from the argmin at the previous valid position
+//      (= the deque front changed, _fastani.pyx:219-222); wave ballots + popcount prefix give ordered compaction.
+// The one sequential quirk of the reference -- a new front whose hash equals the first emitted record is
+// suppressed while that record's wpos is 0 (_fastani.pyx:216,220) -- is resolved per sequence afterwards
+// (k_suppress_runs) because it only ever affects the leading run of records of a sequence.
+#pragma once
+
+#include "fa_common.h"
+
+namespace fa {
+
+constexpr int TILE = 2048;         // k-mer positions per workgroup
+constexpr int SK_THREADS = 256;
+constexpr int SK_ITERS = TILE / SK_THREADS;
+
+struct Tile {
+  int64_t base;     // store offset (in bases / residues) of the first base of the sequence
+  int32_t seq_len;  // sequence length
+  int32_t pos0;     // first k-mer position of the tile, sequence-local
+  int32_t npos;     // k-mer positions in the tile (1..TILE)
+  int32_t seq;      // sequence number (contig id, or fragment number)
+  int32_t exc_lo;   // first exception inside the tile's base span
+  int32_t exc_n;    // number of exceptions inside the span (0 => fast 2-bit path)
+};
+static_assert(sizeof(Tile) == 32, "tile descriptor layout");
+
+// ----------------------------------------------------------------------------------------------------------
+// host: upper-casing, complement, packing (replaces copy_upper / reverse_complement of _sequtils)
+// ----------------------------------------------------------------------------------------------------------
+inline uint8_t host_upper(uint8_t c) { return (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c; }
+
+inline uint8_t host_read(const void *data, int width, int64_t i) {
+  switch (width) {
+    case 1: return ((const uint8_t *)data)[i];
+    case 2: return (uint8_t)((const uint16_t *)data)[i];
+    default: return (uint8_t)((const uint32_t *)data)[i];
+  }
+}
+
+// Host image of a sequence store, appended to contig by contig and uploaded in one go.
+struct HostStore {
+  bool protein = false;
+  std::vector<uint32_t> packed;   // nucleotide
+  std::vector<uint8_t> bytes;     // protein
+  std::vector<int64_t> exc_pos;
+  std::vector<uint8_t> exc_val;
+  std::vector<int64_t> seq_off;   // store offset of each sequence
+  std::vector<int64_t> seq_len;
+  int64_t total = 0;              // store length in bases (multiple of 64)
+
+  void clear() {
+    packed.clear(); bytes.clear(); exc_pos.clear(); exc_val.clear(); seq_off.clear(); seq_len.clear(); total = 0;
+  }
+
+  // appends one sequence; returns its index
+  int64_t append(const void *data, int width, int64_t len) {
+    static const uint8_t code_of[256] = {
+#define X4(v) v, v, v, v
+#define X16(v) X4(v), X4(v), X4(v), X4(v)
+        X16(4), X16(4), X16(4), X16(4),                               // 0x00-0x3f
+        4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,               // @ A B C D E F G H I J K L M N O
+        4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,               // P Q R S T ...
+        4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,               // ` a b c d e f g ...
+        4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,               // p q r s t ...
+        X16(4), X16(4), X16(4), X16(4), X16(4), X16(4), X16(4), X16(4)  // 0x80-0xff
+#undef X16
+#undef X4
+    };
+    int64_t off = total;
+    seq_off.push_back(off);
+    seq_len.push_back(len);
+    int64_t padded = (len + 63) / 64 * 64;
+    if (protein) {
+      size_t o = bytes.size();
+      bytes.resize(o + (size_t)padded, 0);
+      for (int64_t i = 0; i < len; i++) bytes[o + i] = host_upper(host_read(data, width, i));
+    } else {
+      size_t o = packed.size();
+      packed.resize(o + (size_t)(padded / 16), 0u);
+      uint32_t *dst = packed.data() + o;
+      if (width == 1) {
+        const uint8_t *src = (const uint8_t *)data;
+        for (int64_t i = 0; i < len; i++) {
+          uint8_t c = code_of[src[i]];
+          if (c > 3) { exc_pos.push_back(off + i); exc_val.push_back(host_upper(src[i])); c = 0; }
+          dst[i >> 4] |= (uint32_t)c << ((i & 15) * 2);
+        }
+      } else {
+        for (int64_t i = 0; i < len; i++) {
+          uint8_t ch = host_read(data, width, i);
+          uint8_t c = code_of[ch];
+          if (c > 3) { exc_pos.push_back(off + i); exc_val.push_back(host_upper(ch)); c = 0; }
+          dst[i >> 4] |= (uint32_t)c << ((i & 15) * 2);
+        }
+      }
+    }
+    total += padded;
+    return (int64_t)seq_off.size() - 1;
+  }
+};
+
+// Device image of a sequence store.
+struct DevStore {
+  bool protein = false;
+  DevBuf<uint32_t> packed;
+  DevBuf<uint8_t> bytes;
+  DevBuf<int64_t> exc_pos;
+  DevBuf<uint8_t> exc_val;
+  int64_t n_exc = 0;
+  int64_t total = 0;
+  void upload(const HostStore &h, hipStream_t st) {
+    protein = h.protein;
+    total = h.total;
+    n_exc = (int64_t)h.exc_pos.size();
+    if (protein) {
+      bytes.ensure(h.bytes.size() + 64);
+      bytes.upload(h.bytes.data(), h.bytes.size(), st);
+    } else {
+      packed.ensure(h.packed.size() + 16);
+      packed.upload(h.packed.data(), h.packed.size(), st);
+      if (n_exc) { exc_pos.upload(h.exc_pos, st); exc_val.upload(h.exc_val, st); }
+    }
+  }
+};
+
+// Appends the tiles of one sequence slice [off, off+len) (a whole contig, or one query fragment).
+inline void make_tiles(std::vector<Tile> &tiles, const HostStore &hs, int64_t off, int64_t len, int seq, int k, int w) {
+  int64_t npos_total = len - k + 1;
+  if (npos_total <= 0) return;
+  for (int64_t p0 = 0; p0 < npos_total; p0 += TILE) {
+    Tile t;
+    t.base = off; t.seq_len = (int32_t)len; t.pos0 = (int32_t)p0;
+    t.npos = (int32_t)std::min<int64_t>(TILE, npos_total - p0);
+    t.seq = seq; t.exc_lo = 0; t.exc_n = 0;
+    if (!hs.exc_pos.empty()) {
+      int64_t hb = std::min<int64_t>(p0, 2 * (int64_t)w - 2);
+      int64_t lo = off + p0 - hb, hi = off + p0 + t.npos + k - 1;  // base span [lo, hi)
+      auto a = std::lower_bound(hs.exc_pos.begin(), hs.exc_pos.end(), lo);
+      auto b = std::lower_bound(a, hs.exc_pos.end(), hi);
+      t.exc_lo = (int32_t)(a - hs.exc_pos.begin());
+      t.exc_n = (int32_t)(b - a);
+    }
+    tiles.push_back(t);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// device: MurmurHash3_x64_128, seed 42, low 32 bits (getHash)
+// ----------------------------------------------------------------------------------------------------------
+struct Murmur {
+  uint64_t h1, h2;
+  __device__ __forceinline__ static uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+  __device__ __forceinline__ static uint64_t fmix(uint64_t k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+  }
+  __device__ __forceinline__ void init() { h1 = 42; h2 = 42; }
+  __device__ __forceinline__ void mix1(uint64_t k1) {
+    k1 *= 0x87c37b91114253d5ULL; k1 = rotl(k1, 31); k1 *= 0x4cf5ad432745937fULL; h1 ^= k1;
+  }
+  __device__ __forceinline__ void mix2(uint64_t k2) {
+    k2 *= 0x4cf5ad432745937fULL; k2 = rotl(k2, 33); k2 *= 0x87c37b91114253d5ULL; h2 ^= k2;
+  }
+  __device__ __forceinline__ void block(uint64_t k1, uint64_t k2) {
+    mix1(k1);
+    h1 = rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    mix2(k2);
+    h2 = rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+  }
+  __device__ __forceinline__ void tail(uint64_t k1, uint64_t k2, int rem) {
+    if (rem > 8) mix2(k2);
+    if (rem > 0) mix1(k1);
+  }
+  __device__ __forceinline__ uint32_t finish(int len) {
+    h1 ^= (uint64_t)len; h2 ^= (uint64_t)len;
+    h1 += h2; h2 += h1;
+    h1 = fmix(h1); h2 = fmix(h2);
+    return (uint32_t)(h1 + h2);
+  }
+};
+
+// 4 two-bit codes (8 bits) -> 4 ASCII bytes "ACGT"[code], first base in the low byte
+__device__ __forceinline__ uint32_t expand4(uint32_t x) {
+  uint32_t t = (x | (x << 12)) & 0x000F000Fu;
+  t = (t | (t << 6)) & 0x03030303u;
+  return __builtin_amdgcn_perm(0u, 0x54474341u, t);  // selector bytes 0..3 pick 'A','C','G','T'
+}
+__device__ __forceinline__ uint64_t expand8(uint32_t x16) {
+  return (uint64_t)expand4(x16 & 0xFFu) | ((uint64_t)expand4((x16 >> 8) & 0xFFu) << 32);
+}
+// reverse complement of 16 packed codes: code j of the result = 3 - code (15-j) of the input
+__device__ __forceinline__ uint32_t revcomp16(uint32_t f) {
+  uint32_t x = __brev(~f);
+  return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+// 16 codes starting at base offset b of the LDS image
+__device__ __forceinline__ uint32_t get16(const uint32_t *codes, int b) {
+  int idx = b >> 4, sh = (b & 15) * 2;
+  return __funnelshift_r(codes[idx], codes[idx + 1], sh);
+}
+__device__ __forceinline__ uint64_t bytemask(int n) {  // low n bytes set, n in 0..8
+  return n >= 8 ? ~0ULL : ((1ULL << (8 * n)) - 1ULL);
+}
+
+// canonical hash of the k-mer at base offset b of a 2-bit LDS image; returns false for strand-symmetric k-mers
+template <int KT>
+__device__ __forceinline__ bool hash_codes(const uint32_t *codes, int b, int k_rt, uint32_t &out) {
+  const int k = KT ? KT : k_rt;
+  const int nblocks = k >> 4, rem = k & 15;
+  Murmur f, r;
+  f.init(); r.init();
+  for (int bi = 0; bi < nblocks; bi++) {
+    uint32_t cf = get16(codes, b + 16 * bi);
+    f.block(expand8(cf & 0xFFFFu), expand8(cf >> 16));
+    uint32_t cr = revcomp16(get16(codes, b + k - 16 * (bi + 1)));
+    r.block(expand8(cr & 0xFFFFu), expand8(cr >> 16));
+  }
+  if (rem) {
+    uint32_t cf = get16(codes, b + 16 * nblocks);
+    uint64_t m1 = bytemask(rem < 8 ? rem : 8), m2 = bytemask(rem > 8 ? rem - 8 : 0);
+    f.tail(expand8(cf & 0xFFFFu) & m1, expand8(cf >> 16) & m2, rem);
+    uint32_t cr = revcomp16(get16(codes, b)) >> (2 * (16 - rem));
+    r.tail(expand8(cr & 0xFFFFu) & m1, expand8(cr >> 16) & m2, rem);
+  }
+  uint32_t hf = f.finish(k), hb = r.finish(k);
+  out = hf < hb ? hf : hb;
+  return hf != hb;
+}
+
+// scalar complement of an upper-cased byte: A<->T, C<->G, IUPAC pairs, everything else unchanged
+// (semantics of the reference's scalar table, src/pyfastani/_sequtils/complement.h)
+__device__ __forceinline__ uint32_t complement_byte(uint32_t c) {
+  switch (c) {
+    case 'A': return 'T'; case 'T': return 'A'; case 'C': return 'G'; case 'G': return 'C';
+    case 'R': return 'Y'; case 'Y': return 'R'; case 'K': return 'M'; case 'M': return 'K';
+    case 'B': return 'V'; case 'V': return 'B'; case 'D': return 'H'; case 'H': return 'D';
+    default: return c;
+  }
+}
+
+// byte-image variant (protein residues, or nucleotide tiles that contain non-ACGT bytes)
+__device__ __forceinline__ bool hash_bytes(const uint8_t *bytes, int b, int k, bool protein, uint32_t &out) {
+  const int nblocks = k >> 4, rem = k & 15;
+  Murmur f, r;
+  f.init(); r.init();
+  for (int bi = 0; bi <= nblocks; bi++) {
+    int n = bi < nblocks ? 16 : rem;
+    if (n == 0) break;
+    uint64_t k1 = 0, k2 = 0, q1 = 0, q2 = 0;
+    for (int j = 0; j < n; j++) {
+      uint64_t c = bytes[b + 16 * bi + j];
+      if (j < 8) k1 |= c << (8 * j); else k2 |= c << (8 * (j - 8));
+      if (!protein) {
+        uint64_t d = complement_byte(bytes[b + k - 1 - (16 * bi + j)]);
+        if (j < 8) q1 |= d << (8 * j); else q2 |= d << (8 * (j - 8));
+      }
+    }
+    if (bi < nblocks) { f.block(k1, k2); if (!protein) r.block(q1, q2); }
+    else { f.tail(k1, k2, rem); if (!protein) r.tail(q1, q2, rem); }
+  }
+  uint32_t hf = f.finish(k);
+  if (protein) { out = hf; return true; }
+  uint32_t hb = r.finish(k);
+  out = hf < hb ? hf : hb;
+  return hf != hb;
+}
+
+struct SketchArgs {
+  const Tile *tiles;
+  const uint32_t *packed;
+  const uint8_t *bytes;
+  const int64_t *exc_pos;
+  const uint8_t *exc_val;
+  uint32_t *stage_hash;   // [ntiles * TILE]
+  int32_t *stage_wpos;    // [ntiles * TILE]
+  int32_t *tile_count;    // [ntiles]
+  int32_t k, w, levels;   // levels = floor(log2(w))
+  int32_t protein;
+  int32_t code_words;     // LDS words reserved for the 2-bit image / byte image
+  int32_t npos_cap;       // LDS key slots: TILE + 2w - 2
+};
+
+// LDS carve-up (dynamic): [image: code_words*4 B][keyA: npos_cap*8][keyB: npos_cap*8][valid: (npos_cap/64+1)*8]
+//                         [emit: (TILE/64)*8][prefix: (TILE/64+1)*4]
+inline size_t sketch_lds_bytes(int k, int w) {
+  size_t npos_cap = (size_t)TILE + 2 * (size_t)w - 2;
+  size_t span = npos_cap + (size_t)k - 1 + 64;            // bases (or bytes) staged, with slack for get16 over-read
+  size_t image = ((span + 3) / 4 + 4) * 4;                // byte image is the larger of the two
+  image = (image + 15) / 16 * 16;
+  return image + npos_cap * 16 + (npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16;
+}
+
+template <int KT>
+__global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(SketchArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const Tile t = a.tiles[blockIdx.x];
+  const int k = KT ? KT : a.k, w = a.w;
+
+  uint32_t *codes = (uint32_t *)lds;
+  uint8_t *img = (uint8_t *)lds;
+  uint64_t *keyA = (uint64_t *)(lds + (size_t)a.code_words * 4);
+  uint64_t *keyB = keyA + a.npos_cap;
+  uint64_t *valid = keyB + a.npos_cap;
+  uint64_t *emit = valid + (a.npos_cap / 64 + 1);
+  uint32_t *prefix = (uint32_t *)(emit + TILE / 64);
+
+  const int hb = min(t.pos0, 2 * w - 2);          // halo of k-mer positions in front of the tile
+  const int jlo = t.pos0 - hb;                    // first k-mer position computed (sequence-local)
+  const int npt = hb + t.npos;                    // k-mer positions computed
+  const int nb = npt + k - 1;                     // bases staged
+  const int64_t base0 = t.base + jlo;             // store offset of the first staged base
+  const bool byte_mode = a.protein || t.exc_n > 0;
+  int shift = 0;
+
+  // ---- 1. stage the sequence image ----
+  if (a.protein) {
+    for (int i = tid; i < nb; i += SK_THREADS) img[i] = a.bytes[base0 + i];
+  } else {
+    const int64_t w0 = base0 >> 4;
+    shift = (int)(base0 & 15);
+    const int nwords = (shift + nb + 15) / 16 + 1;
+    if (!byte_mode) {
+      for (int i = tid; i < nwords; i += SK_THREADS) codes[i] = a.packed[w0 + i];
+    } else {
+      // expand to bytes, then patch the non-ACGT bytes back in
+      for (int i = tid; i < nb; i += SK_THREADS) {
+        int64_t g = base0 + i;
+        uint32_t c = (a.packed[g >> 4] >> ((g & 15) * 2)) & 3u;
+        img[i] = (uint8_t)((0x54474341u >> (8 * c)) & 0xFFu);
+      }
+      __syncthreads();
+      for (int e = tid; e < t.exc_n; e += SK_THREADS) {
+        int64_t p = a.exc_pos[t.exc_lo + e] - base0;
+        if (p >= 0 && p < nb) img[p] = a.exc_val[t.exc_lo + e];
+      }
+      shift = 0;
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. hash both strands, canonical minimum, validity ----
+  for (int j0 = 0; j0 < npt; j0 += SK_THREADS) {
+    int j = j0 + tid;
+    bool ok = false;
+    uint32_t h = 0xFFFFFFFFu;
+    if (j < npt) {
+      if (byte_mode) ok = hash_bytes(img, j, k, a.protein != 0, h);
+      else ok = hash_codes<KT>(codes, shift + j, k, h);
+    }
+    uint64_t key = ok ? (((uint64_t)h << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)j)) : ~0ULL;
+    uint64_t bal = __ballot(ok);
+    if (j < a.npos_cap) keyA[j] = key;
+    if (lane == 0 && (j0 / 64 + wave) <= a.npos_cap / 64) valid[j0 / 64 + wave] = bal;
+  }
+  __syncthreads();
+
+  // ---- 3. sparse table: after `levels` doubling passes X[j] = min key over [j, j + 2^levels) ----
+  uint64_t *X = keyA, *Y = keyB;
+  for (int lv = 0; lv < a.levels; lv++) {
+    const int step = 1 << lv;
+    for (int j = tid; j < npt; j += SK_THREADS) {
+      uint64_t v = X[j];
+      if (j + step < npt) { uint64_t u = X[j + step]; v = u < v ? u : v; }
+      Y[j] = v;
+    }
+    __syncthreads();
+    uint64_t *tmp = X; X = Y; Y = tmp;
+  }
+  const int span = 1 << a.levels;                 // span <= w < 2*span
+
+  // ---- 4. emission: the window argmin changed since the previous valid position ----
+  const int first_check = (w - 1) - jlo;          // tile-local index of sequence position w-1
+  uint32_t rec_hash[SK_ITERS];
+  bool rec_emit[SK_ITERS];
+#pragma unroll
+  for (int it = 0; it < SK_ITERS; it++) {
+    const int tt = it * SK_THREADS + tid;         // tile position
+    const int il = hb + tt;                       // tile-local index incl. halo
+    bool em = false;
+    uint32_t hsh = 0;
+    if (tt < t.npos && il >= first_check && ((valid[il >> 6] >> (il & 63)) & 1ULL)) {
+      uint64_t a1 = X[il - w + 1], a2 = X[il - span + 1];
+      uint64_t cur = a1 < a2 ? a1 : a2;
+      hsh = (uint32_t)(cur >> 32);
+      // previous valid position that was itself checked, within the last w-1 positions
+      int lo = max(first_check, il - w + 1), prev = -1;
+      for (int q = il - 1; q >= lo; q--) {
+        if ((valid[q >> 6] >> (q & 63)) & 1ULL) { prev = q; break; }
+      }
+      if (prev < 0) em = true;
+      else {
+        uint64_t b1 = X[prev - w + 1], b2 = X[prev - span + 1];
+        uint64_t old = b1 < b2 ? b1 : b2;
+        em = (uint32_t)old != (uint32_t)cur;      // low words hold ~position of the argmin
+      }
+    }
+    rec_hash[it] = hsh;
+    rec_emit[it] = em;
+    uint64_t bal = __ballot(em);
+    if (lane == 0) emit[it * (SK_THREADS / 64) + wave] = bal;
+  }
+  __syncthreads();
+
+  // ---- 5. ordered compaction ----
+  if (wave == 0) {
+    int c = lane < TILE / 64 ? __popcll(emit[lane]) : 0;
+    int incl = c;
+    for (int d = 1; d < 64; d <<= 1) { int o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane < TILE / 64) prefix[lane] = incl - c;
+    if (lane == TILE / 64 - 1) { prefix[TILE / 64] = incl; a.tile_count[blockIdx.x] = incl; }
+  }
+  __syncthreads();
+  const size_t out0 = (size_t)blockIdx.x * TILE;
+#pragma unroll
+  for (int it = 0; it < SK_ITERS; it++) {
+    if (rec_emit[it]) {
+      int word = it * (SK_THREADS / 64) + wave;
+      uint64_t below = emit[word] & ((1ULL << lane) - 1ULL);
+      size_t o = out0 + prefix[word] + __popcll(below);
+      a.stage_hash[o] = rec_hash[it];
+      a.stage_wpos[o] = t.pos0 + it * SK_THREADS + tid - w + 1;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// the leading-run quirk: if the first record of a sequence has wpos 0, the records that directly follow it with
+// the same hash were never emitted by the reference (their wpos field is still 0, so they compare equal to
+// minimizerIndex.back(), _fastani.pyx:216,220).  drop[s] = length of that run.
+// ----------------------------------------------------------------------------------------------------------
+__global__ void k_suppress_runs(const int32_t *seq_tile_lo, int nseq, const int32_t *tile_count, const uint32_t *stage_hash,
+                                const int32_t *stage_wpos, int32_t *drop) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseq) return;
+  int t0 = seq_tile_lo[s], t1 = seq_tile_lo[s + 1];
+  int d = 0;
+  bool have_first = false, done = false;
+  uint32_t h0 = 0;
+  for (int t = t0; t < t1 && !done; t++) {
+    int c = tile_count[t];
+    size_t o = (size_t)t * TILE;
+    for (int i = 0; i < c; i++) {
+      if (!have_first) {
+        if (stage_wpos[o + i] != 0) { done = true; break; }
+        h0 = stage_hash[o + i];
+        have_first = true;
+      } else if (stage_hash[o + i] == h0) d++;
+      else { done = true; break; }
+    }
+  }
+  drop[s] = d;
+}
+
+// copies the staged records of every tile to their final, position-ordered place (reference-side sketching)
+__global__ __launch_bounds__(256) void k_compact_records(const Tile *tiles, const int32_t *tile_count, const int32_t *tile_off,
+                                                         const int32_t *seq_tile_lo, const int32_t *drop,
+                                                         const int32_t *drop_off, const uint32_t *stage_hash,
+                                                         const int32_t *stage_wpos, const int32_t *seq_ids, int64_t out_base,
+                                                         uint32_t *rec_hash, int32_t *rec_seq, int32_t *rec_wpos) {
+  const int t = blockIdx.x;
+  const int s = tiles[t].seq;
+  const int c = tile_count[t];
+  const int first = tile_off[t] - tile_off[seq_tile_lo[s]];   // records of this sequence before the tile
+  const int d = drop[s];
+  const int64_t seq_out = out_base + tile_off[seq_tile_lo[s]] - drop_off[s];
+  for (int i = threadIdx.x; i < c; i += blockDim.x) {
+    int r = first + i;
+    if (r >= 1 && r <= d) continue;
+    int64_t o = seq_out + (r > d ? r - d : r);
+    rec_hash[o] = stage_hash[(size_t)t * TILE + i];
+    rec_seq[o] = seq_ids[s];
+    rec_wpos[o] = stage_wpos[(size_t)t * TILE + i];
+  }
+}
+
+}  // namespace fa
