@@ -494,11 +494,14 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
     a.cnt_slots = smax + 1;
     a.smax_words = (smax + 32) / 32;
-    size_t lds = (size_t)a.cnt_slots * L2_THREADS * 2 + (size_t)a.smax_words * L2_THREADS * 4;
-    lds = (lds + 15) / 16 * 16;
-    FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state (window_size too small for this fragment_length)");
+    int lanes = L2_THREADS;
+    auto l2_lds = [&](int ln) { return ((size_t)a.cnt_slots * ln * 2 + (size_t)a.smax_words * ln * 4 + 15) / 16 * 16; };
+    while (lanes > 1 && l2_lds(lanes) > 144 * 1024) lanes >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
+    size_t lds = l2_lds(lanes);
+    a.lanes = lanes;
+    FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state");
     if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_l2, dim3(ceil_div(nloci, L2_THREADS)), dim3(L2_THREADS), lds, st, a);
+    hipLaunchKernelGGL(k_l2, dim3(ceil_div(nloci, lanes)), dim3(L2_THREADS), lds, st, a);
     FA_HIP(hipGetLastError());
   }
   FA_HIP(hipEventRecord(m.ev[3], st));

@@ -450,6 +450,7 @@ struct L2Args {
   const uint32_t *counters;          // [0] number of loci
   int32_t qcap, cmw, smax_words;     // smax_words = ceil((smax+1)/32)
   int32_t cnt_slots;                 // smax + 1
+  int32_t lanes;                     // loci per workgroup (power of two <= 64; fewer when the sketch is large)
 };
 
 constexpr int L2_THREADS = 64;
@@ -457,10 +458,12 @@ constexpr int L2_THREADS = 64;
 __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   // per-lane arrays, lane-interleaved so that a lane's own element never collides with another lane's bank
-  uint16_t *cnt = (uint16_t *)lds;                                         // [cnt_slots][64]
-  uint32_t *mbit = (uint32_t *)(lds + (size_t)a.cnt_slots * L2_THREADS * 2);   // [smax_words][64]
+  const int LN = a.lanes;
+  uint16_t *cnt = (uint16_t *)lds;                                 // [cnt_slots][LN]
+  uint32_t *mbit = (uint32_t *)(lds + (size_t)a.cnt_slots * LN * 2);   // [smax_words][LN]
   const int lane = threadIdx.x;
-  const uint32_t l = blockIdx.x * L2_THREADS + lane;
+  if (lane >= LN) return;
+  const uint32_t l = blockIdx.x * LN + lane;
   const uint32_t nloci = min(a.counters[0], 0x7FFFFFFFu);
   if (l >= nloci) return;
   const int f = a.l_frag[l];
@@ -478,8 +481,8 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
   int p = wpos[beg];
   int end = lower(p + a.cmw);
   const int last = lower(a.l_end[l] + a.cmw);
-  for (int i = 0; i <= s; i++) cnt[i * L2_THREADS + lane] = 0;
-  for (int i = 0; i < (s + 32) / 32; i++) mbit[i * L2_THREADS + lane] = 0;
+  for (int i = 0; i <= s; i++) cnt[i * LN + lane] = 0;
+  for (int i = 0; i < (s + 32) / 32; i++) mbit[i * LN + lane] = 0;
 
   int rstar = s, P = 0, shared = 0;
   auto rank_of = [&](uint32_t h, bool &found) {
@@ -488,19 +491,19 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
     found = x < s && Q[x] == h;
     return x;
   };
-  auto test = [&](int r) { return (mbit[(r >> 5) * L2_THREADS + lane] >> (r & 31)) & 1u; };
+  auto test = [&](int r) { return (mbit[(r >> 5) * LN + lane] >> (r & 31)) & 1u; };
   auto insert = [&](int i) {
     bool found; int r = rank_of(a.ix.rec_hash[i], found);
     if (found) {
-      mbit[(r >> 5) * L2_THREADS + lane] |= 1u << (r & 31);
+      mbit[(r >> 5) * LN + lane] |= 1u << (r & 31);
       if (r < rstar) shared++;
     } else {
-      cnt[r * L2_THREADS + lane] += 1;
+      cnt[r * LN + lane] += 1;
       if (r < rstar) {
         P++;
         if (rstar - 1 + P >= s) {            // f(r*-1) reached s: the largest query rank falls out of the first s
           rstar--;
-          P -= cnt[rstar * L2_THREADS + lane];
+          P -= cnt[rstar * LN + lane];
           if (test(rstar)) shared--;
         }
       }
@@ -509,13 +512,13 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
   auto remove = [&](int i) {
     bool found; int r = rank_of(a.ix.rec_hash[i], found);
     if (found) {
-      mbit[(r >> 5) * L2_THREADS + lane] &= ~(1u << (r & 31));
+      mbit[(r >> 5) * LN + lane] &= ~(1u << (r & 31));
       if (r < rstar) shared--;
     } else {
-      cnt[r * L2_THREADS + lane] -= 1;
+      cnt[r * LN + lane] -= 1;
       if (r < rstar) P--;
-      if (rstar < s && rstar + P + (int)cnt[rstar * L2_THREADS + lane] < s) {
-        P += cnt[rstar * L2_THREADS + lane];
+      if (rstar < s && rstar + P + (int)cnt[rstar * LN + lane] < s) {
+        P += cnt[rstar * LN + lane];
         if (test(rstar)) shared++;
         rstar++;
       }

@@ -1,0 +1,85 @@
+"""The C-ABI library loads and exports exactly what include/fastani_hip.h declares; host-only entry points agree
+with the oracle (no GPU compute here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+from oracle.oracle import lib as olib, murmur_hash
+from pyfastani_amd import _lib
+from pyfastani_amd._lib import lib, check
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fastani_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported():
+    names = declared_symbols()
+    assert len(names) >= 35
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/fastani_hip.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_struct_layouts():
+    assert C.sizeof(_lib.Params) == 40
+    assert C.sizeof(_lib.CgiRow) == 20
+    assert C.sizeof(_lib.Mapping) == 24
+
+
+def test_host_hash_matches_oracle():
+    rng = np.random.default_rng(0)
+    for k in list(range(1, 40)) + [64, 200]:
+        kmer = bytes(rng.integers(65, 91, k, dtype=np.uint8))
+        assert lib.fa_hash(kmer, k) == murmur_hash(kmer)
+
+
+def test_window_and_min_hits_match_oracle():
+    w = C.c_int(0)
+    for k, frag in [(16, 3000), (14, 1000), (16, 5000), (21, 3000), (21, 1000), (5, 3000)]:
+        check(lib.fa_recommended_window_size(1e-3, k, 4, 80.0, frag, 5_000_000, C.byref(w)))
+        assert w.value == olib().fo_recommended_window(1e-3, k, 4, 80.0, frag, 5_000_000)
+    h = C.c_int(0)
+    for s in list(range(1, 400, 7)) + [1000, 2962]:
+        for pid in (80.0, 90.0, 95.0, 70.0):
+            check(lib.fa_estimate_minimum_hits_relaxed(s, 16, pid, C.byref(h)))
+            assert h.value == olib().fo_min_hits_relaxed(s, 16, pid)
+
+
+def test_identity_table_matches_oracle():
+    a, b = C.c_float(0), C.c_float(0)
+    oa, ob = C.c_float(0), C.c_float(0)
+    for k in (14, 16, 21):
+        for s in (1, 2, 17, 85, 150, 233, 240, 256, 300):
+            prev_upper = -1.0
+            for c in range(0, s + 1):
+                check(lib.fa_mapping_identity(c, s, k, C.byref(a), C.byref(b)))
+                olib().fo_identity(c, s, k, C.byref(oa), C.byref(ob))
+                assert a.value == oa.value and b.value == ob.value  # bit-exact float32
+                assert b.value >= prev_upper  # the pass filter is monotone in the shared count
+                prev_upper = b.value
+
+
+def test_invalid_params_are_reported_not_thrown():
+    p = _lib.Params(0, 24, 3000, 4, 0.2, 80.0, 1e-3, 5_000_000)
+    h = C.c_void_p()
+    assert lib.fa_sketch_new(C.byref(p), C.byref(h)) == _lib.FA_ERR_INVALID
+    assert b"kmer_size" in lib.fa_last_error()
+
+
+@pytest.mark.skipif(has_gpu(), reason="CPU-only behaviour")
+def test_compute_fails_loudly_without_device():
+    import pyfastani_amd as pf
+    sk = pf.Sketch()
+    sk.add_genome("x", "ACGT" * 1000)  # packing is host work
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        len(sk.minimizers)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        sk.index()

@@ -1,0 +1,375 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed fixtures -- MI355X only.
+
+Integer results (minimizer streams, index size, L1 loci, L2 shared counts, orthologous-fragment counts) must be
+bit-exact; identities are float32 and must be bit-exact too (tolerance stated where a looser one applies: the
+north star allows 1e-4 on reported ANI)."""
+import ctypes as C
+import json
+import os
+import pickle
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+import pyfastani_amd as pf
+from conftest import read_fasta
+from oracle.oracle import OracleSketch
+from pyfastani_amd import _lib, synthetic as syn
+from pyfastani_amd._lib import lib, check
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_synthetic_goldens import build_case  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+ANI_TOL = 1e-4
+
+
+def quiet_sketch(cls, **kw):
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return cls(**kw)
+
+
+def gpu_stream(sk, seq):
+    b = seq.encode("latin-1") if isinstance(seq, str) else bytes(seq)
+    cap = max(len(b), 1)
+    h = np.empty(cap, np.uint32)
+    w = np.empty(cap, np.int32)
+    n = C.c_int64(0)
+    check(lib.fa_debug_sketch_sequence(C.byref(sk._param), b, len(b), 1, h.ctypes.data, w.ctypes.data, cap, C.byref(n)))
+    return h[: n.value], w[: n.value]
+
+
+def hit_tuples(hits):
+    return [(h.name, h.identity, h.matches, h.fragments) for h in hits]
+
+
+def gpu_mappings(mapper):
+    cap = 1 << 20
+    buf = (_lib.Mapping * cap)()
+    n = C.c_int64(0)
+    check(lib.fa_mapper_debug_mappings(mapper._h, buf, cap, C.byref(n)))
+    assert n.value <= cap
+    return sorted((buf[i].query_seq_id, buf[i].ref_seq_id, buf[i].ref_start_pos, buf[i].sketch_size, buf[i].conserved)
+                  for i in range(n.value))
+
+
+def oracle_mappings(det):
+    m = det["mappings"]
+    return sorted(zip(m["qseq"].tolist(), m["rseq"].tolist(), m["rstart"].tolist(), m["sketch"].tolist(), m["shared"].tolist()))
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# K1: minimizer streams
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,frag", [(16, 3000), (14, 1000), (21, 3000), (16, 5000), (12, 500), (33, 3000), (7, 200)])
+def test_minimizer_streams(k, frag):
+    sk = quiet_sketch(pf.Sketch, k=k, fragment_length=frag)
+    osk = OracleSketch(k=k, fragment_length=frag)
+    if osk.window_size < 0:
+        pytest.skip("degenerate parameter cell: no admissible sketch size")
+    assert sk.window_size == osk.window_size
+    g = syn.rng(100 + k)
+    w = sk.window_size
+    rnd = lambda n: bytes(syn.to_ascii(syn.random_codes(g, n)))  # noqa: E731
+    cases = {
+        "random": rnd(10_000),
+        "tile_boundaries": rnd(2048 * 3 + k - 1),
+        "fragment": rnd(frag),
+        "ATGC_repeat": b"ATGC" * 1000,
+        "polyA": b"A" * 5000,
+        "AT_repeat": b"AT" * 3000,
+        "N_runs_and_iupac": rnd(3000) + b"N" * 100 + rnd(4000) + b"nnRYKMBVDHSWU" + rnd(500) + b"N",
+        "lower_case": rnd(5000).lower(),
+        "mixed_case": bytes(c + 32 if i % 3 == 0 else c for i, c in enumerate(rnd(3000))),
+        "shorter_than_k": b"ACGTA"[: max(1, k - 1)],
+        "len_w": rnd(max(w, 1)),
+        "len_w_plus_k_minus_2": rnd(w + k - 2),
+        "len_w_plus_k_minus_1": rnd(w + k - 1),
+        "len_w_plus_k": rnd(w + k),
+        "palindromes": (rnd(40) + b"ACGT" * 10 + b"GAATTC" * 20) * 20,
+        "leading_dup_run": b"ACGTTGCA" * 50 + rnd(2000),
+    }
+    for name, seq in cases.items():
+        gh, gw = gpu_stream(sk, seq)
+        oh, ow = osk.sketch_sequence(seq)
+        assert np.array_equal(gh, oh) and np.array_equal(gw, ow), f"{name}: gpu {len(gh)} records, oracle {len(oh)}"
+
+
+def test_reference_sketch_multi_contig_and_index():
+    g = syn.rng(11)
+    anc, members, _ = syn.family(11, 4, 200_000)
+    sk, osk = pf.Sketch(), OracleSketch()
+    for i, m in enumerate(members):
+        contigs = syn.split_contigs(g, m, 3) + [b"ACGT", b""]
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            sk.add_draft(f"g{i}", contigs)
+        assert len(caught) == 2  # the two short contigs (_fastani.pyx:670-677)
+        osk.add_draft(f"g{i}", contigs)
+    assert len(sk.minimizers) == len(osk.minimizers()[0])
+    h, s, w = sk.minimizers._arrays()
+    oh, os_, ow = osk.minimizers()
+    assert np.array_equal(h, oh) and np.array_equal(s, os_) and np.array_equal(w, ow)
+    first = sk.minimizers[0]
+    assert (first.hash, first.sequence_id, first.window_position) == (int(oh[0]), int(os_[0]), int(ow[0]))
+    assert sk.minimizers[-1].hash == int(oh[-1])
+    mapper = sk.index()
+    osk.index()
+    assert len(sk.minimizers) == 0 and sk.names == []          # ownership moved (_fastani.pyx:793-806)
+    assert len(mapper.minimizers) == len(oh)
+    idx = mapper.lookup_index
+    assert len(idx) == osk.index_size
+    assert mapper.occurences_threshold == osk.freq_threshold
+    keys = list(idx)
+    assert keys == sorted(set(oh.tolist()))
+    for key in keys[:: max(1, len(keys) // 50)]:
+        assert key in idx
+        pos = idx[key]
+        assert len(pos) == osk.index_count(key)
+        want = [(int(a), int(b)) for a, b, c in zip(os_, ow, oh) if c == key]
+        assert [(p.sequence_id, p.window_position) for p in pos] == want
+    missing = next(x for x in range(1, 10_000) if x not in set(keys))
+    assert missing not in idx
+    with pytest.raises(KeyError):
+        idx[missing]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# end to end against the oracle, with stage-level comparison of the L2 mappings
+# ----------------------------------------------------------------------------------------------------------------
+def run_both(params, refs, query, threads=1):
+    sk, osk = quiet_sketch(pf.Sketch, **params), quiet_sketch(OracleSketch, **params)
+    for i, r in enumerate(refs):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk.add_draft(f"ref{i}", r)
+        osk.add_draft(f"ref{i}", r)
+    mapper = sk.index()
+    osk.index()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        hits = mapper.query_draft(query)
+    ohits, det = osk.query_draft(query, threads=threads, details=True)
+    return mapper, hits, ohits, det
+
+
+@pytest.mark.parametrize("seed,length,params", [
+    (21, 400_000, {}),
+    (22, 300_000, {"k": 14, "fragment_length": 1000}),
+    (23, 300_000, {"k": 21, "fragment_length": 3000}),
+    (24, 300_000, {"fragment_length": 5000}),
+    (25, 200_000, {"percentage_identity": 95.0}),
+    (26, 200_000, {"percentage_identity": 70.0, "minimum_fraction": 0.0}),
+])
+def test_end_to_end_vs_oracle(seed, length, params):
+    g = syn.rng(seed)
+    anc = syn.random_codes(g, length)
+    refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.01, 0.04, 0.09, 0.14, 0.20)]
+    refs.append([syn.to_ascii(syn.random_codes(g, length))])
+    # a reference with an internal duplication and an inverted segment (exercises several loci per genome)
+    dup = syn.mutate_codes(g, anc, 0.03)
+    dup = np.concatenate([dup[: length // 2], dup[length // 4: length // 2], syn.reverse_complement_codes(dup[length // 2:])])
+    refs.append([syn.to_ascii(dup)])
+    query = [syn.to_ascii(syn.mutate_codes(g, anc, 0.05))]
+    mapper, hits, ohits, det = run_both(params, refs, query, threads=4)
+    assert gpu_mappings(mapper) == oracle_mappings(det)        # every L2 mapping: position, sketch size, shared count
+    assert hit_tuples(hits) == ohits                           # counts bit-exact, identity bit-exact (<= ANI_TOL required)
+    for (n1, i1, m1, f1), (n2, i2, m2, f2) in zip(hit_tuples(hits), ohits):
+        assert abs(i1 - i2) <= ANI_TOL and (m1, f1) == (m2, f2)
+
+
+def test_draft_query_and_reference():
+    g = syn.rng(31)
+    anc = syn.random_codes(g, 500_000)
+    refs = [syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, d)), 20) for d in (0.02, 0.07, 0.13)]
+    refs.append(syn.split_contigs(g, syn.to_ascii(syn.random_codes(g, 300_000)), 9))
+    query = syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, 0.04)), 15) + [b"ACGT" * 3]
+    mapper, hits, ohits, det = run_both({}, refs, query)
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits and len(hits) == 3
+
+
+def test_l1_candidates_match_oracle():
+    g = syn.rng(41)
+    anc = syn.random_codes(g, 150_000)
+    refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.02, 0.10)]
+    query = syn.to_ascii(syn.mutate_codes(g, anc, 0.05))
+    mapper, hits, ohits, det = run_both({}, refs, [query])
+    cap = 1 << 16
+    arr = [np.empty(cap, np.int32) for _ in range(4)]
+    n = C.c_int64(0)
+    check(lib.fa_mapper_debug_l1(mapper._h, *[a.ctypes.data for a in arr], cap, C.byref(n)))
+    got = {}
+    for f, s, a, b in zip(*[a[: n.value].tolist() for a in arr]):
+        got.setdefault(f, []).append((s, a, b))
+    osk = OracleSketch()
+    for i, r in enumerate(refs):
+        osk.add_draft(f"ref{i}", r)
+    osk.index()
+    qb = bytes(query)
+    for f in range(0, len(qb) // 3000, 3):
+        ss, mh, loci = osk.l1_fragment(qb[f * 3000:(f + 1) * 3000])
+        assert sorted(got.get(f, [])) == sorted(loci), f
+        sz = C.c_int32(0)
+        buf = np.empty(4096, np.uint32)
+        check(lib.fa_mapper_debug_query_sketch(mapper._h, f, buf.ctypes.data, 4096, C.byref(sz)))
+        assert sz.value == ss
+        oh, _ = osk.sketch_sequence(qb[f * 3000:(f + 1) * 3000])
+        assert buf[: sz.value].tolist() == sorted(set(oh.tolist()))
+
+
+def test_frequency_threshold_active():
+    # ~478 000 distinct minimizers => minimizerToIgnore = 4; two planted 45-mers give a handful of hashes with
+    # hundreds of occurrences, so computeFreqHist leaves INT_MAX and the strict `size < threshold` filter bites
+    g = syn.rng(51)
+    n = 1_000_000
+    genomes = [syn.random_codes(g, n) for _ in range(6)]
+    r1, r2 = syn.random_codes(g, 45), syn.random_codes(g, 45)
+    m = genomes[0]
+    for p in range(1000, n - 1000, n // 300):
+        m[p: p + 45] = r1
+    for p in range(2500, n - 1000, n // 150):
+        m[p: p + 45] = r2
+    refs = [[syn.to_ascii(x)] for x in genomes]
+    query = [syn.to_ascii(syn.mutate_codes(g, m, 0.02))]
+    mapper, hits, ohits, det = run_both({}, refs, query, threads=8)
+    assert mapper.occurences_threshold == 218                  # value from the oracle
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+
+
+def test_protein_golden_on_device(golden_dir):
+    # reference: src/pyfastani/tests/test_ani.py:96-115
+    b1 = read_fasta(os.path.join(golden_dir, "BGC0001425.faa"))
+    b3 = read_fasta(os.path.join(golden_dir, "BGC0001428.faa"))
+    for carrier in (str, lambda s: s.encode("ascii"), lambda s: np.frombuffer(s.encode("ascii"), dtype=np.uint8)):
+        sk = pf.Sketch(protein=True, fragment_length=100)
+        sk.add_draft("BGC0001425", map(carrier, b1))
+        sk.add_draft("BGC0001427", map(carrier, b1))
+        assert len(sk.minimizers) == 36054
+        mapper = sk.index()
+        assert len(mapper.lookup_index) == 13890
+        hits = mapper.query_draft(map(carrier, b3))
+        assert len(hits) == 2
+        assert (hits[0].name, hits[0].matches, hits[0].fragments) == ("BGC0001425", 130, 176)
+        assert (hits[1].name, hits[1].matches, hits[1].fragments) == ("BGC0001427", 130, 176)
+        assert hits[0].identity == pytest.approx(94.99492645263672, abs=ANI_TOL)
+
+
+def test_committed_fixtures(golden_dir):
+    fixtures = json.load(open(os.path.join(golden_dir, "synthetic_goldens.json")))
+    for fx in fixtures:
+        case = fx["case"]
+        refs, queries = build_case(case)
+        sk = quiet_sketch(pf.Sketch, **case["params"])
+        for i, r in enumerate(refs):
+            sk.add_draft(f"ref{i}", r)
+        assert sk.window_size == fx["window"], case["name"]
+        assert len(sk.minimizers) == fx["n_minimizers"], case["name"]
+        mapper = sk.index()
+        assert len(mapper.lookup_index) == fx["index_size"] and mapper.occurences_threshold == fx["freq_threshold"]
+        for q, want in zip(queries, fx["queries"]):
+            hits = mapper.query_draft(q)
+            assert [[h.name, h.identity, h.matches, h.fragments] for h in hits] == want["hits"], case["name"]
+            assert len(gpu_mappings(mapper)) == want["n_mappings"]
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# edge cases of the API
+# ----------------------------------------------------------------------------------------------------------------
+def test_edge_cases():
+    g = syn.rng(61)
+    ref = syn.to_ascii(syn.random_codes(g, 50_000))
+    sk = pf.Sketch()
+    sk.add_genome("r", ref)
+    mapper = sk.index()
+    assert mapper.query_draft([]) == []                                # no contigs
+    assert mapper.query_genome(ref[:2999]) == []                       # shorter than one fragment: no warning, no hit
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        assert mapper.query_draft([b"ACGT", b""]) == []                # shorter than min(w, k, frag): warns (:1061-1070)
+    assert len(caught) == 2
+    assert mapper.query_genome(b"N" * 9000) == []                      # sketch size 0 (_fastani.pyx:937-938)
+    assert mapper.query_genome(b"AT" * 4500) == []                     # only strand-symmetric k-mers
+    assert hit_tuples(mapper.query_genome(ref)) == [("r", 100.0, 16, 16)]
+    assert hit_tuples(mapper.query_genome(bytes(ref).decode().lower())) == [("r", 100.0, 16, 16)]
+    with pytest.raises(ValueError):
+        mapper.query_genome(ref, threads=-1)
+    # an empty index answers with no hits
+    empty = pf.Sketch().index()
+    assert empty.query_genome(ref) == [] and len(empty.lookup_index) == 0
+    # a sketch stays usable after index() (_fastani.pyx:803-804)
+    sk.add_genome("again", ref)
+    assert hit_tuples(sk.index().query_genome(ref)) == [("again", 100.0, 16, 16)]
+
+
+def test_clear_and_names():
+    g = syn.rng(62)
+    sk = pf.Sketch()
+    sk.add_genome("a", syn.to_ascii(syn.random_codes(g, 10_000)))
+    assert len(sk.minimizers) > 0
+    sk.clear()
+    assert len(sk.minimizers) == 0 and sk.names == []
+    sk.add_genome("b", syn.to_ascii(syn.random_codes(g, 10_000)))
+    assert sk.names == ["b"] and sk.minimizers[0].sequence_id == 0
+
+
+def test_pickling_round_trips():
+    # reference: test_ani.py:135-173 and test_sketch.py:54-61
+    g = syn.rng(71)
+    anc = syn.random_codes(g, 200_000)
+    ref = syn.to_ascii(syn.mutate_codes(g, anc, 0.03))
+    query = syn.to_ascii(syn.mutate_codes(g, anc, 0.02))
+    sk = pf.Sketch()
+    sk.add_genome("ref", ref)
+    sk2 = pickle.loads(pickle.dumps(sk))
+    assert sk2.names == ["ref"] and len(sk2.minimizers) == len(sk.minimizers)
+    want = hit_tuples(sk.index().query_genome(query))
+    m2 = sk2.index()
+    assert hit_tuples(m2.query_genome(query)) == want
+    m3 = pickle.loads(pickle.dumps(m2))
+    assert hit_tuples(m3.query_genome(query)) == want and len(m3.lookup_index) == len(m2.lookup_index)
+    assert len(want) == 1 and want[0][2] > 60
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# full-size, oracle-free properties (BASELINE sizes)
+# ----------------------------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    g = syn.rng(81)
+    n = 5_000_000
+    anc = syn.random_codes(g, n)
+    refs = {"self": anc, "d05": syn.mutate_codes(g, anc, 0.05), "d15": syn.mutate_codes(g, anc, 0.15), "unrelated": syn.random_codes(g, n)}
+    sk = pf.Sketch()
+    for name, codes in refs.items():
+        sk.add_genome(name, syn.to_ascii(codes))
+    n_min = len(sk.minimizers)
+    assert abs(n_min - 4 * 2 * n / 25) < 0.02 * 4 * 2 * n / 25          # density 2/(w+1)
+    mapper = sk.index()
+    hits = mapper.query_genome(syn.to_ascii(anc))
+    assert hit_tuples(hits)[0] == ("self", 100.0, 1666, 1666)            # self-query invariant (test_ani.py:66-71)
+    assert [h.name for h in hits] == ["self", "d05", "d15"]
+    assert hits[1].matches >= 1640 and 94.0 < hits[1].identity < 95.0
+    # strand symmetry: the reverse complement of the query gives the same per-genome counts and identities
+    rc_hits = mapper.query_genome(syn.to_ascii(syn.reverse_complement_codes(anc)))
+    # (not exactly 100.0: a window is only evaluated when its LAST k-mer is not strand-symmetric (_fastani.pyx:202),
+    # so the ~76 palindromic 16-mers of a 5 Mb genome make the two strands see slightly different window sets;
+    # the oracle gives the same value on this input)
+    assert hit_tuples(rc_hits)[0] == ("self", 99.99999237060547, 1666, 1666)
+    # order independence: the same references added in another order give the same rows per name
+    sk2 = pf.Sketch()
+    for name in ["unrelated", "d15", "self", "d05"]:
+        sk2.add_genome(name, syn.to_ascii(refs[name]))
+    hits2 = sk2.index().query_genome(syn.to_ascii(anc))
+    assert sorted(hit_tuples(hits)) == sorted(hit_tuples(hits2))
+    # batch API == one call per genome
+    queries = [[syn.to_ascii(refs["d05"])], [syn.to_ascii(refs["unrelated"])], syn.split_contigs(g, syn.to_ascii(refs["d15"]), 50)]
+    batch = mapper.upload_genomes(queries)
+    per_genome = batch.query()
+    for q, got in zip(queries, per_genome):
+        assert hit_tuples(got) == hit_tuples(mapper.query_draft(q))
+    assert hit_tuples(per_genome[0])[0][:1] == ("d05",) and per_genome[0][0].identity == 100.0
+    assert hit_tuples(batch.query(1, 2)[1]) == hit_tuples(per_genome[2])
