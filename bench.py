@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Headline benchmark: genome-pair ANI estimates per second on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): one 5 Mb query genome x 100 synthetic 5 Mb reference genomes (60 related to
+the query's ancestor at mixed divergence, 40 unrelated), k=16, fragment_length=3000 (w=24).  The index is built
+once, untimed, and stays resident in HBM; the query genome is packed 2-bit and resident in HBM before the timed
+region.  One *step* = one pass of the hot path over that query: K1 minimizer extraction of its 1666 fragments,
+sort/unique, index lookup, L1 candidate regions, L2 sliding-window Jaccard and the core-genome identity
+reduction, ending with the 100-pair hit table in device memory (= Mapper.query_draft up to computeCGI,
+src/pyfastani/_fastani.pyx:1006-1118 of the reference, which is also what the reference's own benchmark times).
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds a replica of the index
+and maps its own query genome (queries are sharded, weak scaling); each step ends with the RCCL all-gather of the
+per-pair hit tables.  value = pairs processed by all ranks / max-over-ranks time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# Algorithmic bytes
+K1_BYTES_PER_BASE = 0.25 + 12.0 * 2.0 / 25.0      # 2-bit input + 12 B records at density 2/(w+1), w = 24
+L2_BYTES_PER_LOCUS = 12.0 * 480.0                  # ~2 fragment lengths of reference minimizer records per locus
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--refs", type=int, default=100, help="reference genomes in the index (60%% related)")
+    ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-refs", type=int, default=10, help="references in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+    entry.build()
+    import pyfastani_amd as pf
+    from pyfastani_amd import synthetic as syn, sharding
+    from pyfastani_amd._lib import lib, check
+
+    check(lib.fa_set_device(local_rank))
+
+    # ---- synthetic workload (identical index on every rank; one query genome per rank) ----
+    n_related = int(round(args.refs * 0.6))
+    g = syn.rng(1000)
+    anc = syn.random_codes(g, args.length)
+    t0 = time.time()
+    sk = pf.Sketch()
+    for i in range(args.refs):
+        if i < n_related:
+            d = syn.DIVERGENCES[i % len(syn.DIVERGENCES)]
+            sk.add_genome(f"A{i:03d}", syn.to_ascii(syn.mutate_codes(g, anc, d)))
+        else:
+            sk.add_genome(f"U{i:03d}", syn.to_ascii(syn.random_codes(g, args.length)))
+    t_pack = time.time() - t0
+    t0 = time.time()
+    n_min = len(sk.minimizers)
+    mapper = sk.index()
+    t_index = time.time() - t0
+    gq = syn.rng(5000 + rank)
+    query = syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))
+    batch = mapper.upload_genomes([[query]])
+    n_pairs_step = args.refs
+
+    rows = torch.zeros((max(args.refs, 1), 5), dtype=torch.int32, device="cuda")
+
+    def step():
+        n = batch.query_rows_device(0, 1, rows.data_ptr(), rows.shape[0])
+        if world > 1:
+            return sharding.all_gather_rows(rows[:n])
+        return rows[:n]
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    phase_ms = np.zeros(5)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        ms = (C.c_float * 8)()
+        lib.fa_mapper_last_timings(mapper._h, ms, 8)     # HIP-event timings of this step, on the library's stream
+        phase_ms += np.array(list(ms)[:5])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_hits = int(out.shape[0])
+    phase_ms /= max(args.steps, 1)
+
+    result = None
+    if rank == 0:
+        value = world * n_pairs_step * args.steps / elapsed
+        # ---- roofline of the dominant kernel, from the HIP-event timings taken inside the timed region ----
+        from pyfastani_amd._lib import lib as _l
+        names = ["sketch(K1+sort)", "lookup", "L1", "L2", "cgi"]
+        phase = dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase_ms]))
+        n_loci = C.c_int64(0)
+        cap = 1
+        # K1 alone, repeated, for the minimizer-extraction roofline the north star asks for
+        k1_ms, bases, mins = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
+        check(lib.fa_bench_sketch_kernel(mapper._h, batch._h, 50, C.byref(k1_ms), C.byref(bases), C.byref(mins)))
+        k1_bytes = bases.value * 0.25 + mins.value * 12.0
+        k1_gbs = k1_bytes / (k1_ms.value * 1e-3) / 1e9
+        buf4 = [np.empty(1, np.int32) for _ in range(4)]
+        check(lib.fa_mapper_debug_l1(mapper._h, *[b.ctypes.data for b in buf4], cap, C.byref(n_loci)))
+        l2_bytes = n_loci.value * L2_BYTES_PER_LOCUS
+        l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
+        dominant = "k_l2" if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
+        roof = {"k_l2": (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
+        result = {
+            "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
+            "value": value,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"1 query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
+                       "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "parallelism": f"query-sharded x{world}",
+                       "index_minimizers": n_min, "index_build_s": t_index, "host_pack_s": t_pack},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": roof[0] / HBM_PEAK_GBS, "traffic": None, "kernel_ms": roof[1]},
+            "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_tiles", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,
+                                "algorithmic_bytes": k1_bytes},
+            "phases_ms": phase,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, anc)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def cpu_baseline(args, anc):
+    """The CPU oracle (a restatement: the reference's own C++ cannot be built) timed on this box's host
+    cores on a bounded sample of the same workload: the same 5 Mb query against the first `cpu_refs` references
+    (same 60/40 related/unrelated mix), query_draft only -- the index build is excluded exactly as on the GPU."""
+    from oracle.oracle import OracleSketch
+    from pyfastani_amd import synthetic as syn
+    cores = os.cpu_count() or 1
+    n_refs = args.cpu_refs
+    n_related = int(round(n_refs * 0.6))
+    g = syn.rng(1000)
+    anc2 = syn.random_codes(g, args.length)  # same stream as the GPU workload: identical ancestor
+    assert np.array_equal(anc, anc2)
+    osk = OracleSketch()
+    for i in range(n_refs):
+        if i < n_related:
+            d = syn.DIVERGENCES[i % len(syn.DIVERGENCES)]
+            osk.add_genome(f"A{i:03d}", syn.to_ascii(syn.mutate_codes(g, anc, d)))
+        else:
+            osk.add_genome(f"U{i:03d}", syn.to_ascii(syn.random_codes(g, args.length)))
+    osk.index()
+    gq = syn.rng(5000)
+    query = syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))
+    hits, det = osk.query_draft([query], threads=cores, details=True)
+    hits1, det1 = (hits, det) if cores == 1 else osk.query_draft([query], threads=1, details=True)
+    return {
+        "value": n_refs / det["seconds"], "unit": "pairs/s", "cores": cores, "kind": "port",
+        "sample": f"1 query x {n_refs} refs ({n_related} related) of {args.length / 1e6:g} Mb, Mapper.query_draft only",
+        "seconds": det["seconds"], "single_thread_value": n_refs / det1["seconds"], "hits": len(hits),
+    }
+
+
+if __name__ == "__main__":
+    main()
