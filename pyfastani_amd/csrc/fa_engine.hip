@@ -234,6 +234,10 @@ struct fa_mapper {
   SketchWork sk;
   DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
   DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
+  DevBuf<int32_t> l_beg, l_end0, l_last;
+  DevBuf<uint32_t> l_items, l_ioff;
+  DevBuf<unsigned char> items;
+  uint64_t last_items = 0;
   DevBuf<uint64_t> totals;
   DevBuf<unsigned long long> group_best, bins;
   DevBuf<float> row_ident;
@@ -484,24 +488,55 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   FA_HIP(hipEventRecord(m.ev[2], st));
   const uint32_t nloci = h_counters[0], ngroups = h_counters[1];
   m.last_loci = nloci;
-  // ---- L2 ----
+  // ---- L2: prep (ranges) -> scan of range sizes -> rank items -> sequential slide ----
   if (nloci > 0) {
     FA_HIP(hipMemsetAsync(m.group_best.p, 0, (size_t)ngroups * sizeof(unsigned long long), st));
+    m.l_beg.ensure((size_t)nloci + 1); m.l_end0.ensure((size_t)nloci + 1); m.l_last.ensure((size_t)nloci + 1);
+    m.l_items.ensure((size_t)nloci + 2); m.l_ioff.ensure((size_t)nloci + 2);
     L2Args a;
     a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
     a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+    a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_items = m.l_items.p; a.l_ioff = m.l_ioff.p;
+    a.items = nullptr;
     a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
     a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
     a.cnt_slots = smax + 1;
     a.smax_words = (smax + 32) / 32;
+    a.lanes = L2_THREADS;
+    hipLaunchKernelGGL(k_l2_prep, dim3(ceil_div((int64_t)nloci + 1, 256)), dim3(256), 0, st, a);
+    {
+      size_t bytes = 0;
+      FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, m.l_items.p, m.l_ioff.p, (int)nloci + 1, st));
+      m.sk.cub_temp.ensure(bytes + 16);
+      FA_HIP(hipcub::DeviceScan::ExclusiveSum(m.sk.cub_temp.p, bytes, m.l_items.p, m.l_ioff.p, (int)nloci + 1, st));
+    }
+    uint32_t total_items = 0;
+    FA_HIP(hipMemcpyAsync(&total_items, m.l_ioff.p + nloci, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    FA_HIP(hipStreamSynchronize(st));
+    const bool wide = smax > 4095;
+    m.items.ensure(((size_t)total_items + 8) * (wide ? 4 : 2));
+    a.items = m.items.p;
+    m.last_items = total_items;
+    m.last_ms[5] += (float)total_items;   // records visited by L2 in this call (for the roofline line)
+    m.last_ms[6] += (float)nloci;
+    size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + 16;
+    FA_REQUIRE(rank_lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged rank kernel");
     int lanes = L2_THREADS;
     auto l2_lds = [&](int ln) { return ((size_t)a.cnt_slots * ln * 2 + (size_t)a.smax_words * ln * 4 + 15) / 16 * 16; };
     while (lanes > 1 && l2_lds(lanes) > 144 * 1024) lanes >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
     size_t lds = l2_lds(lanes);
     a.lanes = lanes;
     FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state");
-    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_l2, dim3(ceil_div(nloci, lanes)), dim3(L2_THREADS), lds, st, a);
+    if (wide) {
+      if (rank_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2_rank<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
+      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2_scan<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_l2_rank<uint32_t>, dim3(nloci), dim3(RANK_THREADS), rank_lds, st, a);
+      hipLaunchKernelGGL(k_l2_scan<uint32_t>, dim3(ceil_div(nloci, lanes)), dim3(L2_THREADS), lds, st, a);
+    } else {
+      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2_scan<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_l2_rank<uint16_t>, dim3(nloci), dim3(RANK_THREADS), rank_lds, st, a);
+      hipLaunchKernelGGL(k_l2_scan<uint16_t>, dim3(ceil_div(nloci, lanes)), dim3(L2_THREADS), lds, st, a);
+    }
     FA_HIP(hipGetLastError());
   }
   FA_HIP(hipEventRecord(m.ev[3], st));

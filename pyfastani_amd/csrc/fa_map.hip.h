@@ -439,23 +439,87 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
 // among the s smallest of the union iff f(r) < s, so shared = #{matched r < r*}, r* = min{r : f(r) >= s}.
 // r* moves by at most one per inserted / deleted hash, exactly like the reference's pivot.
 // ----------------------------------------------------------------------------------------------------------
+// The work is split into three launches so that nothing slow sits on the sequential chain:
+//   k_l2_prep   one lane per locus: the three searchIndex() binary searches -> record range [beg, last) and the end
+//               of the first super-window;
+//   k_l2_rank   one workgroup per locus, query sketch staged in LDS: every record of the range is reduced to an
+//               `item` = rank | found | the duplicate-linking flags (fully parallel, 8-step binary searches);
+//   k_l2_scan   one lane per locus: the sequential slide, reading one precomputed item per admitted / dropped record
+//               and keeping cnt[] / the matched bitmap in lane-interleaved LDS.
 struct L2Args {
   IndexView ix;
   const uint32_t *q_hash;
   const int32_t *q_size;
   const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;
+  int32_t *l_beg, *l_end0, *l_last;  // record range of the locus, end of the first super-window
+  uint32_t *l_items;                 // [loci + 1] number of records in the range, then (after the scan) offsets
+  const uint32_t *l_ioff;            // exclusive scan of l_items
+  void *items;                       // uint16 or uint32 per record of every locus range
   int32_t *l_shared, *l_pos;
   const int32_t *pass_lut;           // [smax+1]
   unsigned long long *group_best;    // [groups] (shared<<32 | ~locus)
   const uint32_t *counters;          // [0] number of loci
   int32_t qcap, cmw, smax_words;     // smax_words = ceil((smax+1)/32)
   int32_t cnt_slots;                 // smax + 1
-  int32_t lanes;                     // loci per workgroup (power of two <= 64; fewer when the sketch is large)
+  int32_t lanes;                     // loci per workgroup of k_l2_scan (power of two <= 64)
 };
 
 constexpr int L2_THREADS = 64;
+constexpr int RANK_THREADS = 128;
 
-__global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
+// item layouts: rank in the low bits, then found / previous-occurrence-linked / next-occurrence-linked / duplicate of a
+// record already inside the first super-window
+template <typename T> struct ItemBits;
+template <> struct ItemBits<uint16_t> { static constexpr int RANK = 12; };
+template <> struct ItemBits<uint32_t> { static constexpr int RANK = 24; };
+constexpr uint32_t IT_FOUND = 1, IT_INS_LINKED = 2, IT_DEL_LINKED = 4, IT_INIT_DUP = 8;
+
+__global__ void k_l2_prep(L2Args a) {
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nloci = a.counters[0];
+  if (l > nloci) return;
+  if (l == nloci) { a.l_items[l] = 0; return; }
+  const int seq = a.l_seq[l];
+  const int lo = a.ix.contig_rec[seq], hi = a.ix.contig_rec[seq + 1];
+  const int32_t *wpos = a.ix.rec_wpos;
+  auto lower = [&](int from, int target) {
+    int x = from, y = hi;
+    while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+    return x;
+  };
+  const int beg = lower(lo, a.l_start[l]);                       // searchIndex(seqId, rangeStartPos)
+  const int end0 = lower(beg, wpos[beg] + a.cmw);                // searchIndex(seqId, first wpos + countMinimizerWindows)
+  const int last = lower(end0, a.l_end[l] + a.cmw);              // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
+  a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last;
+  a.l_items[l] = (uint32_t)(last - beg);
+}
+
+template <typename T>
+__global__ __launch_bounds__(RANK_THREADS) void k_l2_rank(L2Args a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  uint32_t *Q = (uint32_t *)lds;
+  const uint32_t l = blockIdx.x;
+  const int f = a.l_frag[l];
+  const int s = a.q_size[f];
+  for (int i = threadIdx.x; i < s; i += RANK_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  __syncthreads();
+  const int beg = a.l_beg[l], last = a.l_last[l];
+  T *out = (T *)a.items + a.l_ioff[l];
+  for (int i = beg + (int)threadIdx.x; i < last; i += RANK_THREADS) {
+    const uint32_t h = a.ix.rec_hash[i];
+    int x = 0, y = s;
+    while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
+    uint32_t flags = (x < s && Q[x] == h) ? IT_FOUND : 0u;
+    const uint8_t rf = a.ix.rec_flags[i];
+    if (rf & FLAG_INS_LINKED) flags |= IT_INS_LINKED;
+    if (rf & FLAG_DEL_LINKED) flags |= IT_DEL_LINKED;
+    if (a.ix.rec_prev[i] >= beg) flags |= IT_INIT_DUP;
+    out[i - beg] = (T)((uint32_t)x | (flags << ItemBits<T>::RANK));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   // per-lane arrays, lane-interleaved so that a lane's own element never collides with another lane's bank
   const int LN = a.lanes;
@@ -464,37 +528,22 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
   const int lane = threadIdx.x;
   if (lane >= LN) return;
   const uint32_t l = blockIdx.x * LN + lane;
-  const uint32_t nloci = min(a.counters[0], 0x7FFFFFFFu);
-  if (l >= nloci) return;
-  const int f = a.l_frag[l];
-  const int s = a.q_size[f];
-  const uint32_t *Q = a.q_hash + (size_t)f * a.qcap;
-  const int seq = a.l_seq[l];
-  const int lo = a.ix.contig_rec[seq], hi = a.ix.contig_rec[seq + 1];
+  if (l >= a.counters[0]) return;
+  const int s = a.q_size[a.l_frag[l]];
+  const int hi = a.ix.contig_rec[a.l_seq[l] + 1];
   const int32_t *wpos = a.ix.rec_wpos;
-  auto lower = [&](int target) {
-    int x = lo, y = hi;
-    while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
-    return x;
-  };
-  int beg = lower(a.l_start[l]);
-  int p = wpos[beg];
-  int end = lower(p + a.cmw);
-  const int last = lower(a.l_end[l] + a.cmw);
+  const int beg0 = a.l_beg[l], last = a.l_last[l];
+  int beg = beg0, end = a.l_end0[l];
+  const T *items = (const T *)a.items + a.l_ioff[l];
+  constexpr uint32_t RANK_MASK = (1u << ItemBits<T>::RANK) - 1u;
   for (int i = 0; i <= s; i++) cnt[i * LN + lane] = 0;
   for (int i = 0; i < (s + 32) / 32; i++) mbit[i * LN + lane] = 0;
 
   int rstar = s, P = 0, shared = 0;
-  auto rank_of = [&](uint32_t h, bool &found) {
-    int x = 0, y = s;
-    while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
-    found = x < s && Q[x] == h;
-    return x;
-  };
   auto test = [&](int r) { return (mbit[(r >> 5) * LN + lane] >> (r & 31)) & 1u; };
-  auto insert = [&](int i) {
-    bool found; int r = rank_of(a.ix.rec_hash[i], found);
-    if (found) {
+  auto insert = [&](uint32_t it) {
+    const int r = (int)(it & RANK_MASK);
+    if ((it >> ItemBits<T>::RANK) & IT_FOUND) {
       mbit[(r >> 5) * LN + lane] |= 1u << (r & 31);
       if (r < rstar) shared++;
     } else {
@@ -509,9 +558,9 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
       }
     }
   };
-  auto remove = [&](int i) {
-    bool found; int r = rank_of(a.ix.rec_hash[i], found);
-    if (found) {
+  auto remove = [&](uint32_t it) {
+    const int r = (int)(it & RANK_MASK);
+    if ((it >> ItemBits<T>::RANK) & IT_FOUND) {
       mbit[(r >> 5) * LN + lane] &= ~(1u << (r & 31));
       if (r < rstar) shared--;
     } else {
@@ -526,15 +575,29 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2(L2Args a) {
   };
 
   // first super-window: distinct hashes among records [beg, end)
-  for (int i = beg; i < end; i++) if (a.ix.rec_prev[i] < beg) insert(i);
-  int best = shared, opt_s = wpos[beg], opt_e = opt_s;
+  for (int i = beg; i < end; i++) {
+    uint32_t it = items[i - beg0];
+    if (!((it >> ItemBits<T>::RANK) & IT_INIT_DUP)) insert(it);
+  }
+  int p = wpos[beg];
+  int best = shared, opt_s = p, opt_e = p;
+  int next_drop = (beg + 1 < hi) ? wpos[beg + 1] : 0x7FFFFFFF;
+  int w_end = end < last ? wpos[end] : 0x7FFFFFFF;
   while (end < last) {
     // next window position at which a record is dropped or admitted
-    int next_drop = (beg + 1 < hi) ? wpos[beg + 1] : 0x7FFFFFFF;
-    int next_admit = wpos[end] - a.cmw + 1;
-    p = max(p + 1, min(next_drop, next_admit));
-    if (next_drop <= p) { if (!(a.ix.rec_flags[beg] & FLAG_DEL_LINKED)) remove(beg); beg++; }
-    if (wpos[end] <= p + a.cmw - 1) { if (!(a.ix.rec_flags[end] & FLAG_INS_LINKED)) insert(end); end++; }
+    p = max(p + 1, min(next_drop, w_end - a.cmw + 1));
+    if (next_drop <= p) {
+      uint32_t it = items[beg - beg0];
+      if (!((it >> ItemBits<T>::RANK) & IT_DEL_LINKED)) remove(it);
+      beg++;
+      next_drop = (beg + 1 < hi) ? wpos[beg + 1] : 0x7FFFFFFF;
+    }
+    if (w_end <= p + a.cmw - 1) {
+      uint32_t it = items[end - beg0];
+      if (!((it >> ItemBits<T>::RANK) & IT_INS_LINKED)) insert(it);
+      end++;
+      w_end = end < last ? wpos[end] : 0x7FFFFFFF;
+    }
     if (shared > best) { best = shared; opt_s = opt_e = wpos[beg]; }
     else if (shared == best) opt_e = wpos[beg];
   }
