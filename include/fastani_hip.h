@@ -159,8 +159,10 @@ int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashe
 int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t length, int char_width,
                              uint32_t *hash, int32_t *wpos, int64_t cap, int64_t *n);
 
-/* last-call device timings in milliseconds, measured with HIP events on the library's stream:
- * [0] sketch (K1+sort/unique) [1] lookup+L1 [2] L2 [3] CGI [4] total; and the number of K1 launches/bases */
+/* last-call statistics: [0] sketch ms (K1 + fragment sort/unique), [1] lookup + L1 ms, [2] L2 ms, [3] CGI ms,
+ * [4] total ms -- measured with HIP events on the library's stream -- then counters of the call:
+ * [5] reference records inside L2 locus ranges, [6] L2 loci, [7] L2 slide events, [8] loci redone with the wide
+ * L2 state.  n <= 16. */
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n);
 /* the HIP stream the library launches on (so callers can bracket it with their own events) */
 int fa_mapper_stream(fa_mapper *m, void **stream);

@@ -103,6 +103,12 @@ class OracleSketch:
 
     def __init__(self, k=16, fragment_length=3000, minimum_fraction=0.2, p_value=1e-3, percentage_identity=80.0,
                  reference_size=5_000_000, protein=False, window=0):
+        if not protein and window <= 0:
+            window = lib().fo_recommended_window(p_value, k, 4, percentage_identity, fragment_length, reference_size)
+            if window <= 0:
+                # no admissible sketch size: the reference reads an uninitialised variable here;
+                # both the oracle and the product clamp to the largest window instead of emulating UB
+                window = fragment_length
         self._h = lib().fo_new(k, fragment_length, minimum_fraction, p_value, percentage_identity, reference_size,
                                int(protein), window)
         self.names = []

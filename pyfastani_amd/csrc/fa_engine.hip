@@ -234,9 +234,10 @@ struct fa_mapper {
   SketchWork sk;
   DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
   DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
-  DevBuf<int32_t> l_beg, l_end0, l_last;
+  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop;
   DevBuf<uint32_t> l_items, l_ioff;
   DevBuf<unsigned char> items;
+  DevBuf<uint8_t> l_redo;
   uint64_t last_items = 0;
   DevBuf<uint64_t> totals;
   DevBuf<unsigned long long> group_best, bins;
@@ -246,7 +247,7 @@ struct fa_mapper {
   int64_t last_F = 0, last_f0 = 0;
   uint32_t last_loci = 0;
   const fa_genomes *last_genomes = nullptr;
-  float last_ms[8] = {0};
+  float last_ms[16] = {0};
   hipEvent_t ev[6] = {nullptr};
 
   IndexView view() const {
@@ -492,17 +493,19 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   if (nloci > 0) {
     FA_HIP(hipMemsetAsync(m.group_best.p, 0, (size_t)ngroups * sizeof(unsigned long long), st));
     m.l_beg.ensure((size_t)nloci + 1); m.l_end0.ensure((size_t)nloci + 1); m.l_last.ensure((size_t)nloci + 1);
-    m.l_items.ensure((size_t)nloci + 2); m.l_ioff.ensure((size_t)nloci + 2);
+    m.l_items.ensure((size_t)nloci + 2); m.l_ioff.ensure((size_t)nloci + 2); m.l_ndrop.ensure((size_t)nloci + 1);
     L2Args a;
     a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
     a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
-    a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_items = m.l_items.p; a.l_ioff = m.l_ioff.p;
+    a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_items = m.l_items.p; a.l_ioff = m.l_ioff.p; a.l_ndrop = m.l_ndrop.p;
     a.items = nullptr;
     a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
     a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
     a.cnt_slots = smax + 1;
     a.smax_words = (smax + 32) / 32;
     a.lanes = L2_THREADS;
+    a.rec_total = (unsigned long long *)(m.totals.p + 3);
+    a.wpos_lds = 4096;
     hipLaunchKernelGGL(k_l2_prep, dim3(ceil_div((int64_t)nloci + 1, 256)), dim3(256), 0, st, a);
     {
       size_t bytes = 0;
@@ -511,32 +514,47 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       FA_HIP(hipcub::DeviceScan::ExclusiveSum(m.sk.cub_temp.p, bytes, m.l_items.p, m.l_ioff.p, (int)nloci + 1, st));
     }
     uint32_t total_items = 0;
+    uint64_t total_records = 0;
     FA_HIP(hipMemcpyAsync(&total_items, m.l_ioff.p + nloci, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    FA_HIP(hipMemcpyAsync(&total_records, m.totals.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     FA_HIP(hipStreamSynchronize(st));
     const bool wide = smax > 4095;
     m.items.ensure(((size_t)total_items + 8) * (wide ? 4 : 2));
     a.items = m.items.p;
     m.last_items = total_items;
-    m.last_ms[5] += (float)total_items;   // records visited by L2 in this call (for the roofline line)
+    m.last_ms[5] += (float)total_records;   // reference records inside the locus ranges of this call (roofline line)
+    m.last_ms[7] += (float)total_items;     // slide events
     m.last_ms[6] += (float)nloci;
-    size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + 16;
-    FA_REQUIRE(rank_lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged rank kernel");
-    int lanes = L2_THREADS;
-    auto l2_lds = [&](int ln) { return ((size_t)a.cnt_slots * ln * 2 + (size_t)a.smax_words * ln * 4 + 15) / 16 * 16; };
-    while (lanes > 1 && l2_lds(lanes) > 144 * 1024) lanes >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
-    size_t lds = l2_lds(lanes);
-    a.lanes = lanes;
-    FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state");
-    if (wide) {
-      if (rank_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2_rank<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
-      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2_scan<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_l2_rank<uint32_t>, dim3(nloci), dim3(RANK_THREADS), rank_lds, st, a);
-      hipLaunchKernelGGL(k_l2_scan<uint32_t>, dim3(ceil_div(nloci, lanes)), dim3(L2_THREADS), lds, st, a);
-    } else {
-      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l2_scan<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_l2_rank<uint16_t>, dim3(nloci), dim3(RANK_THREADS), rank_lds, st, a);
-      hipLaunchKernelGGL(k_l2_scan<uint16_t>, dim3(ceil_div(nloci, lanes)), dim3(L2_THREADS), lds, st, a);
-    }
+    const size_t q_lds = ((size_t)smax * 4 + 15) / 16 * 16;
+    a.wpos_lds = 4096;                                         // records of a locus range staged in LDS (longer ranges read HBM)
+    size_t rank_lds = q_lds + (size_t)a.wpos_lds * 4 + 16;
+    FA_REQUIRE(rank_lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
+    m.l_redo.ensure((size_t)nloci + 4);
+    a.l_redo = m.l_redo.p;
+    a.redo_count = m.counters.p + 3;
+    // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
+    auto scan_lds = [&](int ln, int bytes) { return ((size_t)a.cnt_slots * ln * bytes + 15) / 16 * 16; };
+    auto pick_lanes = [&](int bytes) {
+      int ln = L2_THREADS;
+      while (ln > 1 && scan_lds(ln, bytes) > 144 * 1024) ln >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
+      FA_REQUIRE(scan_lds(ln, bytes) <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state");
+      return ln;
+    };
+    FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
+    const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
+    const size_t lds8 = scan_lds(lanes8, 1), lds16 = scan_lds(lanes16, 2);
+    auto launch = [&](auto ev_kernel, auto scan8, auto scan16) {
+      if (rank_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
+      if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+      if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+      hipLaunchKernelGGL(ev_kernel, dim3(nloci), dim3(EV_THREADS), rank_lds, st, a);
+      a.lanes = lanes8;
+      hipLaunchKernelGGL(scan8, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
+      a.lanes = lanes16;
+      hipLaunchKernelGGL(scan16, dim3(ceil_div(nloci, lanes16)), dim3(L2_THREADS), lds16, st, a);
+    };
+    if (wide) launch(k_l2_events<uint32_t>, k_l2_scan<uint32_t, uint8_t>, k_l2_scan<uint32_t, uint16_t>);
+    else launch(k_l2_events<uint16_t>, k_l2_scan<uint16_t, uint8_t>, k_l2_scan<uint16_t, uint16_t>);
     FA_HIP(hipGetLastError());
   }
   FA_HIP(hipEventRecord(m.ev[3], st));
@@ -562,13 +580,16 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
     exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
     int32_t total_rows = 0;
+    uint32_t redo = 0;
     FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    FA_HIP(hipMemcpyAsync(&redo, m.counters.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
                        npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
     FA_HIP(hipGetLastError());
     FA_HIP(hipEventRecord(m.ev[4], st));
     FA_HIP(hipStreamSynchronize(st));
     nrows = total_rows;
+    m.last_ms[8] += (float)redo;   // loci that needed the wide L2 state
   } else {
     FA_HIP(hipEventRecord(m.ev[4], st));
     FA_HIP(hipStreamSynchronize(st));
@@ -1010,7 +1031,7 @@ int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t 
 }
 
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {
-  for (int i = 0; i < n && i < 8; i++) ms[i] = m->last_ms[i];
+  for (int i = 0; i < n && i < 16; i++) ms[i] = m->last_ms[i];
   return FA_OK;
 }
 int fa_mapper_stream(fa_mapper *m, void **stream) { *stream = (void *)m->stream; return FA_OK; }

@@ -440,21 +440,26 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
 // r* moves by at most one per inserted / deleted hash, exactly like the reference's pivot.
 // ----------------------------------------------------------------------------------------------------------
 // The work is split into three launches so that nothing slow sits on the sequential chain:
-//   k_l2_prep   one lane per locus: the three searchIndex() binary searches -> record range [beg, last) and the end
-//               of the first super-window;
-//   k_l2_rank   one workgroup per locus, query sketch staged in LDS: every record of the range is reduced to an
-//               `item` = rank | found | the duplicate-linking flags (fully parallel, 8-step binary searches);
-//   k_l2_scan   one lane per locus: the sequential slide, reading one precomputed item per admitted / dropped record
-//               and keeping cnt[] / the matched bitmap in lane-interleaved LDS.
+//   k_l2_prep   one lane per locus: the searchIndex() binary searches -> record range [beg, last), the end of the
+//               first super-window, and the number of slide events;
+//   k_l2_events one workgroup per locus, query sketch and the locus' window positions staged in LDS: every record is
+//               reduced to its rank in the query sketch (8-step binary search) and written as one or two *events*
+//               (admit / drop) directly at their position in the time-ordered event stream of the locus -- the merge
+//               of the two monotone streams is a binary search per record, so this kernel is fully parallel;
+//   k_l2_scan   one lane per locus: the sequential slide is now a fixed-trip loop over the event stream (one 16-byte
+//               load per 8 events), with cnt[] / the matched bitmap in lane-interleaved LDS.
+// Event layout: rank | found | drop | skip | eval.  `skip` = the duplicate-linking rule says the set does not change;
+// `eval` = last event of its window position, i.e. the point where the reference compares sharedSketchElements.
 struct L2Args {
   IndexView ix;
   const uint32_t *q_hash;
   const int32_t *q_size;
   const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;
   int32_t *l_beg, *l_end0, *l_last;  // record range of the locus, end of the first super-window
-  uint32_t *l_items;                 // [loci + 1] number of records in the range, then (after the scan) offsets
+  int32_t *l_ndrop;                  // records dropped before the slide ends
+  uint32_t *l_items;                 // [loci + 1] events of the locus rounded up to a multiple of 8
   const uint32_t *l_ioff;            // exclusive scan of l_items
-  void *items;                       // uint16 or uint32 per record of every locus range
+  void *items;                       // uint16 or uint32 per event
   int32_t *l_shared, *l_pos;
   const int32_t *pass_lut;           // [smax+1]
   unsigned long long *group_best;    // [groups] (shared<<32 | ~locus)
@@ -462,17 +467,19 @@ struct L2Args {
   int32_t qcap, cmw, smax_words;     // smax_words = ceil((smax+1)/32)
   int32_t cnt_slots;                 // smax + 1
   int32_t lanes;                     // loci per workgroup of k_l2_scan (power of two <= 64)
+  int32_t wpos_lds;                  // window positions staged per workgroup of k_l2_events
+  unsigned long long *rec_total;     // sum over loci of the records in their range (for the roofline line)
+  uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
+  uint32_t *redo_count;              // number of loci sent to the uint16 pass
 };
 
 constexpr int L2_THREADS = 64;
-constexpr int RANK_THREADS = 128;
+constexpr int EV_THREADS = 128;
 
-// item layouts: rank in the low bits, then found / previous-occurrence-linked / next-occurrence-linked / duplicate of a
-// record already inside the first super-window
-template <typename T> struct ItemBits;
-template <> struct ItemBits<uint16_t> { static constexpr int RANK = 12; };
-template <> struct ItemBits<uint32_t> { static constexpr int RANK = 24; };
-constexpr uint32_t IT_FOUND = 1, IT_INS_LINKED = 2, IT_DEL_LINKED = 4, IT_INIT_DUP = 8;
+template <typename T> struct EvBits;
+template <> struct EvBits<uint16_t> { static constexpr int RANK = 12; };
+template <> struct EvBits<uint32_t> { static constexpr int RANK = 24; };
+constexpr uint32_t EV_FOUND = 1, EV_DROP = 2, EV_SKIP = 4, EV_EVAL = 8;
 
 __global__ void k_l2_prep(L2Args a) {
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -482,127 +489,165 @@ __global__ void k_l2_prep(L2Args a) {
   const int seq = a.l_seq[l];
   const int lo = a.ix.contig_rec[seq], hi = a.ix.contig_rec[seq + 1];
   const int32_t *wpos = a.ix.rec_wpos;
-  auto lower = [&](int from, int target) {
-    int x = from, y = hi;
+  auto lower = [&](int from, int to, int target) {
+    int x = from, y = to;
     while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
     return x;
   };
-  const int beg = lower(lo, a.l_start[l]);                       // searchIndex(seqId, rangeStartPos)
-  const int end0 = lower(beg, wpos[beg] + a.cmw);                // searchIndex(seqId, first wpos + countMinimizerWindows)
-  const int last = lower(end0, a.l_end[l] + a.cmw);              // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
-  a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last;
-  a.l_items[l] = (uint32_t)(last - beg);
+  const int beg = lower(lo, hi, a.l_start[l]);                       // searchIndex(seqId, rangeStartPos)
+  const int end0 = lower(beg, hi, wpos[beg] + a.cmw);                // searchIndex(seqId, first wpos + countMinimizerWindows)
+  const int last = lower(end0, hi, a.l_end[l] + a.cmw);              // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
+  int ndrop = 0;
+  if (last > end0) {
+    // the slide stops at the window position where the last record is admitted; record r is dropped at wpos[r+1]
+    const int p_last = wpos[last - 1] - a.cmw + 1;
+    ndrop = lower(beg + 1, hi, p_last + 1) - (beg + 1);              // #{r >= beg : wpos[r+1] <= p_last}
+  }
+  a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last; a.l_ndrop[l] = ndrop;
+  a.l_items[l] = (uint32_t)((last - beg + ndrop + 7) & ~7);
+  atomicAdd(a.rec_total, (unsigned long long)(last - beg));
 }
 
 template <typename T>
-__global__ __launch_bounds__(RANK_THREADS) void k_l2_rank(L2Args a) {
+__global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  uint32_t *Q = (uint32_t *)lds;
+  uint32_t *Q = (uint32_t *)lds;                                     // [smax]
+  int32_t *W = (int32_t *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16);   // [wpos_lds]
   const uint32_t l = blockIdx.x;
   const int f = a.l_frag[l];
   const int s = a.q_size[f];
-  for (int i = threadIdx.x; i < s; i += RANK_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
+  const int32_t *gw = a.ix.rec_wpos;
+  // window positions of records [beg, last + 1) (the drop time of record r is wpos[r+1])
+  const int nw = last - beg + 1;
+  const bool staged = nw <= a.wpos_lds;
+  const int hi = a.ix.contig_rec[a.l_seq[l] + 1];
+  for (int i = threadIdx.x; i < s; i += EV_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  if (staged) for (int i = threadIdx.x; i < nw; i += EV_THREADS) W[i] = (beg + i < hi) ? gw[beg + i] : 0x7FFFFFFF;
   __syncthreads();
-  const int beg = a.l_beg[l], last = a.l_last[l];
+  auto wp = [&](int i) { return staged ? W[i - beg] : ((i < hi) ? gw[i] : 0x7FFFFFFF); };
+  const int n_init = end0 - beg;
+  const uint32_t total = (uint32_t)(last - beg + ndrop);
+  const uint32_t padded = (total + 7u) & ~7u;
   T *out = (T *)a.items + a.l_ioff[l];
-  for (int i = beg + (int)threadIdx.x; i < last; i += RANK_THREADS) {
+  for (uint32_t i = total + threadIdx.x; i < padded; i += EV_THREADS) out[i] = (T)(EV_SKIP << EvBits<T>::RANK);
+  for (int i = beg + (int)threadIdx.x; i < last; i += EV_THREADS) {
     const uint32_t h = a.ix.rec_hash[i];
     int x = 0, y = s;
     while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
-    uint32_t flags = (x < s && Q[x] == h) ? IT_FOUND : 0u;
+    const uint32_t base = (uint32_t)x | (((x < s && Q[x] == h) ? EV_FOUND : 0u) << EvBits<T>::RANK);
     const uint8_t rf = a.ix.rec_flags[i];
-    if (rf & FLAG_INS_LINKED) flags |= IT_INS_LINKED;
-    if (rf & FLAG_DEL_LINKED) flags |= IT_DEL_LINKED;
-    if (a.ix.rec_prev[i] >= beg) flags |= IT_INIT_DUP;
-    out[i - beg] = (T)((uint32_t)x | (flags << ItemBits<T>::RANK));
+    if (i < end0) {
+      // first super-window: inserted in record order, compared once after the last one
+      uint32_t fl = (a.ix.rec_prev[i] >= beg ? EV_SKIP : 0u) | (i == end0 - 1 ? EV_EVAL : 0u);
+      out[i - beg] = (T)(base | (fl << EvBits<T>::RANK));
+    } else {
+      // admitted at window position ta = wpos - cmw + 1, after the drops of positions <= ta
+      const int ta = wp(i) - a.cmw + 1;
+      int lo2 = beg + 1, hi2 = beg + 1 + ndrop;                       // drop times wpos[beg+1 .. beg+ndrop]
+      while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (wp(mid) <= ta) lo2 = mid + 1; else hi2 = mid; }
+      const uint32_t pos = (uint32_t)(n_init + (i - end0) + (lo2 - (beg + 1)));
+      uint32_t fl = ((rf & FLAG_INS_LINKED) ? EV_SKIP : 0u) | EV_EVAL;
+      out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+    }
+    if (i - beg < ndrop) {
+      // dropped at window position td = wpos[i+1], before the admit of that position (if any)
+      const int td = wp(i + 1);
+      int lo2 = end0, hi2 = last;                                     // admits with time < td  <=>  wpos < td + cmw - 1
+      const int key = td + a.cmw - 1;
+      while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (wp(mid) < key) lo2 = mid + 1; else hi2 = mid; }
+      const uint32_t pos = (uint32_t)(n_init + (i - beg) + (lo2 - end0));
+      const bool admit_same_step = lo2 < last && wp(lo2) == key;
+      uint32_t fl = EV_DROP | ((rf & FLAG_DEL_LINKED) ? EV_SKIP : 0u) | (admit_same_step ? 0u : EV_EVAL);
+      out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+    }
   }
 }
 
-template <typename T>
+// State of one lane: ST[r] = (query rank r currently matched) << (bits-1) | number of distinct window-only hashes of
+// insertion rank r.  ST is uint8 on the fast path (one byte per rank keeps 8 waves per CU resident); if a count would
+// reach 128 the lane flags its locus and the uint16 instantiation redoes it (l_redo).
+template <typename T, typename ST>
 __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  // per-lane arrays, lane-interleaved so that a lane's own element never collides with another lane's bank
+  constexpr int SBITS = 8 * (int)sizeof(ST);
+  constexpr uint32_t MATCH = 1u << (SBITS - 1), CMASK = MATCH - 1u;
+  constexpr bool REDO = sizeof(ST) > 1;
   const int LN = a.lanes;
-  uint16_t *cnt = (uint16_t *)lds;                                 // [cnt_slots][LN]
-  uint32_t *mbit = (uint32_t *)(lds + (size_t)a.cnt_slots * LN * 2);   // [smax_words][LN]
+  ST *st = (ST *)lds;                                              // [cnt_slots][LN], lane-interleaved
   const int lane = threadIdx.x;
   if (lane >= LN) return;
   const uint32_t l = blockIdx.x * LN + lane;
   if (l >= a.counters[0]) return;
+  if (REDO) { if (!a.l_redo[l]) return; }
+  else a.l_redo[l] = 0;
   const int s = a.q_size[a.l_frag[l]];
-  const int hi = a.ix.contig_rec[a.l_seq[l] + 1];
-  const int32_t *wpos = a.ix.rec_wpos;
-  const int beg0 = a.l_beg[l], last = a.l_last[l];
-  int beg = beg0, end = a.l_end0[l];
-  const T *items = (const T *)a.items + a.l_ioff[l];
-  constexpr uint32_t RANK_MASK = (1u << ItemBits<T>::RANK) - 1u;
-  for (int i = 0; i <= s; i++) cnt[i * LN + lane] = 0;
-  for (int i = 0; i < (s + 32) / 32; i++) mbit[i * LN + lane] = 0;
+  const int beg0 = a.l_beg[l];
+  const uint32_t nev = a.l_ioff[l + 1] - a.l_ioff[l];               // multiple of 8
+  constexpr int PER = 16 / sizeof(T);                               // events per 16-byte load
+  const uint4 *ev = (const uint4 *)((const T *)a.items + a.l_ioff[l]);
+  constexpr uint32_t RANK_MASK = (1u << EvBits<T>::RANK) - 1u;
+  for (int i = 0; i <= s; i++) st[i * LN + lane] = 0;
 
-  int rstar = s, P = 0, shared = 0;
-  auto test = [&](int r) { return (mbit[(r >> 5) * LN + lane] >> (r & 31)) & 1u; };
-  auto insert = [&](uint32_t it) {
-    const int r = (int)(it & RANK_MASK);
-    if ((it >> ItemBits<T>::RANK) & IT_FOUND) {
-      mbit[(r >> 5) * LN + lane] |= 1u << (r & 31);
-      if (r < rstar) shared++;
-    } else {
-      cnt[r * LN + lane] += 1;
-      if (r < rstar) {
-        P++;
-        if (rstar - 1 + P >= s) {            // f(r*-1) reached s: the largest query rank falls out of the first s
-          rstar--;
-          P -= cnt[rstar * LN + lane];
-          if (test(rstar)) shared--;
+  int rstar = s, P = 0, shared = 0, beg = beg0;
+  int best = -1, opt_s = beg0, opt_e = beg0;
+  bool overflow = false;
+  const uint32_t ngroups = nev / PER;
+  uint4 cur = ngroups ? ev[0] : make_uint4(0, 0, 0, 0);
+  for (uint32_t g = 0; g < ngroups; g++) {
+    const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);   // prefetch: the load is off the chain
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      constexpr int WPE = (int)sizeof(T);
+      uint32_t word = (q * WPE / 4 == 0) ? cur.x : (q * WPE / 4 == 1) ? cur.y : (q * WPE / 4 == 2) ? cur.z : cur.w;
+      const uint32_t e = sizeof(T) == 2 ? ((q & 1) ? (word >> 16) : (word & 0xFFFFu)) : word;
+      const int r = (int)(e & RANK_MASK);
+      const uint32_t fl = e >> EvBits<T>::RANK;
+      const bool drop = (fl & EV_DROP) != 0;
+      const int delta = drop ? -1 : 1;
+      if (!(fl & EV_SKIP)) {
+        const uint32_t v = st[r * LN + lane];
+        if (fl & EV_FOUND) {
+          st[r * LN + lane] = (ST)(drop ? (v & CMASK) : (v | MATCH));
+          shared += (r < rstar) ? delta : 0;
+        } else {
+          const uint32_t nv = v + (uint32_t)delta;                 // count lives in the low bits; MATCH bit untouched
+          if (!drop && (nv & CMASK) == 0) overflow = true;         // count wrapped into the MATCH bit
+          st[r * LN + lane] = (ST)nv;
+          P += (r < rstar) ? delta : 0;
+          if (drop) {
+            // a window-only hash left: the next query rank may re-enter the s smallest of the union
+            if (rstar < s) {
+              const uint32_t vr = (r == rstar) ? nv : (uint32_t)st[rstar * LN + lane];
+              const int cr = (int)(vr & CMASK);
+              if (rstar + P + cr < s) {
+                P += cr;
+                shared += (vr & MATCH) ? 1 : 0;
+                rstar++;
+              }
+            }
+          } else if (r < rstar && rstar - 1 + P >= s) {
+            // f(r*-1) reached s: the largest query rank falls out of the s smallest of the union
+            rstar--;
+            const uint32_t vr = (r == rstar) ? nv : (uint32_t)st[rstar * LN + lane];
+            P -= (int)(vr & CMASK);
+            shared -= (vr & MATCH) ? 1 : 0;
+          }
         }
       }
-    }
-  };
-  auto remove = [&](uint32_t it) {
-    const int r = (int)(it & RANK_MASK);
-    if ((it >> ItemBits<T>::RANK) & IT_FOUND) {
-      mbit[(r >> 5) * LN + lane] &= ~(1u << (r & 31));
-      if (r < rstar) shared--;
-    } else {
-      cnt[r * LN + lane] -= 1;
-      if (r < rstar) P--;
-      if (rstar < s && rstar + P + (int)cnt[rstar * LN + lane] < s) {
-        P += cnt[rstar * LN + lane];
-        if (test(rstar)) shared++;
-        rstar++;
+      beg += drop ? 1 : 0;
+      if (fl & EV_EVAL) {
+        if (shared > best) { best = shared; opt_s = beg; opt_e = beg; }
+        else if (shared == best) opt_e = beg;
       }
     }
-  };
-
-  // first super-window: distinct hashes among records [beg, end)
-  for (int i = beg; i < end; i++) {
-    uint32_t it = items[i - beg0];
-    if (!((it >> ItemBits<T>::RANK) & IT_INIT_DUP)) insert(it);
+    cur = nxt;
   }
-  int p = wpos[beg];
-  int best = shared, opt_s = p, opt_e = p;
-  int next_drop = (beg + 1 < hi) ? wpos[beg + 1] : 0x7FFFFFFF;
-  int w_end = end < last ? wpos[end] : 0x7FFFFFFF;
-  while (end < last) {
-    // next window position at which a record is dropped or admitted
-    p = max(p + 1, min(next_drop, w_end - a.cmw + 1));
-    if (next_drop <= p) {
-      uint32_t it = items[beg - beg0];
-      if (!((it >> ItemBits<T>::RANK) & IT_DEL_LINKED)) remove(it);
-      beg++;
-      next_drop = (beg + 1 < hi) ? wpos[beg + 1] : 0x7FFFFFFF;
-    }
-    if (w_end <= p + a.cmw - 1) {
-      uint32_t it = items[end - beg0];
-      if (!((it >> ItemBits<T>::RANK) & IT_INS_LINKED)) insert(it);
-      end++;
-      w_end = end < last ? wpos[end] : 0x7FFFFFFF;
-    }
-    if (shared > best) { best = shared; opt_s = opt_e = wpos[beg]; }
-    else if (shared == best) opt_e = wpos[beg];
+  if (overflow) {
+    if (!REDO) { a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u); return; }
   }
-  a.l_shared[l] = best;
-  a.l_pos[l] = (opt_s + opt_e) / 2;
+  a.l_shared[l] = best < 0 ? 0 : best;
+  a.l_pos[l] = (a.ix.rec_wpos[opt_s] + a.ix.rec_wpos[opt_e]) / 2;
   if (best >= a.pass_lut[s]) {
     unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)(0xFFFFFFFFu - l);
     atomicMax(&a.group_best[a.l_group[l]], key);

@@ -68,8 +68,6 @@ def oracle_mappings(det):
 def test_minimizer_streams(k, frag):
     sk = quiet_sketch(pf.Sketch, k=k, fragment_length=frag)
     osk = OracleSketch(k=k, fragment_length=frag)
-    if osk.window_size < 0:
-        pytest.skip("degenerate parameter cell: no admissible sketch size")
     assert sk.window_size == osk.window_size
     g = syn.rng(100 + k)
     w = sk.window_size
@@ -237,6 +235,27 @@ def test_frequency_threshold_active():
     query = [syn.to_ascii(syn.mutate_codes(g, m, 0.02))]
     mapper, hits, ohits, det = run_both({}, refs, query, threads=8)
     assert mapper.occurences_threshold == 218                  # value from the oracle
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+
+
+def test_small_sketch_against_crowded_window():
+    # percentage_identity=68 gives w=3, so a super-window holds ~1500 reference minimizers, while a fragment that is
+    # all N except a ~20 bp island keeps about twenty: hundreds of window-only hashes share one insertion rank,
+    # which overflows the one-byte L2 lane state and sends those loci through the uint16 redo pass.
+    g = syn.rng(55)
+    ref = syn.random_codes(g, 200_000)
+    q = bytearray(b"N" * 3000 * 60)
+    for f in range(60):
+        n, a = 17 + f % 14, 5000 + f * 3000
+        q[f * 3000 + 1400: f * 3000 + 1400 + n] = bytes(syn.to_ascii(ref[a: a + n]))
+    params = {"minimum_fraction": 0.0, "percentage_identity": 68.0}
+    mapper, hits, ohits, det = run_both(params, [[syn.to_ascii(ref)]], [bytes(q)], threads=8)
+    assert mapper.window_size == 3
+    ms = (C.c_float * 16)()
+    lib.fa_mapper_last_timings(mapper._h, ms, 16)
+    assert ms[8] > 0, "the wide-state redo pass was not exercised"
+    assert len(det["mappings"]["qseq"]) >= 5
     assert gpu_mappings(mapper) == oracle_mappings(det)
     assert hit_tuples(hits) == ohits
 

@@ -57,13 +57,13 @@ WORKER = textwrap.dedent("""
     assert out.tolist() == [tuple(w) for w in np.array(want, dtype=ROW_DTYPE).tolist()], (rank, out.tolist())
     dist.barrier()
     dist.destroy_process_group()
-    print("rank", rank, "ok", len(out))
+    open(os.path.join({out!r}, f"rank{{rank}}.ok"), "w").write(str(len(out)))
 """)
 
 
 def test_all_gather_rows_world2(tmp_path):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
+    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -72,4 +72,4 @@ def test_all_gather_rows_world2(tmp_path):
            "--master-port", str(port), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
-    assert "rank 0 ok 11" in res.stdout and "rank 1 ok 11" in res.stdout
+    assert (tmp_path / "rank0.ok").read_text() == "11" and (tmp_path / "rank1.ok").read_text() == "11"
