@@ -235,7 +235,7 @@ struct fa_mapper {
   DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
   DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
   DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop;
-  DevBuf<uint32_t> l_items, l_ioff;
+  DevBuf<uint32_t> l_items, l_ioff, f_loci_lo, f_loci_n;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo;
   uint64_t last_items = 0;
@@ -422,6 +422,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, m.sk.stage_hash.p, m.sk.stage_wpos.p, m.sk.tile_count.p, st);
   m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
   m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
+  m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
   m.stats_dev.ensure(4); m.totals.ensure(4); m.counters.ensure(4);
   FA_HIP(hipMemsetAsync(m.stats_dev.p, 0, 4 * sizeof(int32_t), st));
   FA_HIP(hipMemsetAsync(m.totals.p, 0, 4 * sizeof(uint64_t), st));
@@ -475,6 +476,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
     a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
     a.lds_seed_cap = LDS_SEED_CAP;
+    a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
     uint32_t seed_slots = std::min<uint32_t>(LDS_SEED_CAP, next_pow2((uint32_t)std::max<uint64_t>(max_seeds, 2)));
     size_t lds = (size_t)seed_slots * 4;
     if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -505,7 +507,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.smax_words = (smax + 32) / 32;
     a.lanes = L2_THREADS;
     a.rec_total = (unsigned long long *)(m.totals.p + 3);
-    a.wpos_lds = 4096;
+    a.wpos_lds = 1024;
     hipLaunchKernelGGL(k_l2_prep, dim3(ceil_div((int64_t)nloci + 1, 256)), dim3(256), 0, st, a);
     {
       size_t bytes = 0;
@@ -526,12 +528,13 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.last_ms[7] += (float)total_items;     // slide events
     m.last_ms[6] += (float)nloci;
     const size_t q_lds = ((size_t)smax * 4 + 15) / 16 * 16;
-    a.wpos_lds = 4096;                                         // records of a locus range staged in LDS (longer ranges read HBM)
-    size_t rank_lds = q_lds + (size_t)a.wpos_lds * 4 + 16;
+    a.wpos_lds = 1024;                                         // records of a locus range staged in LDS per wave (longer ranges read HBM)
+    size_t rank_lds = q_lds + (size_t)a.wpos_lds * 4 * (EV_THREADS / 64) + 16;
     FA_REQUIRE(rank_lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
     m.l_redo.ensure((size_t)nloci + 4);
     a.l_redo = m.l_redo.p;
     a.redo_count = m.counters.p + 3;
+    a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
     // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
     auto scan_lds = [&](int ln, int bytes) { return ((size_t)a.cnt_slots * ln * bytes + 15) / 16 * 16; };
     auto pick_lanes = [&](int bytes) {
@@ -547,7 +550,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       if (rank_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
       if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
       if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-      hipLaunchKernelGGL(ev_kernel, dim3(nloci), dim3(EV_THREADS), rank_lds, st, a);
+      hipLaunchKernelGGL(ev_kernel, dim3((unsigned)F), dim3(EV_THREADS), rank_lds, st, a);
       a.lanes = lanes8;
       hipLaunchKernelGGL(scan8, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
       a.lanes = lanes16;
@@ -574,7 +577,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(std::max<uint32_t>(ngroups, 1), 256)), dim3(256), 0, st, a);
     m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
     m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
-    hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 128)), dim3(128), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
+    hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
                        m.row_count.p, m.row_ident.p);
     hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
     FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));

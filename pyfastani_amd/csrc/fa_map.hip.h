@@ -282,6 +282,7 @@ struct L1Args {
   const int32_t *min_hits_lut;   // [smax+1]
   int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
   uint32_t *counters;            // [0] loci, [1] groups, [2] loci overflow flag
+  uint32_t *f_loci_lo, *f_loci_n; // [F] loci of each fragment (contiguous)
   int32_t qcap, frag_len, l_cap;
   uint32_t lds_seed_cap;
 };
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
   const uint32_t n = a.n_seeds[f];
+  if (tid == 0) { a.f_loci_lo[f] = 0; a.f_loci_n[f] = 0; }
   if (s == 0 || n == 0) return;
   uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
   if (n32 < 2) n32 = 2;
@@ -390,6 +392,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
         if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); cnt = 0; }
         sh_base = base;
         sh_gbase = cnt;   // reuse: number of loci (0 => skip)
+        a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
       }
       __syncthreads();
       if (sh_gbase == 0) return;
@@ -471,10 +474,11 @@ struct L2Args {
   unsigned long long *rec_total;     // sum over loci of the records in their range (for the roofline line)
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
+  const uint32_t *f_loci_lo, *f_loci_n;   // [F] loci of each fragment
 };
 
 constexpr int L2_THREADS = 64;
-constexpr int EV_THREADS = 128;
+constexpr int EV_THREADS = 256;
 
 template <typename T> struct EvBits;
 template <> struct EvBits<uint16_t> { static constexpr int RANK = 12; };
@@ -508,59 +512,108 @@ __global__ void k_l2_prep(L2Args a) {
   atomicAdd(a.rec_total, (unsigned long long)(last - beg));
 }
 
+// first j in [lo, hi] with !pred(j) (pred is true on a prefix), searching outwards from a guess: the two event
+// streams of a locus advance almost in lock-step, so the answer is a handful of records away from the guess
+template <typename F>
+__device__ __forceinline__ int gallop(int lo, int hi, int guess, F pred) {
+  guess = min(max(guess, lo), hi);
+  int L, R;
+  if (guess < hi && pred(guess)) {
+    L = guess + 1;
+    int step = 1;
+    R = min(hi, L + step);
+    while (R < hi && pred(R)) { L = R + 1; step <<= 1; R = min(hi, R + step); }
+  } else {
+    R = guess;
+    int step = 1;
+    L = max(lo, R - step);
+    while (L > lo && !pred(L)) { R = L; step <<= 1; L = max(lo, L - step); }
+    if (L < R && pred(L)) L = L + 1;
+  }
+  while (L < R) { int mid = (L + R) >> 1; if (pred(mid)) L = mid + 1; else R = mid; }
+  return L;
+}
+
 template <typename T>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  uint32_t *Q = (uint32_t *)lds;                                     // [smax]
-  int32_t *W = (int32_t *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16);   // [wpos_lds]
-  const uint32_t l = blockIdx.x;
-  const int f = a.l_frag[l];
+  uint32_t *Q = (uint32_t *)lds;                                     // [smax], staged once per fragment
+  const int f = blockIdx.x;
+  const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
+  if (l_n == 0) return;
   const int s = a.q_size[f];
-  const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
-  const int32_t *gw = a.ix.rec_wpos;
-  // window positions of records [beg, last + 1) (the drop time of record r is wpos[r+1])
-  const int nw = last - beg + 1;
-  const bool staged = nw <= a.wpos_lds;
-  const int hi = a.ix.contig_rec[a.l_seq[l] + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int32_t *W = (int32_t *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.wpos_lds;   // per wave
   for (int i = threadIdx.x; i < s; i += EV_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
-  if (staged) for (int i = threadIdx.x; i < nw; i += EV_THREADS) W[i] = (beg + i < hi) ? gw[beg + i] : 0x7FFFFFFF;
   __syncthreads();
-  auto wp = [&](int i) { return staged ? W[i - beg] : ((i < hi) ? gw[i] : 0x7FFFFFFF); };
-  const int n_init = end0 - beg;
-  const uint32_t total = (uint32_t)(last - beg + ndrop);
-  const uint32_t padded = (total + 7u) & ~7u;
-  T *out = (T *)a.items + a.l_ioff[l];
-  for (uint32_t i = total + threadIdx.x; i < padded; i += EV_THREADS) out[i] = (T)(EV_SKIP << EvBits<T>::RANK);
-  for (int i = beg + (int)threadIdx.x; i < last; i += EV_THREADS) {
-    const uint32_t h = a.ix.rec_hash[i];
+  // bucket table over the top 8 hash bits: QT[b] = first query rank whose hash is >= b << 24
+  __shared__ uint16_t QT[258];
+  for (int b = threadIdx.x; b <= 256; b += EV_THREADS) {
     int x = 0, y = s;
-    while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
-    const uint32_t base = (uint32_t)x | (((x < s && Q[x] == h) ? EV_FOUND : 0u) << EvBits<T>::RANK);
-    const uint8_t rf = a.ix.rec_flags[i];
-    if (i < end0) {
-      // first super-window: inserted in record order, compared once after the last one
-      uint32_t fl = (a.ix.rec_prev[i] >= beg ? EV_SKIP : 0u) | (i == end0 - 1 ? EV_EVAL : 0u);
-      out[i - beg] = (T)(base | (fl << EvBits<T>::RANK));
-    } else {
-      // admitted at window position ta = wpos - cmw + 1, after the drops of positions <= ta
-      const int ta = wp(i) - a.cmw + 1;
-      int lo2 = beg + 1, hi2 = beg + 1 + ndrop;                       // drop times wpos[beg+1 .. beg+ndrop]
-      while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (wp(mid) <= ta) lo2 = mid + 1; else hi2 = mid; }
-      const uint32_t pos = (uint32_t)(n_init + (i - end0) + (lo2 - (beg + 1)));
-      uint32_t fl = ((rf & FLAG_INS_LINKED) ? EV_SKIP : 0u) | EV_EVAL;
-      out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+    const uint64_t key = (uint64_t)b << 24;
+    while (x < y) { int mid = (x + y) >> 1; if ((uint64_t)Q[mid] < key) x = mid + 1; else y = mid; }
+    QT[b] = (uint16_t)x;
+  }
+  __syncthreads();
+  const int32_t *gw = a.ix.rec_wpos;
+  // the waves of the workgroup take the loci of the fragment round-robin; everything below is wave-synchronous
+  for (uint32_t l = l_lo + wv; l < l_lo + l_n; l += EV_THREADS / 64) {
+    const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
+    const int hi = a.ix.contig_rec[a.l_seq[l] + 1];
+    // window positions of records [beg, last] (the drop time of record r is wpos[r+1])
+    const int nw = last - beg + 1;
+    const bool staged = nw <= a.wpos_lds;
+    if (staged) for (int i = lane; i < nw; i += 64) W[i] = (beg + i < hi) ? gw[beg + i] : 0x7FFFFFFF;
+    __builtin_amdgcn_wave_barrier();
+    auto wp = [&](int i) { return staged ? W[i - beg] : ((i < hi) ? gw[i] : 0x7FFFFFFF); };
+    const int n_init = end0 - beg;
+    const uint32_t total = (uint32_t)(last - beg + ndrop);
+    const uint32_t padded = (total + 7u) & ~7u;
+    T *out = (T *)a.items + a.l_ioff[l];
+    for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)(EV_SKIP << EvBits<T>::RANK);
+    auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev) __attribute__((always_inline)) {
+      int x = QT[h >> 24], y = QT[(h >> 24) + 1];
+      while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
+      const uint32_t base = (uint32_t)x | (((x < s && Q[x] == h) ? EV_FOUND : 0u) << EvBits<T>::RANK);
+      if (i < end0) {
+        // first super-window: inserted in record order, compared once after the last one
+        uint32_t fl = (prev >= beg ? EV_SKIP : 0u) | (i == end0 - 1 ? EV_EVAL : 0u);
+        out[i - beg] = (T)(base | (fl << EvBits<T>::RANK));
+      } else {
+        // admitted at window position ta = wpos - cmw + 1, after the drops of positions <= ta
+        const int ta = wp(i) - a.cmw + 1;
+        // drop times wpos[beg+1 .. beg+ndrop]; the window holds ~n_init records, so record i enters while i - n_init leaves
+        const int lo2 = gallop(beg + 1, beg + 1 + ndrop, i - n_init + 1, [&](int j) { return wp(j) <= ta; });
+        const uint32_t pos = (uint32_t)(n_init + (i - end0) + (lo2 - (beg + 1)));
+        uint32_t fl = ((rf & FLAG_INS_LINKED) ? EV_SKIP : 0u) | EV_EVAL;
+        out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+      }
+      if (i - beg < ndrop) {
+        // dropped at window position td = wpos[i+1], before the admit of that position (if any)
+        const int td = wp(i + 1);
+        const int key = td + a.cmw - 1;                                 // admits with time < td  <=>  wpos < td + cmw - 1
+        const int lo2 = gallop(end0, last, i + n_init, [&](int j) { return wp(j) < key; });
+        const uint32_t pos = (uint32_t)(n_init + (i - beg) + (lo2 - end0));
+        const bool admit_same_step = lo2 < last && wp(lo2) == key;
+        uint32_t fl = EV_DROP | ((rf & FLAG_DEL_LINKED) ? EV_SKIP : 0u) | (admit_same_step ? 0u : EV_EVAL);
+        out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+      }
+    };
+    // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
+    for (int i0 = beg + lane; i0 < last; i0 += 256) {
+      uint32_t h[4]; uint8_t rf[4]; int32_t pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + 64 * u;
+        const bool ok = i < last;
+        h[u] = ok ? a.ix.rec_hash[i] : 0u;
+        rf[u] = ok ? a.ix.rec_flags[i] : (uint8_t)0;
+        pv[u] = ok ? a.ix.rec_prev[i] : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u]);
     }
-    if (i - beg < ndrop) {
-      // dropped at window position td = wpos[i+1], before the admit of that position (if any)
-      const int td = wp(i + 1);
-      int lo2 = end0, hi2 = last;                                     // admits with time < td  <=>  wpos < td + cmw - 1
-      const int key = td + a.cmw - 1;
-      while (lo2 < hi2) { int mid = (lo2 + hi2) >> 1; if (wp(mid) < key) lo2 = mid + 1; else hi2 = mid; }
-      const uint32_t pos = (uint32_t)(n_init + (i - beg) + (lo2 - end0));
-      const bool admit_same_step = lo2 < last && wp(lo2) == key;
-      uint32_t fl = EV_DROP | ((rf & FLAG_DEL_LINKED) ? EV_SKIP : 0u) | (admit_same_step ? 0u : EV_EVAL);
-      out[pos] = (T)(base | (fl << EvBits<T>::RANK));
-    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -605,36 +658,27 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
       const uint32_t fl = e >> EvBits<T>::RANK;
       const bool drop = (fl & EV_DROP) != 0;
       const int delta = drop ? -1 : 1;
-      if (!(fl & EV_SKIP)) {
-        const uint32_t v = st[r * LN + lane];
-        if (fl & EV_FOUND) {
-          st[r * LN + lane] = (ST)(drop ? (v & CMASK) : (v | MATCH));
-          shared += (r < rstar) ? delta : 0;
-        } else {
-          const uint32_t nv = v + (uint32_t)delta;                 // count lives in the low bits; MATCH bit untouched
-          if (!drop && (nv & CMASK) == 0) overflow = true;         // count wrapped into the MATCH bit
-          st[r * LN + lane] = (ST)nv;
-          P += (r < rstar) ? delta : 0;
-          if (drop) {
-            // a window-only hash left: the next query rank may re-enter the s smallest of the union
-            if (rstar < s) {
-              const uint32_t vr = (r == rstar) ? nv : (uint32_t)st[rstar * LN + lane];
-              const int cr = (int)(vr & CMASK);
-              if (rstar + P + cr < s) {
-                P += cr;
-                shared += (vr & MATCH) ? 1 : 0;
-                rstar++;
-              }
-            }
-          } else if (r < rstar && rstar - 1 + P >= s) {
-            // f(r*-1) reached s: the largest query rank falls out of the s smallest of the union
-            rstar--;
-            const uint32_t vr = (r == rstar) ? nv : (uint32_t)st[rstar * LN + lane];
-            P -= (int)(vr & CMASK);
-            shared -= (vr & MATCH) ? 1 : 0;
-          }
-        }
-      }
+      const bool active = !(fl & EV_SKIP);
+      const bool isM = active && (fl & EV_FOUND), isW = active && !(fl & EV_FOUND);
+      // both LDS reads are issued together: the touched rank, and the rank at the boundary r* the pivot may move across
+      const int rb = drop ? min(rstar, s) : max(rstar - 1, 0);
+      const uint32_t v = st[r * LN + lane];
+      const uint32_t vb0 = st[rb * LN + lane];
+      const uint32_t nv = isM ? (drop ? (v & CMASK) : (v | MATCH)) : (v + (isW ? (uint32_t)delta : 0u));
+      if (active) st[r * LN + lane] = (ST)nv;
+      overflow |= isW && !drop && (nv & CMASK) == 0;               // count wrapped into the MATCH bit
+      const bool below = r < rstar;
+      shared += (isM && below) ? delta : 0;
+      P += (isW && below) ? delta : 0;
+      const uint32_t vb = (rb == r) ? nv : vb0;
+      const int cb = (int)(vb & CMASK), mb = (vb & MATCH) ? 1 : 0;
+      // a window-only hash left and query rank r* re-enters the s smallest of the union ...
+      const bool up = isW && drop && rstar < s && (rstar + P + cb < s);
+      // ... or one arrived below r* and f(r*-1) reached s: the largest query rank falls out
+      const bool down = isW && !drop && below && (rstar - 1 + P >= s);
+      P += up ? cb : (down ? -cb : 0);
+      shared += up ? mb : (down ? -mb : 0);
+      rstar += up ? 1 : (down ? -1 : 0);
       beg += drop ? 1 : 0;
       if (fl & EV_EVAL) {
         if (shared > best) { best = shared; opt_s = beg; opt_e = beg; }
@@ -692,20 +736,33 @@ __global__ void k_cgi_bins(CgiArgs a) {
   atomicMax(&a.bins[(size_t)(a.frag_query[f] - a.query_base) * a.ix.total_bins + bin], key);
 }
 
-__global__ void k_cgi_rows(const unsigned long long *bins, const int32_t *genome_bin, int total_bins, int G, int NQ,
-                           int32_t *row_count, float *row_ident) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per (query genome, reference genome) pair: coalesced 64-bin reads, then the non-empty bins are added one
+// by one in bin order (readlane + add), which reproduces the reference's sequential float32 sum bit for bit.
+__global__ __launch_bounds__(256) void k_cgi_rows(const unsigned long long *bins, const int32_t *genome_bin, int total_bins, int G, int NQ,
+                                                  int32_t *row_count, float *row_ident) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= (int64_t)NQ * G) return;
-  int q = (int)(i / G), g = (int)(i % G);
+  const int q = (int)(i / G), g = (int)(i % G);
   const unsigned long long *b = bins + (size_t)q * total_bins;
+  const int x0 = genome_bin[g], x1 = genome_bin[g + 1];
   int cnt = 0;
   float sum = 0.0f;
-  for (int x = genome_bin[g]; x < genome_bin[g + 1]; x++) {
-    unsigned long long v = b[x];
-    if (v) { cnt++; sum += __uint_as_float((uint32_t)(v >> 32)); }
+  for (int x = x0; x < x1; x += 64) {
+    unsigned long long v = (x + lane < x1) ? b[x + lane] : 0ULL;
+    float val = __uint_as_float((uint32_t)(v >> 32));
+    unsigned long long mask = __ballot(v != 0ULL);
+    cnt += __popcll(mask);
+    while (mask) {
+      int src = __ffsll((long long)mask) - 1;
+      sum += __shfl(val, src);
+      mask &= mask - 1;
+    }
   }
-  row_count[i] = cnt;
-  row_ident[i] = cnt ? sum / (float)cnt : 0.0f;
+  if (lane == 0) {
+    row_count[i] = cnt;
+    row_ident[i] = cnt ? sum / (float)cnt : 0.0f;
+  }
 }
 
 // ordered compaction of the non-empty (query, genome) pairs into fa_cgi_row records
