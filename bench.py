@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--refs", type=int, default=100, help="reference genomes in the index (60%% related)")
     ap.add_argument("--length", type=int, default=5_000_000)
+    ap.add_argument("--batch", type=int, default=1, help="query genomes mapped per step and per GPU (1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-refs", type=int, default=10, help="references in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -86,14 +87,14 @@ def main():
     mapper = sk.index()
     t_index = time.time() - t0
     gq = syn.rng(5000 + rank)
-    query = syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))
-    batch = mapper.upload_genomes([[query]])
-    n_pairs_step = args.refs
+    queries = [[syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))] for _ in range(args.batch)]
+    batch = mapper.upload_genomes(queries)
+    n_pairs_step = args.refs * args.batch
 
-    rows = torch.zeros((max(args.refs, 1), 5), dtype=torch.int32, device="cuda")
+    rows = torch.zeros((max(n_pairs_step, 1), 5), dtype=torch.int32, device="cuda")
 
     def step():
-        n = batch.query_rows_device(0, 1, rows.data_ptr(), rows.shape[0])
+        n = batch.query_rows_device(0, args.batch, rows.data_ptr(), rows.shape[0])
         if world > 1:
             return sharding.all_gather_rows(rows[:n])
         return rows[:n]
@@ -155,7 +156,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"1 query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
+            "config": {"workload": f"{args.batch} query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
                        "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
                        "index_minimizers": n_min, "index_build_s": t_index, "host_pack_s": t_pack},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -219,7 +219,7 @@ struct fa_mapper {
   std::mutex mtx;
   // reference records and index (see fa_map.hip.h for the layout)
   DevBuf<uint32_t> rec_hash, uniq_hash, uniq_off, pos_ridx, dir;
-  DevBuf<int32_t> rec_seq, rec_wpos, rec_prev, contig_rec, contig_genome, contig_bin, genome_bin;
+  DevBuf<int32_t> rec_seq, rec_wpos, rec_prev, rec_fwd, rec_bwd, contig_rec, contig_genome, contig_bin, genome_bin;
   DevBuf<uint8_t> rec_flags;
   int64_t N = 0, U = 0;
   int32_t C = 0, G = 0, dir_shift = 0, freq_threshold = INT_MAX, total_bins = 0;
@@ -234,7 +234,7 @@ struct fa_mapper {
   SketchWork sk;
   DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
   DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
-  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop;
+  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
   DevBuf<uint32_t> l_items, l_ioff, f_loci_lo, f_loci_n;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo;
@@ -252,7 +252,7 @@ struct fa_mapper {
 
   IndexView view() const {
     IndexView v;
-    v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_flags = rec_flags.p;
+    v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
     v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.dir = dir.p;
     v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
     v.N = N; v.U = U; v.C = C; v.G = G; v.dir_shift = dir_shift; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
@@ -314,6 +314,8 @@ static void build_index(fa_mapper &m) {
   // hash-grouped order (stable radix sort keeps record order inside a hash group)
   m.pos_ridx.ensure((size_t)N + 4);
   m.rec_prev.ensure((size_t)N + 4);
+  m.rec_fwd.ensure((size_t)N + 4);
+  m.rec_bwd.ensure((size_t)N + 4);
   m.rec_flags.ensure(((size_t)N + 7) / 4 * 4);
   FA_HIP(hipMemsetAsync(m.rec_flags.p, 0, ((size_t)N + 7) / 4 * 4, st));
   m.U = 0;
@@ -369,6 +371,8 @@ static void build_index(fa_mapper &m) {
     hipLaunchKernelGGL(k_build_dir, dim3(ceil_div(nb + 1, 256)), dim3(256), 0, st, m.uniq_hash.p, (int64_t)U, m.dir_shift, nb, m.dir.p);
     hipLaunchKernelGGL(k_link_duplicates, dim3(ceil_div(N, 256)), dim3(256), 0, st, sorted_hash.p, m.pos_ridx.p, N, m.rec_seq.p,
                        m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
+    hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, m.contig_rec.p, N, m.cmw,
+                       m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(st));
   } else {
@@ -466,14 +470,17 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   uint32_t h_counters[4] = {0, 0, 0, 0};
   for (int attempt = 0; attempt < 2 && total_seeds > 0; attempt++) {
     m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap);
+    m.l_rfirst.ensure((size_t)l_cap); m.l_rlast.ensure((size_t)l_cap);
     m.l_group.ensure((size_t)l_cap); m.l_shared.ensure((size_t)l_cap); m.l_pos.ensure((size_t)l_cap);
     m.group_best.ensure((size_t)l_cap);
     FA_HIP(hipMemsetAsync(m.l_end.p, 0, (size_t)l_cap * sizeof(int32_t), st));
+    FA_HIP(hipMemsetAsync(m.l_rlast.p, 0, (size_t)l_cap * sizeof(int32_t), st));
     FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
     L1Args a;
     a.ix = ix; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p; a.n_seeds = m.n_seeds.p;
     a.ovf_off = m.ovf_off.p; a.ovf_buf = m.ovf_buf.p; a.min_hits_lut = m.d_min_hits.p;
     a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+    a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p;
     a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
     a.lds_seed_cap = LDS_SEED_CAP;
     a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
@@ -499,6 +506,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     L2Args a;
     a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
     a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+    a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p; a.frag_len = m.P.fragment_length;
     a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_items = m.l_items.p; a.l_ioff = m.l_ioff.p; a.l_ndrop = m.l_ndrop.p;
     a.items = nullptr;
     a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
@@ -507,7 +515,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.smax_words = (smax + 32) / 32;
     a.lanes = L2_THREADS;
     a.rec_total = (unsigned long long *)(m.totals.p + 3);
-    a.wpos_lds = 1024;
+    a.wpos_lds = 0;
     hipLaunchKernelGGL(k_l2_prep, dim3(ceil_div((int64_t)nloci + 1, 256)), dim3(256), 0, st, a);
     {
       size_t bytes = 0;
@@ -527,10 +535,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.last_ms[5] += (float)total_records;   // reference records inside the locus ranges of this call (roofline line)
     m.last_ms[7] += (float)total_items;     // slide events
     m.last_ms[6] += (float)nloci;
-    const size_t q_lds = ((size_t)smax * 4 + 15) / 16 * 16;
-    a.wpos_lds = 1024;                                         // records of a locus range staged in LDS per wave (longer ranges read HBM)
-    size_t rank_lds = q_lds + (size_t)a.wpos_lds * 4 * (EV_THREADS / 64) + 16;
-    FA_REQUIRE(rank_lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
+    const size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + 16;   // the query sketch of one fragment
+    FA_REQUIRE(rank_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
     m.l_redo.ensure((size_t)nloci + 4);
     a.l_redo = m.l_redo.p;
     a.redo_count = m.counters.p + 3;

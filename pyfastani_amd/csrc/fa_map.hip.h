@@ -183,6 +183,43 @@ __global__ void k_link_duplicates(const uint32_t *sorted_hash, const uint32_t *p
   }
 }
 
+// Query-independent geometry of the L2 slide, computed once per index (cmw = windows per fragment):
+//   rec_fwd[i] = first record of the contig with wpos >= wpos[i] + cmw   (end of the super-window that starts at i)
+//   rec_bwd[i] = last record of the contig with wpos <= wpos[i] - cmw + 1 (the record active when i is admitted)
+//   FLAG_SAME_STEP on record r: the window position that drops r (wpos[r+1]) also admits a record
+// With these, the position of every admit / drop event in the time-ordered event stream of a locus is plain
+// arithmetic (no merge search per query).
+constexpr uint8_t FLAG_SAME_STEP = 4;
+__global__ void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, const int32_t *contig_rec, int64_t N, int cmw,
+                               int32_t *rec_fwd, int32_t *rec_bwd, uint8_t *rec_flags) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int c = rec_seq[i];
+  const int lo = contig_rec[c], hi = contig_rec[c + 1];
+  const int w = rec_wpos[i];
+  {
+    int x = (int)i + 1, y = min(hi, (int)i + 1 + cmw), key = w + cmw;   // wpos is strictly increasing: at most cmw records ahead
+    if (y < hi && rec_wpos[y - 1] < key) y = hi;
+    while (x < y) { int mid = (x + y) >> 1; if (rec_wpos[mid] < key) x = mid + 1; else y = mid; }
+    rec_fwd[i] = x;
+  }
+  {
+    int x = max(lo, (int)i - cmw), y = (int)i + 1, key = w - cmw + 1;    // first index with wpos > key, minus one
+    if (x > lo && rec_wpos[x] > key) x = lo;
+    while (x < y) { int mid = (x + y) >> 1; if (rec_wpos[mid] <= key) x = mid + 1; else y = mid; }
+    rec_bwd[i] = x - 1;
+  }
+  if (i + 1 < hi) {
+    int key = rec_wpos[i + 1] + cmw - 1;
+    int x = (int)i + 1, y = hi;
+    int cap = min(hi, (int)i + 2 + cmw);
+    if (cap < hi && rec_wpos[cap - 1] >= key) y = cap;
+    while (x < y) { int mid = (x + y) >> 1; if (rec_wpos[mid] < key) x = mid + 1; else y = mid; }
+    if (x < hi && rec_wpos[x] == key)
+      atomicOr((unsigned int *)(rec_flags + ((uint32_t)i & ~3u)), (unsigned int)FLAG_SAME_STEP << (8 * ((uint32_t)i & 3u)));
+  }
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // resident index view passed to the mapping kernels
 // ----------------------------------------------------------------------------------------------------------
@@ -191,6 +228,7 @@ struct IndexView {
   const int32_t *rec_seq;
   const int32_t *rec_wpos;
   const int32_t *rec_prev;
+  const int32_t *rec_fwd, *rec_bwd;
   const uint8_t *rec_flags;
   const uint32_t *uniq_hash;
   const uint32_t *uniq_off;
@@ -281,6 +319,7 @@ struct L1Args {
   uint32_t *ovf_buf;
   const int32_t *min_hits_lut;   // [smax+1]
   int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
+  int32_t *l_rfirst, *l_rlast;   // record index of the first / last seed of the locus
   uint32_t *counters;            // [0] loci, [1] groups, [2] loci overflow flag
   uint32_t *f_loci_lo, *f_loci_n; // [F] loci of each fragment (contiguous)
   int32_t qcap, frag_len, l_cap;
@@ -341,8 +380,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       uint32_t i = i0 + tid;
       bool flag = false;
       int seq = -1, wa = 0, start = 0;
+      uint32_t ra = 0;
       if (i < ncand) {
-        uint32_t ra = seeds[i], rb = seeds[i + m - 1];
+        ra = seeds[i];
+        uint32_t rb = seeds[i + m - 1];
         seq = a.ix.rec_seq[ra];
         int seqb = a.ix.rec_seq[rb];
         wa = a.ix.rec_wpos[ra];
@@ -373,8 +414,12 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       for (int q = 0; q < wv; q++) slot += w_heads[q];
       if (pass == 1 && flag) {
         uint32_t li = sh_base + slot - 1;
-        if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; }
-        atomicMax(&a.l_end[li], wa);
+        if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; a.l_rfirst[li] = (int32_t)ra; }
+        // the end of a locus is its last flagged seed; only the last flagged lane of a locus inside this wave
+        // touches memory (same-address atomics from every lane would serialise)
+        const uint64_t above = (lane == 63) ? 0ULL : (bal & ~((2ULL << lane) - 1ULL));
+        const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
+        if (last_here) { atomicMax(&a.l_end[li], wa); atomicMax(&a.l_rlast[li], (int32_t)ra); }
       }
       __syncthreads();
       if (tid == 0) {
@@ -457,7 +502,8 @@ struct L2Args {
   IndexView ix;
   const uint32_t *q_hash;
   const int32_t *q_size;
-  const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;
+  const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group, *l_rfirst, *l_rlast;
+  int32_t frag_len;
   int32_t *l_beg, *l_end0, *l_last;  // record range of the locus, end of the first super-window
   int32_t *l_ndrop;                  // records dropped before the slide ends
   uint32_t *l_items;                 // [loci + 1] events of the locus rounded up to a multiple of 8
@@ -490,64 +536,37 @@ __global__ void k_l2_prep(L2Args a) {
   const uint32_t nloci = a.counters[0];
   if (l > nloci) return;
   if (l == nloci) { a.l_items[l] = 0; return; }
-  const int seq = a.l_seq[l];
-  const int lo = a.ix.contig_rec[seq], hi = a.ix.contig_rec[seq + 1];
+  const int lo = a.ix.contig_rec[a.l_seq[l]];
   const int32_t *wpos = a.ix.rec_wpos;
-  auto lower = [&](int from, int to, int target) {
-    int x = from, y = to;
-    while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
-    return x;
-  };
-  const int beg = lower(lo, hi, a.l_start[l]);                       // searchIndex(seqId, rangeStartPos)
-  const int end0 = lower(beg, hi, wpos[beg] + a.cmw);                // searchIndex(seqId, first wpos + countMinimizerWindows)
-  const int last = lower(end0, hi, a.l_end[l] + a.cmw);              // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
-  int ndrop = 0;
-  if (last > end0) {
-    // the slide stops at the window position where the last record is admitted; record r is dropped at wpos[r+1]
-    const int p_last = wpos[last - 1] - a.cmw + 1;
-    ndrop = lower(beg + 1, hi, p_last + 1) - (beg + 1);              // #{r >= beg : wpos[r+1] <= p_last}
-  }
+  // searchIndex(seqId, rangeStartPos): rangeStartPos <= wpos of the first seed and wpos is strictly increasing, so the
+  // answer lies within fragment_length records before that seed
+  const int rfirst = a.l_rfirst[l], target = a.l_start[l];
+  int x = max(lo, rfirst - a.frag_len), y = rfirst;
+  while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+  const int beg = x;
+  const int end0 = a.ix.rec_fwd[beg];                  // searchIndex(seqId, first wpos + countMinimizerWindows)
+  const int last = a.ix.rec_fwd[a.l_rlast[l]];         // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
+  // the slide stops at the window position where the last record is admitted; the records dropped by then are the
+  // ones before the record active at that position
+  const int ndrop = last > end0 ? a.ix.rec_bwd[last - 1] - beg : 0;
   a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last; a.l_ndrop[l] = ndrop;
   a.l_items[l] = (uint32_t)((last - beg + ndrop + 7) & ~7);
   atomicAdd(a.rec_total, (unsigned long long)(last - beg));
-}
-
-// first j in [lo, hi] with !pred(j) (pred is true on a prefix), searching outwards from a guess: the two event
-// streams of a locus advance almost in lock-step, so the answer is a handful of records away from the guess
-template <typename F>
-__device__ __forceinline__ int gallop(int lo, int hi, int guess, F pred) {
-  guess = min(max(guess, lo), hi);
-  int L, R;
-  if (guess < hi && pred(guess)) {
-    L = guess + 1;
-    int step = 1;
-    R = min(hi, L + step);
-    while (R < hi && pred(R)) { L = R + 1; step <<= 1; R = min(hi, R + step); }
-  } else {
-    R = guess;
-    int step = 1;
-    L = max(lo, R - step);
-    while (L > lo && !pred(L)) { R = L; step <<= 1; L = max(lo, L - step); }
-    if (L < R && pred(L)) L = L + 1;
-  }
-  while (L < R) { int mid = (L + R) >> 1; if (pred(mid)) L = mid + 1; else R = mid; }
-  return L;
 }
 
 template <typename T>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   uint32_t *Q = (uint32_t *)lds;                                     // [smax], staged once per fragment
+  __shared__ uint16_t QT[258];
   const int f = blockIdx.x;
   const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
   if (l_n == 0) return;
   const int s = a.q_size[f];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int32_t *W = (int32_t *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.wpos_lds;   // per wave
   for (int i = threadIdx.x; i < s; i += EV_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
   __syncthreads();
   // bucket table over the top 8 hash bits: QT[b] = first query rank whose hash is >= b << 24
-  __shared__ uint16_t QT[258];
   for (int b = threadIdx.x; b <= 256; b += EV_THREADS) {
     int x = 0, y = s;
     const uint64_t key = (uint64_t)b << 24;
@@ -555,23 +574,15 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     QT[b] = (uint16_t)x;
   }
   __syncthreads();
-  const int32_t *gw = a.ix.rec_wpos;
-  // the waves of the workgroup take the loci of the fragment round-robin; everything below is wave-synchronous
+  // the waves of the workgroup take the loci of the fragment round-robin
   for (uint32_t l = l_lo + wv; l < l_lo + l_n; l += EV_THREADS / 64) {
     const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
-    const int hi = a.ix.contig_rec[a.l_seq[l] + 1];
-    // window positions of records [beg, last] (the drop time of record r is wpos[r+1])
-    const int nw = last - beg + 1;
-    const bool staged = nw <= a.wpos_lds;
-    if (staged) for (int i = lane; i < nw; i += 64) W[i] = (beg + i < hi) ? gw[beg + i] : 0x7FFFFFFF;
-    __builtin_amdgcn_wave_barrier();
-    auto wp = [&](int i) { return staged ? W[i - beg] : ((i < hi) ? gw[i] : 0x7FFFFFFF); };
     const int n_init = end0 - beg;
     const uint32_t total = (uint32_t)(last - beg + ndrop);
     const uint32_t padded = (total + 7u) & ~7u;
     T *out = (T *)a.items + a.l_ioff[l];
     for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)(EV_SKIP << EvBits<T>::RANK);
-    auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev) __attribute__((always_inline)) {
+    auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
       int x = QT[h >> 24], y = QT[(h >> 24) + 1];
       while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
       const uint32_t base = (uint32_t)x | (((x < s && Q[x] == h) ? EV_FOUND : 0u) << EvBits<T>::RANK);
@@ -580,40 +591,36 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
         uint32_t fl = (prev >= beg ? EV_SKIP : 0u) | (i == end0 - 1 ? EV_EVAL : 0u);
         out[i - beg] = (T)(base | (fl << EvBits<T>::RANK));
       } else {
-        // admitted at window position ta = wpos - cmw + 1, after the drops of positions <= ta
-        const int ta = wp(i) - a.cmw + 1;
-        // drop times wpos[beg+1 .. beg+ndrop]; the window holds ~n_init records, so record i enters while i - n_init leaves
-        const int lo2 = gallop(beg + 1, beg + 1 + ndrop, i - n_init + 1, [&](int j) { return wp(j) <= ta; });
-        const uint32_t pos = (uint32_t)(n_init + (i - end0) + (lo2 - (beg + 1)));
+        // admitted after the drops of all records before the one active at its window position (rec_bwd)
+        const uint32_t pos = (uint32_t)(n_init + (i - end0) + (bwd - beg));
         uint32_t fl = ((rf & FLAG_INS_LINKED) ? EV_SKIP : 0u) | EV_EVAL;
         out[pos] = (T)(base | (fl << EvBits<T>::RANK));
       }
       if (i - beg < ndrop) {
-        // dropped at window position td = wpos[i+1], before the admit of that position (if any)
-        const int td = wp(i + 1);
-        const int key = td + a.cmw - 1;                                 // admits with time < td  <=>  wpos < td + cmw - 1
-        const int lo2 = gallop(end0, last, i + n_init, [&](int j) { return wp(j) < key; });
-        const uint32_t pos = (uint32_t)(n_init + (i - beg) + (lo2 - end0));
-        const bool admit_same_step = lo2 < last && wp(lo2) == key;
-        uint32_t fl = EV_DROP | ((rf & FLAG_DEL_LINKED) ? EV_SKIP : 0u) | (admit_same_step ? 0u : EV_EVAL);
+        // dropped at window position wpos[i+1], after the admits of earlier positions and before the admit of
+        // that same position (FLAG_SAME_STEP), which then carries the comparison
+        const bool same = (rf & FLAG_SAME_STEP) != 0;
+        const uint32_t pos = (uint32_t)(n_init + (i - beg) + (fwd1 - (same ? 1 : 0) - end0));
+        uint32_t fl = EV_DROP | ((rf & FLAG_DEL_LINKED) ? EV_SKIP : 0u) | (same ? 0u : EV_EVAL);
         out[pos] = (T)(base | (fl << EvBits<T>::RANK));
       }
     };
     // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
     for (int i0 = beg + lane; i0 < last; i0 += 256) {
-      uint32_t h[4]; uint8_t rf[4]; int32_t pv[4];
+      uint32_t h[4]; uint8_t rf[4]; int32_t pv[4], bw[4], fw[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int i = i0 + 64 * u;
         const bool ok = i < last;
         h[u] = ok ? a.ix.rec_hash[i] : 0u;
         rf[u] = ok ? a.ix.rec_flags[i] : (uint8_t)0;
-        pv[u] = ok ? a.ix.rec_prev[i] : -1;
+        pv[u] = (ok && i < end0) ? a.ix.rec_prev[i] : -1;
+        bw[u] = (ok && i >= end0) ? a.ix.rec_bwd[i] : 0;
+        fw[u] = (ok && i - beg < ndrop) ? a.ix.rec_fwd[i + 1] : 0;
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u]);
+      for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u], bw[u], fw[u]);
     }
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
