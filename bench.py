@@ -56,10 +56,18 @@ def main():
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # FA_BENCH_SHARE_GPU=1 is a debugging aid for 1-GPU boxes: every rank uses cuda:0 and the hit tables are gathered
+    # over gloo (RCCL refuses two ranks on one device).  It exercises the N>1 code path, not the interconnect.
+    share_gpu = os.environ.get("FA_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
     entry.build()
@@ -96,7 +104,7 @@ def main():
     def step():
         n = batch.query_rows_device(0, args.batch, rows.data_ptr(), rows.shape[0])
         if world > 1:
-            return sharding.all_gather_rows(rows[:n])
+            return sharding.all_gather_rows(rows[:n].cpu() if share_gpu else rows[:n])
         return rows[:n]
 
     def fence():
@@ -117,7 +125,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_hits = int(out.shape[0])

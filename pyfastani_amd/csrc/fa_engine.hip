@@ -542,7 +542,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.redo_count = m.counters.p + 3;
     a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
     // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
-    auto scan_lds = [&](int ln, int bytes) { return ((size_t)a.cnt_slots * ln * bytes + 15) / 16 * 16; };
+    auto scan_lds = [&](int ln, int bytes) { return ((size_t)(a.cnt_slots + 1) * ln * bytes + 15) / 16 * 16; };
     auto pick_lanes = [&](int bytes) {
       int ln = L2_THREADS;
       while (ln > 1 && scan_lds(ln, bytes) > 144 * 1024) ln >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
@@ -552,18 +552,28 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
     const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
     const size_t lds8 = scan_lds(lanes8, 1), lds16 = scan_lds(lanes16, 2);
-    auto launch = [&](auto ev_kernel, auto scan8, auto scan16) {
+    auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
       if (rank_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
-      if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-      if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
       hipLaunchKernelGGL(ev_kernel, dim3((unsigned)F), dim3(EV_THREADS), rank_lds, st, a);
       a.lanes = lanes8;
-      hipLaunchKernelGGL(scan8, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
+      if (lanes8 == L2_THREADS) {
+        if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        hipLaunchKernelGGL(scan8, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
+      } else {
+        if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+        hipLaunchKernelGGL(scan8_rt, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
+      }
       a.lanes = lanes16;
-      hipLaunchKernelGGL(scan16, dim3(ceil_div(nloci, lanes16)), dim3(L2_THREADS), lds16, st, a);
+      if (lanes16 == L2_THREADS) {
+        if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        hipLaunchKernelGGL(scan16, dim3(ceil_div(nloci, lanes16)), dim3(L2_THREADS), lds16, st, a);
+      } else {
+        if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+        hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(nloci, lanes16)), dim3(L2_THREADS), lds16, st, a);
+      }
     };
-    if (wide) launch(k_l2_events<uint32_t>, k_l2_scan<uint32_t, uint8_t>, k_l2_scan<uint32_t, uint16_t>);
-    else launch(k_l2_events<uint16_t>, k_l2_scan<uint16_t, uint8_t>, k_l2_scan<uint16_t, uint16_t>);
+    if (wide) launch(k_l2_events<uint32_t>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+    else launch(k_l2_events<uint16_t>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
     FA_HIP(hipGetLastError());
   }
   FA_HIP(hipEventRecord(m.ev[3], st));

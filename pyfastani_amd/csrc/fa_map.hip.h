@@ -626,15 +626,17 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
 
 // State of one lane: ST[r] = (query rank r currently matched) << (bits-1) | number of distinct window-only hashes of
 // insertion rank r.  ST is uint8 on the fast path (one byte per rank keeps 8 waves per CU resident); if a count would
-// reach 128 the lane flags its locus and the uint16 instantiation redoes it (l_redo).
-template <typename T, typename ST>
+// reach 128 the lane flags its locus and the uint16 instantiation redoes it (l_redo).  The array is shifted by one
+// slot so that the boundary rank r*-1 needs no clamp when r* = 0.  LNT = lanes per workgroup at compile time (64) or
+// 0 for the run-time value used when a huge sketch forces fewer lanes per workgroup.
+template <typename T, typename ST, int LNT>
 __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   constexpr int SBITS = 8 * (int)sizeof(ST);
   constexpr uint32_t MATCH = 1u << (SBITS - 1), CMASK = MATCH - 1u;
   constexpr bool REDO = sizeof(ST) > 1;
-  const int LN = a.lanes;
-  ST *st = (ST *)lds;                                              // [cnt_slots][LN], lane-interleaved
+  const int LN = LNT ? LNT : a.lanes;
+  ST *st = (ST *)lds;                                              // [cnt_slots + 1][LN], lane-interleaved
   const int lane = threadIdx.x;
   if (lane >= LN) return;
   const uint32_t l = blockIdx.x * LN + lane;
@@ -646,12 +648,13 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   const uint32_t nev = a.l_ioff[l + 1] - a.l_ioff[l];               // multiple of 8
   constexpr int PER = 16 / sizeof(T);                               // events per 16-byte load
   const uint4 *ev = (const uint4 *)((const T *)a.items + a.l_ioff[l]);
-  constexpr uint32_t RANK_MASK = (1u << EvBits<T>::RANK) - 1u;
-  for (int i = 0; i <= s; i++) st[i * LN + lane] = 0;
+  constexpr int RB = EvBits<T>::RANK;
+  constexpr uint32_t RANK_MASK = (1u << RB) - 1u;
+  for (int i = 0; i <= s + 1; i++) st[i * LN + lane] = 0;
 
   int rstar = s, P = 0, shared = 0, beg = beg0;
   int best = -1, opt_s = beg0, opt_e = beg0;
-  bool overflow = false;
+  uint32_t overflow = 0;
   const uint32_t ngroups = nev / PER;
   uint4 cur = ngroups ? ev[0] : make_uint4(0, 0, 0, 0);
   for (uint32_t g = 0; g < ngroups; g++) {
@@ -662,35 +665,38 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
       uint32_t word = (q * WPE / 4 == 0) ? cur.x : (q * WPE / 4 == 1) ? cur.y : (q * WPE / 4 == 2) ? cur.z : cur.w;
       const uint32_t e = sizeof(T) == 2 ? ((q & 1) ? (word >> 16) : (word & 0xFFFFu)) : word;
       const int r = (int)(e & RANK_MASK);
-      const uint32_t fl = e >> EvBits<T>::RANK;
-      const bool drop = (fl & EV_DROP) != 0;
-      const int delta = drop ? -1 : 1;
-      const bool active = !(fl & EV_SKIP);
-      const bool isM = active && (fl & EV_FOUND), isW = active && !(fl & EV_FOUND);
-      // both LDS reads are issued together: the touched rank, and the rank at the boundary r* the pivot may move across
-      const int rb = drop ? min(rstar, s) : max(rstar - 1, 0);
-      const uint32_t v = st[r * LN + lane];
-      const uint32_t vb0 = st[rb * LN + lane];
-      const uint32_t nv = isM ? (drop ? (v & CMASK) : (v | MATCH)) : (v + (isW ? (uint32_t)delta : 0u));
-      if (active) st[r * LN + lane] = (ST)nv;
-      overflow |= isW && !drop && (nv & CMASK) == 0;               // count wrapped into the MATCH bit
-      const bool below = r < rstar;
-      shared += (isM && below) ? delta : 0;
-      P += (isW && below) ? delta : 0;
-      const uint32_t vb = (rb == r) ? nv : vb0;
-      const int cb = (int)(vb & CMASK), mb = (vb & MATCH) ? 1 : 0;
+      // flag bits as 0/1 integers: everything below is straight-line selects (the 64 lanes of a wave follow 64
+      // different loci, any branch would serialise them)
+      const uint32_t fnd = (e >> RB) & 1u, drp = (e >> (RB + 1)) & 1u, skp = (e >> (RB + 2)) & 1u, evl = (e >> (RB + 3)) & 1u;
+      const uint32_t actM = fnd & ~skp & 1u, actW = ~fnd & ~skp & 1u;
+      const int delta = 1 - 2 * (int)drp;
+      // both LDS reads are issued together: the touched rank, and the rank at the boundary the pivot may move across
+      const int rbs = rstar + (int)drp;                            // slot of rank r* (drop) or r*-1 (insert)
+      const uint32_t v = st[(r + 1) * LN + lane];
+      const uint32_t vb0 = st[rbs * LN + lane];
+      uint32_t nv = v + (actW ? (uint32_t)delta : 0u);
+      overflow |= actW & ~drp & (uint32_t)((nv & CMASK) == 0);     // count wrapped into the MATCH bit
+      nv = (actM & ~drp) ? (nv | MATCH) : nv;
+      nv = (actM & drp) ? (nv & CMASK) : nv;
+      st[(r + 1) * LN + lane] = (ST)nv;
+      const int t = (r < rstar) ? delta : 0;
+      shared += actM ? t : 0;
+      P += actW ? t : 0;
+      const uint32_t vb = (rbs == r + 1) ? nv : vb0;
+      const int cb = (int)(vb & CMASK), mb = (int)((vb >> (SBITS - 1)) & 1u);
       // a window-only hash left and query rank r* re-enters the s smallest of the union ...
-      const bool up = isW && drop && rstar < s && (rstar + P + cb < s);
+      const bool up = (actW & drp) && rstar < s && (rstar + P + cb < s);
       // ... or one arrived below r* and f(r*-1) reached s: the largest query rank falls out
-      const bool down = isW && !drop && below && (rstar - 1 + P >= s);
-      P += up ? cb : (down ? -cb : 0);
-      shared += up ? mb : (down ? -mb : 0);
-      rstar += up ? 1 : (down ? -1 : 0);
-      beg += drop ? 1 : 0;
-      if (fl & EV_EVAL) {
-        if (shared > best) { best = shared; opt_s = beg; opt_e = beg; }
-        else if (shared == best) opt_e = beg;
-      }
+      const bool down = (actW & ~drp & 1u) && (r < rstar) && (rstar - 1 + P >= s);
+      const int dir = up ? 1 : (down ? -1 : 0);
+      P += dir * cb;
+      shared += dir * mb;
+      rstar += dir;
+      beg += (int)drp;
+      const bool gt = evl && shared > best, ge = evl && shared >= best;
+      best = gt ? shared : best;
+      opt_s = gt ? beg : opt_s;
+      opt_e = ge ? beg : opt_e;
     }
     cur = nxt;
   }
