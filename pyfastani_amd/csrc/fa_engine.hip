@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -623,7 +624,15 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   return nrows;
 }
 
-static const int64_t PASS_FRAGMENTS = 48 * 1024;   // fragments mapped per pass (bounds the workspace)
+// fragments mapped per pass (bounds the workspace); FA_PASS_FRAGMENTS overrides it (tests force several passes)
+static int64_t pass_fragments() {
+  static const int64_t v = [] {
+    const char *e = getenv("FA_PASS_FRAGMENTS");
+    long long x = e ? atoll(e) : 0;
+    return (int64_t)(x > 0 ? x : 48 * 1024);
+  }();
+  return v;
+}
 
 static int64_t run_query(fa_mapper &m, const fa_genomes &g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap, bool rows_device) {
   require_device();
@@ -635,7 +644,7 @@ static int64_t run_query(fa_mapper &m, const fa_genomes &g, int32_t first, int32
   int32_t g0 = first;
   while (g0 < first + count) {
     int32_t g1 = g0 + 1;
-    while (g1 < first + count && g.genome_frag_lo[g1 + 1] - g.genome_frag_lo[g0] <= PASS_FRAGMENTS) g1++;
+    while (g1 < first + count && g.genome_frag_lo[g1 + 1] - g.genome_frag_lo[g0] <= pass_fragments()) g1++;
     // frag_query is batch-wide: the bins of a pass are indexed by (genome - g0), handled through the pointer offset below
     nrows += run_query_pass(m, g, g0, g1, dst, cap, nrows);
     g0 = g1;

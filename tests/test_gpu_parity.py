@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import pyfastani_amd as pf
-from conftest import read_fasta
+from conftest import ROOT, read_fasta
 from oracle.oracle import OracleSketch
 from pyfastani_amd import _lib, synthetic as syn
 from pyfastani_amd._lib import lib, check
@@ -392,3 +392,45 @@ def test_full_size_properties():
         assert hit_tuples(got) == hit_tuples(mapper.query_draft(q))
     assert hit_tuples(per_genome[0])[0][:1] == ("d05",) and per_genome[0][0].identity == 100.0
     assert hit_tuples(batch.query(1, 2)[1]) == hit_tuples(per_genome[2])
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# many-to-many (BASELINE configs 3/4 in miniature): draft assemblies, all-vs-all, several passes per call
+# ----------------------------------------------------------------------------------------------------------------
+def test_all_vs_all_drafts_multi_pass():
+    import subprocess
+    import textwrap
+    # the pass size is read once per process, so the multi-pass run happens in a child process
+    code = textwrap.dedent("""
+        import os, sys, json, warnings
+        sys.path.insert(0, %r)
+        import numpy as np
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        from oracle.oracle import OracleSketch
+        g = syn.rng(91)
+        genomes = []
+        for fam in range(3):
+            anc = syn.random_codes(g, 150_000)
+            for d in (0.0, 0.03, 0.08, 0.14):
+                genomes.append(syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, d)), 10))
+        genomes.append([b"ACGT" * 2])                      # a genome made of one short contig
+        genomes.append([])                                 # an empty genome
+        sk, osk = pf.Sketch(), OracleSketch()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i, c in enumerate(genomes):
+                sk.add_draft(i, c); osk.add_draft(i, c)
+            mapper = sk.index(); osk.index()
+            batch = mapper.upload_genomes(genomes)
+            got = [[(h.name, h.identity, h.matches, h.fragments) for h in hits] for hits in batch.query()]
+            part = [[(h.name, h.identity, h.matches, h.fragments) for h in hits] for hits in batch.query(5, 4)]
+        want = [osk.query_draft(c, threads=8) for c in genomes]
+        assert got == want, "all-vs-all mismatch"
+        assert part == want[5:9]
+        assert sum(len(w) for w in want) >= 3 * 12 and want[-1] == [] and want[-2] == []
+        print("OK", sum(len(w) for w in want))
+    """ % ROOT)
+    env = dict(os.environ, FA_PASS_FRAGMENTS="120")        # 14 genomes x ~45 fragments -> several passes
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout + res.stderr
