@@ -536,7 +536,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.last_ms[5] += (float)total_records;   // reference records inside the locus ranges of this call (roofline line)
     m.last_ms[7] += (float)total_items;     // slide events
     m.last_ms[6] += (float)nloci;
-    const size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + 16;   // the query sketch of one fragment
+    a.wpos_lds = 2048;                                                  // events staged per wave (longer streams go direct)
+    const size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.wpos_lds * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
     FA_REQUIRE(rank_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
     m.l_redo.ensure((size_t)nloci + 4);
     a.l_redo = m.l_redo.p;

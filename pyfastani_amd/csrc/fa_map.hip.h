@@ -516,7 +516,7 @@ struct L2Args {
   int32_t qcap, cmw, smax_words;     // smax_words = ceil((smax+1)/32)
   int32_t cnt_slots;                 // smax + 1
   int32_t lanes;                     // loci per workgroup of k_l2_scan (power of two <= 64)
-  int32_t wpos_lds;                  // window positions staged per workgroup of k_l2_events
+  int32_t wpos_lds;                  // events of one locus staged in LDS per wave of k_l2_events
   unsigned long long *rec_total;     // sum over loci of the records in their range (for the roofline line)
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
@@ -580,7 +580,11 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     const int n_init = end0 - beg;
     const uint32_t total = (uint32_t)(last - beg + ndrop);
     const uint32_t padded = (total + 7u) & ~7u;
-    T *out = (T *)a.items + a.l_ioff[l];
+    T *gout = (T *)a.items + a.l_ioff[l];
+    // events land at scattered 2-byte positions: build the stream of a locus in LDS and stream it out in 16-byte
+    // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
+    const bool staged = padded <= (uint32_t)a.wpos_lds;
+    T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.wpos_lds : gout;
     for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)(EV_SKIP << EvBits<T>::RANK);
     auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
       int x = QT[h >> 24], y = QT[(h >> 24) + 1];
@@ -620,6 +624,14 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u], bw[u], fw[u]);
+    }
+    if (staged) {
+      __builtin_amdgcn_wave_barrier();
+      const uint4 *src = (const uint4 *)out;
+      uint4 *dst = (uint4 *)gout;
+      const uint32_t n16 = padded * (uint32_t)sizeof(T) / 16u;
+      for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
