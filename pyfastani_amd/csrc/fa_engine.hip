@@ -674,7 +674,19 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   g->frag_tile_lo.clear();
   const int frag = P.fragment_length;
   const int64_t min_len = std::min<int64_t>(std::min(P.window_size, P.kmer_size), frag);
+  // pass 1: which contigs are mapped, and how many whole fragments each holds; pack them all at once (threaded)
+  std::vector<const void *> use_ptr;
+  std::vector<int64_t> use_len, use_contig;
+  for (int64_t c = 0; c < n_contigs; c++) {
+    const int64_t len = lengths[c];
+    if (len < min_len) continue;
+    const int64_t nfrag = len / frag;
+    if (nfrag > 0) { use_ptr.push_back(contigs[c]); use_len.push_back(nfrag * frag); use_contig.push_back(c); }   // the tail past the last whole fragment is never read
+  }
+  hs.append_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width);
+  // pass 2: fragments, tiles and per-genome bookkeeping, in contig order
   int32_t cur = 0;
+  size_t used = 0;
   for (int64_t c = 0; c < n_contigs; c++) {
     int32_t gi = contig_genome ? contig_genome[c] : 0;
     FA_REQUIRE(gi >= cur && gi < n_genomes, FA_ERR_INVALID, "contig_genome must be non-decreasing and < n_genomes");
@@ -683,7 +695,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
     if (len < min_len) { g->n_short[gi]++; continue; }               // _fastani.pyx:1061-1070
     const int64_t nfrag = len / frag;                                 // :1097
     if (nfrag > 0) {
-      int64_t si = hs.append(contigs[c], width, nfrag * frag);        // the tail past the last whole fragment is never read
+      const int64_t si = (int64_t)used++;
       for (int64_t i = 0; i < nfrag; i++) {
         g->frag_tile_lo.push_back((int32_t)tiles.size());
         make_tiles(tiles, hs, hs.seq_off[si] + i * frag, frag, (int)frag_query.size(), P.kmer_size, P.window_size);

@@ -28,6 +28,10 @@
 // (k_suppress_runs) because it only ever affects the leading run of records of a sequence.
 #pragma once
 
+#include <atomic>
+#include <cstdlib>
+#include <thread>
+
 #include "fa_common.h"
 
 namespace fa {
@@ -60,6 +64,31 @@ inline uint8_t host_read(const void *data, int width, int64_t i) {
   }
 }
 
+// ASCII -> 2-bit code (A/a=0 C/c=1 G/g=2 T/t=3), 4 = not a plain nucleotide (goes to the exception list)
+static const uint8_t kCodeOf[256] = {
+#define X4(v) v, v, v, v
+#define X16(v) X4(v), X4(v), X4(v), X4(v)
+    X16(4), X16(4), X16(4), X16(4),                               // 0x00-0x3f
+    4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,               // @ A B C D E F G H I J K L M N O
+    4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,               // P Q R S T ...
+    4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,               // ` a b c d e f g ...
+    4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,               // p q r s t ...
+    X16(4), X16(4), X16(4), X16(4), X16(4), X16(4), X16(4), X16(4)  // 0x80-0xff
+#undef X16
+#undef X4
+};
+
+// host threads used for packing (FA_HOST_THREADS overrides; default = hardware concurrency, at most 64)
+inline int host_threads() {
+  static const int v = [] {
+    const char *e = getenv("FA_HOST_THREADS");
+    int x = e ? atoi(e) : 0;
+    if (x <= 0) x = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    return x;
+  }();
+  return v;
+}
+
 // Host image of a sequence store, appended to contig by contig and uploaded in one go.
 struct HostStore {
   bool protein = false;
@@ -77,48 +106,68 @@ struct HostStore {
 
   // appends one sequence; returns its index
   int64_t append(const void *data, int width, int64_t len) {
-    static const uint8_t code_of[256] = {
-#define X4(v) v, v, v, v
-#define X16(v) X4(v), X4(v), X4(v), X4(v)
-        X16(4), X16(4), X16(4), X16(4),                               // 0x00-0x3f
-        4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,               // @ A B C D E F G H I J K L M N O
-        4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,               // P Q R S T ...
-        4, 0, 4, 1, 4, 4, 4, 2, 4, 4, 4, 4, 4, 4, 4, 4,               // ` a b c d e f g ...
-        4, 4, 4, 4, 3, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4, 4,               // p q r s t ...
-        X16(4), X16(4), X16(4), X16(4), X16(4), X16(4), X16(4), X16(4)  // 0x80-0xff
-#undef X16
-#undef X4
-    };
-    int64_t off = total;
-    seq_off.push_back(off);
-    seq_len.push_back(len);
-    int64_t padded = (len + 63) / 64 * 64;
-    if (protein) {
-      size_t o = bytes.size();
-      bytes.resize(o + (size_t)padded, 0);
-      for (int64_t i = 0; i < len; i++) bytes[o + i] = host_upper(host_read(data, width, i));
-    } else {
-      size_t o = packed.size();
-      packed.resize(o + (size_t)(padded / 16), 0u);
-      uint32_t *dst = packed.data() + o;
-      if (width == 1) {
-        const uint8_t *src = (const uint8_t *)data;
-        for (int64_t i = 0; i < len; i++) {
-          uint8_t c = code_of[src[i]];
-          if (c > 3) { exc_pos.push_back(off + i); exc_val.push_back(host_upper(src[i])); c = 0; }
-          dst[i >> 4] |= (uint32_t)c << ((i & 15) * 2);
-        }
-      } else {
-        for (int64_t i = 0; i < len; i++) {
-          uint8_t ch = host_read(data, width, i);
-          uint8_t c = code_of[ch];
-          if (c > 3) { exc_pos.push_back(off + i); exc_val.push_back(host_upper(ch)); c = 0; }
-          dst[i >> 4] |= (uint32_t)c << ((i & 15) * 2);
-        }
+    const void *ptrs[1] = {data};
+    int64_t lens[1] = {len};
+    int64_t first = (int64_t)seq_off.size();
+    append_many(ptrs, lens, 1, width);
+    return first;
+  }
+
+  // Appends n sequences, packing them with a pool of host threads (the packer is the host-side bottleneck of the
+  // many-to-many workloads: ~1 GB/s per core).  Work is cut into chunks of whole words; every chunk collects its own
+  // exceptions, which are concatenated in store order afterwards.
+  void append_many(const void *const *datas, const int64_t *lens, int64_t n, int width) {
+    struct Chunk { const void *data; int64_t src0, count, store_off; size_t word0; std::vector<int64_t> epos; std::vector<uint8_t> eval; };
+    std::vector<Chunk> chunks;
+    const int64_t CH = 1 << 20;   // bases per chunk (multiple of 16)
+    for (int64_t q = 0; q < n; q++) {
+      const int64_t len = lens[q], off = total, padded = (len + 63) / 64 * 64;
+      seq_off.push_back(off);
+      seq_len.push_back(len);
+      const size_t base = protein ? bytes.size() : packed.size();
+      if (protein) bytes.resize(base + (size_t)padded, 0); else packed.resize(base + (size_t)(padded / 16), 0u);
+      for (int64_t c0 = 0; c0 < len; c0 += CH) {
+        Chunk c;
+        c.data = datas[q]; c.src0 = c0; c.count = std::min(CH, len - c0); c.store_off = off + c0;
+        c.word0 = base + (size_t)(protein ? c0 : c0 / 16);
+        chunks.push_back(std::move(c));
       }
+      total += padded;
     }
-    total += padded;
-    return (int64_t)seq_off.size() - 1;
+    auto work = [&](Chunk &c) {
+      if (protein) {
+        uint8_t *dst = bytes.data() + c.word0;
+        for (int64_t i = 0; i < c.count; i++) dst[i] = host_upper(host_read(c.data, width, c.src0 + i));
+        return;
+      }
+      uint32_t *dst = packed.data() + c.word0;
+      const uint8_t *src8 = width == 1 ? (const uint8_t *)c.data + c.src0 : nullptr;
+      for (int64_t i = 0; i < c.count; i += 16) {
+        const int m = (int)std::min<int64_t>(16, c.count - i);
+        uint32_t wv = 0;
+        for (int j = 0; j < m; j++) {
+          const uint8_t ch = src8 ? src8[i + j] : host_read(c.data, width, c.src0 + i + j);
+          uint8_t code = kCodeOf[ch];
+          if (code > 3) { c.epos.push_back(c.store_off + i + j); c.eval.push_back(host_upper(ch)); code = 0; }
+          wv |= (uint32_t)code << (2 * j);
+        }
+        dst[i >> 4] = wv;
+      }
+    };
+    int nthreads = (int)std::min<size_t>(chunks.size(), (size_t)host_threads());
+    if (nthreads <= 1) {
+      for (auto &c : chunks) work(c);
+    } else {
+      std::atomic<size_t> next(0);
+      std::vector<std::thread> pool;
+      for (int t = 0; t < nthreads; t++)
+        pool.emplace_back([&] { for (size_t i; (i = next.fetch_add(1)) < chunks.size();) work(chunks[i]); });
+      for (auto &t : pool) t.join();
+    }
+    for (auto &c : chunks) {
+      exc_pos.insert(exc_pos.end(), c.epos.begin(), c.epos.end());
+      exc_val.insert(exc_val.end(), c.eval.begin(), c.eval.end());
+    }
   }
 };
 
