@@ -28,7 +28,6 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # Algorithmic bytes
 K1_BYTES_PER_BASE = 0.25 + 12.0 * 2.0 / 25.0      # 2-bit input + 12 B records at density 2/(w+1), w = 24
-L2_BYTES_PER_LOCUS = 12.0 * 480.0                  # ~2 fragment lengths of reference minimizer records per locus
 
 
 def parse_args():
@@ -135,8 +134,6 @@ def main():
     if rank == 0:
         value = world * n_pairs_step * args.steps / elapsed
         # ---- roofline of the dominant kernel, from the HIP-event timings taken inside the timed region ----
-        from pyfastani_amd._lib import lib as _l
-        names = ["sketch(K1+sort)", "lookup", "L1", "L2", "cgi"]
         phase = dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase_ms]))
         # K1 alone, repeated, for the minimizer-extraction roofline the north star asks for
         k1_ms, bases, mins = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
@@ -149,8 +146,11 @@ def main():
         # every reference record inside a locus range is one 12-byte MinimizerInfo of the reference's layout
         l2_bytes = l2_records * 12.0
         l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
-        dominant = "k_l2_prep+rank+scan" if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
-        roof = {"k_l2_prep+rank+scan": (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
+        l2_name = "k_l2_prep+k_l2_events+k_l2_scan"
+        dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
+        roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
+        traffic = profiled_traffic(["k_l2_prep", "k_l2_events<unsigned short>", "k_l2_scan<unsigned short, unsigned char, 64>"]
+                                   if dominant == l2_name else ["k_sketch_tiles<16>"]) if args.batch == 1 and args.refs == 100 else None
         result = {
             "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
             "value": value,
@@ -168,7 +168,8 @@ def main():
                        "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
                        "index_minimizers": n_min, "index_build_s": t_index, "host_pack_s": t_pack},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": roof[0] / HBM_PEAK_GBS, "traffic": None, "kernel_ms": roof[1]},
+                         "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": roof[1],
+                         "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes},
             "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_tiles", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,
                                 "algorithmic_bytes": k1_bytes},
@@ -181,6 +182,19 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def profiled_traffic(kernels):
+    """HBM bytes per launch of the given kernels from the committed rocprofv3 PMC passes (profiles/r01_traffic.json,
+    collected on this exact workload): FETCH_SIZE and WRITE_SIZE come from separate passes, are in KB, and FETCH_SIZE is
+    doubled as MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read from inside the benchmark, so
+    this is the profiled value, not a live one; None if the profile is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        table = json.load(open(path))["kernels"]
+        return sum((2.0 * table[k]["fetch_size_kb"] + table[k]["write_size_kb"]) * 1024.0 for k in kernels)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(args, anc):

@@ -219,11 +219,12 @@ struct fa_mapper {
   hipStream_t stream = nullptr;
   std::mutex mtx;
   // reference records and index (see fa_map.hip.h for the layout)
-  DevBuf<uint32_t> rec_hash, uniq_hash, uniq_off, pos_ridx, dir;
+  DevBuf<uint32_t> rec_hash, uniq_hash, uniq_off, pos_ridx;
+  DevBuf<uint4> table;
   DevBuf<int32_t> rec_seq, rec_wpos, rec_prev, rec_fwd, rec_bwd, contig_rec, contig_genome, contig_bin, genome_bin;
   DevBuf<uint8_t> rec_flags;
   int64_t N = 0, U = 0;
-  int32_t C = 0, G = 0, dir_shift = 0, freq_threshold = INT_MAX, total_bins = 0;
+  int32_t C = 0, G = 0, table_bits = 4, freq_threshold = INT_MAX, total_bins = 0;
   std::vector<uint64_t> lengths;
   std::vector<int32_t> seqs_by_file;
   int32_t cmw = 0, qcap = 1;
@@ -254,9 +255,9 @@ struct fa_mapper {
   IndexView view() const {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
-    v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.dir = dir.p;
+    v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.table = table.p;
     v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
-    v.N = N; v.U = U; v.C = C; v.G = G; v.dir_shift = dir_shift; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
+    v.N = N; v.U = U; v.C = C; v.G = G; v.table_bits = table_bits; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
     return v;
   }
 };
@@ -364,12 +365,12 @@ static void build_index(fa_mapper &m) {
       else if (j == to_ignore) { m.freq_threshold = (int)top[i]; break; }
       else break;
     }
-    // directory over the top bits
-    int db = std::min(24, std::max(4, floor_log2(std::max(U, 1)) - 2));
-    m.dir_shift = 32 - db;
-    const int nb = 1 << db;
-    m.dir.ensure((size_t)nb + 2);
-    hipLaunchKernelGGL(k_build_dir, dim3(ceil_div(nb + 1, 256)), dim3(256), 0, st, m.uniq_hash.p, (int64_t)U, m.dir_shift, nb, m.dir.p);
+    // lookup table at load factor <= 1/2
+    m.table_bits = std::max(4, floor_log2(std::max(U, 1)) + 2);
+    FA_REQUIRE(m.table_bits <= 31, FA_ERR_UNSUPPORTED, "too many distinct minimizers for the lookup table");
+    m.table.ensure((size_t)1 << m.table_bits);
+    FA_HIP(hipMemsetAsync(m.table.p, 0, ((size_t)1 << m.table_bits) * sizeof(uint4), st));
+    hipLaunchKernelGGL(k_build_table, dim3(ceil_div(U, 256)), dim3(256), 0, st, m.uniq_hash.p, m.uniq_off.p, (int64_t)U, m.table_bits, m.table.p);
     hipLaunchKernelGGL(k_link_duplicates, dim3(ceil_div(N, 256)), dim3(256), 0, st, sorted_hash.p, m.pos_ridx.p, N, m.rec_seq.p,
                        m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
     hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, m.contig_rec.p, N, m.cmw,
@@ -377,9 +378,9 @@ static void build_index(fa_mapper &m) {
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(st));
   } else {
-    m.dir_shift = 28;
-    m.dir.ensure(18);
-    FA_HIP(hipMemsetAsync(m.dir.p, 0, 18 * sizeof(uint32_t), st));
+    m.table_bits = 4;
+    m.table.ensure(16);
+    FA_HIP(hipMemsetAsync(m.table.p, 0, 16 * sizeof(uint4), st));
     m.uniq_hash.ensure(2); m.uniq_off.ensure(2);
     FA_HIP(hipMemsetAsync(m.uniq_off.p, 0, 2 * sizeof(uint32_t), st));
     FA_HIP(hipStreamSynchronize(st));
@@ -454,6 +455,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
     a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = LDS_SEED_CAP;
     hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
+    hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, LDS_SEED_CAP, m.totals.p, m.ovf_off.p);
     FA_HIP(hipGetLastError());
   }
   int32_t h_stats[4];

@@ -14,7 +14,7 @@
 //                                  is admitted; bit1: the next same-hash record is admitted before this one is dropped
 //   uniq_hash[U], uniq_off[U+1]    sorted distinct hashes and CSR offsets into pos_ridx = minimizerPosLookupIndex
 //   pos_ridx[N]                    record indices grouped by hash, ascending inside a group
-//   dir[2^DB + 1]                  first entry of uniq_hash per top-DB-bits bucket (shortens the binary search)
+//   table[2^B]                     open-addressing hash table {hash, CSR offset, length+1}: one 16-byte probe per lookup
 //   contig_rec[C+1], contig_genome[C], contig_bin[C+1], genome_bin[G+1]
 //
 // Query side, per batch of fragments: q_hash[F*QCAP] sorted distinct query minimizers, q_size[F] = sketchSize.
@@ -136,15 +136,19 @@ __global__ void k_iota(uint32_t *a, int64_t n) {
   if (i < n) a[i] = (uint32_t)i;
 }
 
-// dir[b] = first u with (uniq_hash[u] >> shift) >= b, for b in 0..nb (dir[nb] = U)
-__global__ void k_build_dir(const uint32_t *uniq_hash, int64_t U, int shift, int nb, uint32_t *dir) {
-  int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > nb) return;
-  if (b == nb) { dir[b] = (uint32_t)U; return; }
-  uint64_t key = (uint64_t)b << shift;
-  int64_t lo = 0, hi = U;
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if ((uint64_t)uniq_hash[mid] < key) lo = mid + 1; else hi = mid; }
-  dir[b] = (uint32_t)lo;
+// Open-addressing lookup table over the distinct hashes (= unordered_map::find of _fastani.pyx:943 in one 16-byte
+// probe): entry = {hash, offset into pos_ridx, list length + 1, unused}; .z == 0 marks an empty slot.  Slots are
+// chosen by a multiplicative mix because minimizer hashes are biased towards small values.
+__device__ __forceinline__ uint32_t ht_slot(uint32_t h, int bits) { return (h * 0x9E3779B1u) >> (32 - bits); }
+
+__global__ void k_build_table(const uint32_t *uniq_hash, const uint32_t *uniq_off, int64_t U, int bits, uint4 *table) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= U) return;
+  const uint32_t h = uniq_hash[u], off = uniq_off[u], cnt = uniq_off[u + 1] - off;
+  const uint32_t mask = (1u << bits) - 1u;
+  for (uint32_t slot = ht_slot(h, bits);; slot = (slot + 1) & mask) {
+    if (atomicCAS(&table[slot].z, 0u, cnt + 1u) == 0u) { table[slot].x = h; table[slot].y = off; return; }
+  }
 }
 
 // contig_rec[c] = first record with rec_seq >= c
@@ -233,23 +237,26 @@ struct IndexView {
   const uint32_t *uniq_hash;
   const uint32_t *uniq_off;
   const uint32_t *pos_ridx;
-  const uint32_t *dir;
+  const uint4 *table;
   const int32_t *contig_rec;
   const int32_t *contig_genome;
   const int32_t *contig_bin;
   const int32_t *genome_bin;
   int64_t N, U;
   int32_t C, G;
-  int32_t dir_shift;
+  int32_t table_bits;
   int32_t freq_threshold;
   int32_t total_bins;
 };
 
-__device__ __forceinline__ int64_t index_find(const IndexView &ix, uint32_t h) {
-  uint32_t b = h >> ix.dir_shift;
-  int64_t lo = ix.dir[b], hi = ix.dir[b + 1];
-  while (lo < hi) { int64_t mid = (lo + hi) >> 1; if (ix.uniq_hash[mid] < h) lo = mid + 1; else hi = mid; }
-  return (lo < ix.U && ix.uniq_hash[lo] == h) ? lo : -1;
+// position list of hash h: true if present; off / cnt receive the CSR slice
+__device__ __forceinline__ bool index_find(const IndexView &ix, uint32_t h, uint32_t &off, uint32_t &cnt) {
+  const uint32_t mask = (1u << ix.table_bits) - 1u;
+  for (uint32_t slot = ht_slot(h, ix.table_bits);; slot = (slot + 1) & mask) {
+    const uint4 e = ix.table[slot];
+    if (e.z == 0u) return false;
+    if (e.x == h) { off = e.y; cnt = e.z - 1u; return true; }
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -275,11 +282,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_lookup(LookupArgs a) {
   uint32_t mine = 0;
   for (int j = tid; j < s; j += blockDim.x) {
     uint32_t h = a.q_hash[(size_t)f * a.qcap + j];
-    int64_t u = index_find(a.ix, h);
     uint32_t off = 0, cnt = 0;
-    if (u >= 0) {
-      off = a.ix.uniq_off[u];
-      cnt = a.ix.uniq_off[u + 1] - off;
+    if (index_find(a.ix, h, off, cnt)) {
       if ((int64_t)cnt >= (int64_t)a.ix.freq_threshold) cnt = 0;   // strict `size < threshold` keeps the list
     }
     a.q_off[(size_t)f * a.qcap + j] = off;
@@ -293,14 +297,37 @@ __global__ __launch_bounds__(MAP_THREADS) void k_lookup(LookupArgs a) {
     uint32_t n = 0;
     for (int q = 0; q < MAP_THREADS / 64; q++) n += red[q];
     a.n_seeds[f] = n;
-    atomicAdd((unsigned long long *)&a.totals[0], (unsigned long long)n);
-    atomicMax((unsigned long long *)&a.totals[1], (unsigned long long)n);
-    uint32_t off = 0;
-    if (n > a.lds_seed_cap) {
-      uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
-      off = (uint32_t)atomicAdd((unsigned long long *)&a.totals[2], (unsigned long long)n32);
+  }
+}
+
+// totals[0] = sum of seeds, [1] = largest fragment, [2] = HBM scratch words for fragments whose seeds do not fit LDS
+// (their offsets go to ovf_off).  One workgroup: thousands of same-address atomics from k_lookup cost more than this.
+__global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
+                                                      uint32_t *ovf_off) {
+  __shared__ unsigned long long sh_sum;
+  __shared__ unsigned int sh_max, sh_any;
+  if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; }
+  __syncthreads();
+  unsigned long long sum = 0;
+  unsigned int mx = 0, any = 0;
+  for (int64_t f = threadIdx.x; f < F; f += blockDim.x) {
+    const uint32_t n = n_seeds[f];
+    sum += n; mx = max(mx, n); any |= n > lds_seed_cap;
+    ovf_off[f] = 0;
+  }
+  for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d); mx = max(mx, (unsigned int)__shfl_down((int)mx, d)); any |= (unsigned int)__shfl_down((int)any, d); }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&sh_sum, sum); atomicMax(&sh_max, mx); atomicOr(&sh_any, any); }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    totals[0] = sh_sum; totals[1] = sh_max;
+    unsigned long long words = 0;
+    if (sh_any) {
+      for (int64_t f = 0; f < F; f++) {
+        const uint32_t n = n_seeds[f];
+        if (n > lds_seed_cap) { uint32_t n32 = 1; while (n32 < n) n32 <<= 1; ovf_off[f] = (uint32_t)words; words += n32; }
+      }
     }
-    a.ovf_off[f] = off;
+    totals[2] = words;
   }
 }
 
@@ -776,13 +803,12 @@ __global__ __launch_bounds__(256) void k_cgi_rows(const unsigned long long *bins
   for (int x = x0; x < x1; x += 64) {
     unsigned long long v = (x + lane < x1) ? b[x + lane] : 0ULL;
     float val = __uint_as_float((uint32_t)(v >> 32));
-    unsigned long long mask = __ballot(v != 0ULL);
-    cnt += __popcll(mask);
-    while (mask) {
-      int src = __ffsll((long long)mask) - 1;
-      sum += __shfl(val, src);
-      mask &= mask - 1;
-    }
+    cnt += __popcll(__ballot(v != 0ULL));
+    // empty bins hold +0.0f and x + 0.0f == x exactly, so adding all 64 lanes in lane order IS the reference's
+    // sequential sum over the non-empty bins; constant lane indices keep the chain at one v_readlane + v_add each
+    const int bits = (int)__float_as_uint(val);
+#pragma unroll
+    for (int src = 0; src < 64; src++) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane(bits, src));
   }
   if (lane == 0) {
     row_count[i] = cnt;
