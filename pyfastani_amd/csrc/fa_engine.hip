@@ -531,7 +531,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_HIP(hipMemcpyAsync(&total_items, m.l_ioff.p + nloci, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     FA_HIP(hipMemcpyAsync(&total_records, m.totals.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     FA_HIP(hipStreamSynchronize(st));
-    const bool wide = smax > 4095;
+    const bool wide = smax > 1022;                                      // slot = rank + 1 must fit the 10-bit field
     m.items.ensure(((size_t)total_items + 8) * (wide ? 4 : 2));
     a.items = m.items.p;
     m.last_items = total_items;

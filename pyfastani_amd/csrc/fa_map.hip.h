@@ -553,10 +553,16 @@ struct L2Args {
 constexpr int L2_THREADS = 64;
 constexpr int EV_THREADS = 256;
 
+// Event word: slot (= query rank + 1; 0 is the padding no-op) | dM:2 | dW:2 | drop | eval, where dM / dW are two's
+// complement -1 / 0 / +1: the change of the matched bit of that rank, resp. of its count of window-only hashes.  A
+// record whose admit / drop is a no-op by the duplicate-linking rule carries dM = dW = 0 but keeps drop / eval.
 template <typename T> struct EvBits;
-template <> struct EvBits<uint16_t> { static constexpr int RANK = 12; };
+template <> struct EvBits<uint16_t> { static constexpr int RANK = 10; };   // sketches up to 1022 minimizers
 template <> struct EvBits<uint32_t> { static constexpr int RANK = 24; };
-constexpr uint32_t EV_FOUND = 1, EV_DROP = 2, EV_SKIP = 4, EV_EVAL = 8;
+__device__ __forceinline__ uint32_t ev_word(int rank_bits, int slot, int dM, int dW, bool drop, bool eval) {
+  return (uint32_t)slot | (((uint32_t)dM & 3u) << rank_bits) | (((uint32_t)dW & 3u) << (rank_bits + 2)) |
+         ((drop ? 1u : 0u) << (rank_bits + 4)) | ((eval ? 1u : 0u) << (rank_bits + 5));
+}
 
 __global__ void k_l2_prep(L2Args a) {
   const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -612,28 +618,29 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
     const bool staged = padded <= (uint32_t)a.wpos_lds;
     T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.wpos_lds : gout;
-    for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)(EV_SKIP << EvBits<T>::RANK);
+    for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)0;
     auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
       int x = QT[h >> 24], y = QT[(h >> 24) + 1];
       while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
-      const uint32_t base = (uint32_t)x | (((x < s && Q[x] == h) ? EV_FOUND : 0u) << EvBits<T>::RANK);
+      const bool found = x < s && Q[x] == h;
+      constexpr int RB = EvBits<T>::RANK;
       if (i < end0) {
         // first super-window: inserted in record order, compared once after the last one
-        uint32_t fl = (prev >= beg ? EV_SKIP : 0u) | (i == end0 - 1 ? EV_EVAL : 0u);
-        out[i - beg] = (T)(base | (fl << EvBits<T>::RANK));
+        const int on = prev >= beg ? 0 : 1;
+        out[i - beg] = (T)ev_word(RB, x + 1, found ? on : 0, found ? 0 : on, false, i == end0 - 1);
       } else {
         // admitted after the drops of all records before the one active at its window position (rec_bwd)
         const uint32_t pos = (uint32_t)(n_init + (i - end0) + (bwd - beg));
-        uint32_t fl = ((rf & FLAG_INS_LINKED) ? EV_SKIP : 0u) | EV_EVAL;
-        out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+        const int on = (rf & FLAG_INS_LINKED) ? 0 : 1;
+        out[pos] = (T)ev_word(RB, x + 1, found ? on : 0, found ? 0 : on, false, true);
       }
       if (i - beg < ndrop) {
         // dropped at window position wpos[i+1], after the admits of earlier positions and before the admit of
         // that same position (FLAG_SAME_STEP), which then carries the comparison
         const bool same = (rf & FLAG_SAME_STEP) != 0;
         const uint32_t pos = (uint32_t)(n_init + (i - beg) + (fwd1 - (same ? 1 : 0) - end0));
-        uint32_t fl = EV_DROP | ((rf & FLAG_DEL_LINKED) ? EV_SKIP : 0u) | (same ? 0u : EV_EVAL);
-        out[pos] = (T)(base | (fl << EvBits<T>::RANK));
+        const int off = (rf & FLAG_DEL_LINKED) ? 0 : -1;
+        out[pos] = (T)ev_word(RB, x + 1, found ? off : 0, found ? 0 : off, true, !same);
       }
     };
     // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
@@ -703,35 +710,33 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
       constexpr int WPE = (int)sizeof(T);
       uint32_t word = (q * WPE / 4 == 0) ? cur.x : (q * WPE / 4 == 1) ? cur.y : (q * WPE / 4 == 2) ? cur.z : cur.w;
       const uint32_t e = sizeof(T) == 2 ? ((q & 1) ? (word >> 16) : (word & 0xFFFFu)) : word;
-      const int r = (int)(e & RANK_MASK);
-      // flag bits as 0/1 integers: everything below is straight-line selects (the 64 lanes of a wave follow 64
-      // different loci, any branch would serialise them)
-      const uint32_t fnd = (e >> RB) & 1u, drp = (e >> (RB + 1)) & 1u, skp = (e >> (RB + 2)) & 1u, evl = (e >> (RB + 3)) & 1u;
-      const uint32_t actM = fnd & ~skp & 1u, actW = ~fnd & ~skp & 1u;
-      const int delta = 1 - 2 * (int)drp;
+      // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
+      const int slot = (int)(e & RANK_MASK);                       // query rank + 1 (0 = padding)
+      const int dM = __builtin_amdgcn_sbfe(e, RB, 2), dW = __builtin_amdgcn_sbfe(e, RB + 2, 2);
+      const int drp = (int)((e >> (RB + 4)) & 1u);
+      const bool evl = ((e >> (RB + 5)) & 1u) != 0;
       // both LDS reads are issued together: the touched rank, and the rank at the boundary the pivot may move across
-      const int rbs = rstar + (int)drp;                            // slot of rank r* (drop) or r*-1 (insert)
-      const uint32_t v = st[(r + 1) * LN + lane];
+      const int rbs = rstar + drp;                                 // slot of rank r* (drop) or r*-1 (admit)
+      const uint32_t v = st[slot * LN + lane];
       const uint32_t vb0 = st[rbs * LN + lane];
-      uint32_t nv = v + (actW ? (uint32_t)delta : 0u);
-      overflow |= actW & ~drp & (uint32_t)((nv & CMASK) == 0);     // count wrapped into the MATCH bit
-      nv = (actM & ~drp) ? (nv | MATCH) : nv;
-      nv = (actM & drp) ? (nv & CMASK) : nv;
-      st[(r + 1) * LN + lane] = (ST)nv;
-      const int t = (r < rstar) ? delta : 0;
-      shared += actM ? t : 0;
-      P += actW ? t : 0;
-      const uint32_t vb = (rbs == r + 1) ? nv : vb0;
+      const uint32_t cv = v + (uint32_t)dW;                        // count lives in the low bits
+      overflow |= (cv ^ v) & MATCH;                                // a carry into the MATCH bit = count overflow
+      const uint32_t nv = cv ^ (((uint32_t)dM & 1u) << (SBITS - 1));   // admits of a matched rank set the bit, drops clear it
+      st[slot * LN + lane] = (ST)nv;
+      const bool below = slot <= rstar;                            // rank < r*
+      shared += below ? dM : 0;
+      P += below ? dW : 0;
+      const uint32_t vb = (rbs == slot) ? nv : vb0;
       const int cb = (int)(vb & CMASK), mb = (int)((vb >> (SBITS - 1)) & 1u);
-      // a window-only hash left and query rank r* re-enters the s smallest of the union ...
-      const bool up = (actW & drp) && rstar < s && (rstar + P + cb < s);
+      const int f = rstar + P;                                     // f(r*-1) + 1
+      // a window-only hash left and query rank r* re-enters the s smallest of the union (f + cb < s implies r* < s) ...
+      const bool up = dW < 0 && f + cb < s;
       // ... or one arrived below r* and f(r*-1) reached s: the largest query rank falls out
-      const bool down = (actW & ~drp & 1u) && (r < rstar) && (rstar - 1 + P >= s);
-      const int dir = up ? 1 : (down ? -1 : 0);
-      P += dir * cb;
-      shared += dir * mb;
-      rstar += dir;
-      beg += (int)drp;
+      const bool down = dW > 0 && below && f > s;
+      P += up ? cb : (down ? -cb : 0);
+      shared += up ? mb : (down ? -mb : 0);
+      rstar += up ? 1 : (down ? -1 : 0);
+      beg += drp;
       const bool gt = evl && shared > best, ge = evl && shared >= best;
       best = gt ? shared : best;
       opt_s = gt ? beg : opt_s;
