@@ -515,10 +515,9 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
     a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
     a.cnt_slots = smax + 1;
-    a.smax_words = (smax + 32) / 32;
     a.lanes = L2_THREADS;
     a.rec_total = (unsigned long long *)(m.totals.p + 3);
-    a.wpos_lds = 0;
+    a.ev_stage = 0;
     hipLaunchKernelGGL(k_l2_prep, dim3(ceil_div((int64_t)nloci + 1, 256)), dim3(256), 0, st, a);
     {
       size_t bytes = 0;
@@ -538,8 +537,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.last_ms[5] += (float)total_records;   // reference records inside the locus ranges of this call (roofline line)
     m.last_ms[7] += (float)total_items;     // slide events
     m.last_ms[6] += (float)nloci;
-    a.wpos_lds = 2048;                                                  // events staged per wave (longer streams go direct)
-    const size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.wpos_lds * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
+    a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
+    const size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
     FA_REQUIRE(rank_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
     m.l_redo.ensure((size_t)nloci + 4);
     a.l_redo = m.l_redo.p;

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   if (n32 < 2) n32 = 2;
   for (uint32_t i = n + tid; i < n32; i += blockDim.x) buf[i] = SEED_PAD;
   __syncthreads();
-  // NOTE: a real hash may equal SEED_PAD (protein mode); count how many real entries carry that value
+  // a real hash may equal SEED_PAD (protein mode): harmless, the first n sorted entries are then the same multiset
   block_bitonic_sort(buf, n32);
   // unique: keep buf[i] if i == 0 or differs from predecessor, among the first n sorted entries
   if (tid == 0) { sh_n = 0; sh_total = 0; }
@@ -540,10 +540,10 @@ struct L2Args {
   const int32_t *pass_lut;           // [smax+1]
   unsigned long long *group_best;    // [groups] (shared<<32 | ~locus)
   const uint32_t *counters;          // [0] number of loci
-  int32_t qcap, cmw, smax_words;     // smax_words = ceil((smax+1)/32)
+  int32_t qcap, cmw;
   int32_t cnt_slots;                 // smax + 1
   int32_t lanes;                     // loci per workgroup of k_l2_scan (power of two <= 64)
-  int32_t wpos_lds;                  // events of one locus staged in LDS per wave of k_l2_events
+  int32_t ev_stage;                  // events of one locus staged in LDS per wave of k_l2_events
   unsigned long long *rec_total;     // sum over loci of the records in their range (for the roofline line)
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
@@ -616,8 +616,8 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     T *gout = (T *)a.items + a.l_ioff[l];
     // events land at scattered 2-byte positions: build the stream of a locus in LDS and stream it out in 16-byte
     // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
-    const bool staged = padded <= (uint32_t)a.wpos_lds;
-    T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.wpos_lds : gout;
+    const bool staged = padded <= (uint32_t)a.ev_stage;
+    T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
     for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)0;
     auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
       int x = QT[h >> 24], y = QT[(h >> 24) + 1];
