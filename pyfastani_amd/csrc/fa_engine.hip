@@ -469,7 +469,9 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   FA_REQUIRE(total_seeds < (1ULL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 seed hits in one pass; query fewer genomes per call");
   m.ovf_buf.ensure((size_t)ovf_words + 4);
   // ---- L1 (retry with a larger loci capacity if the first guess overflows) ----
-  int64_t l_cap = (int64_t)std::min<uint64_t>(total_seeds, std::max<uint64_t>(1u << 18, total_seeds / 8));
+  // first guess of the loci capacity (FA_LOCI_CAP_MIN lets the tests force the retry path)
+  static const uint64_t loci_cap_min = [] { const char *e = getenv("FA_LOCI_CAP_MIN"); long long x = e ? atoll(e) : 0; return (uint64_t)(x > 0 ? x : (1 << 18)); }();
+  int64_t l_cap = (int64_t)std::min<uint64_t>(total_seeds, std::max<uint64_t>(loci_cap_min, total_seeds / 8));
   uint32_t h_counters[4] = {0, 0, 0, 0};
   for (int attempt = 0; attempt < 2 && total_seeds > 0; attempt++) {
     m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap);

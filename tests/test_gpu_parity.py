@@ -434,3 +434,67 @@ def test_all_vs_all_drafts_multi_pass():
     env = dict(os.environ, FA_PASS_FRAGMENTS="120")        # 14 genomes x ~45 fragments -> several passes
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "OK" in res.stdout, res.stdout + res.stderr
+
+
+def _run_child(code, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "OK" in res.stdout, res.stdout + res.stderr
+
+
+def test_seed_overflow_to_hbm_scratch():
+    # 200 copies of one small genome: every query minimizer hits 200 positions, so a fragment gathers ~48 000 seed
+    # hits -- more than the 32 768 that fit the LDS sort -- and takes the HBM scratch path of k_l1
+    g = syn.rng(95)
+    base = syn.random_codes(g, 21_000)
+    refs = [[syn.to_ascii(base)] for _ in range(200)]
+    query = [syn.to_ascii(syn.mutate_codes(g, base, 0.01))]
+    mapper, hits, ohits, det = run_both({}, refs, query, threads=8)
+    assert mapper.occurences_threshold == 2**31 - 1 and len(ohits) == 200
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+
+
+def test_loci_capacity_retry():
+    # forces the first guess of the loci capacity below the real number so that k_l1 reports overflow and is re-run
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, warnings
+        sys.path.insert(0, %r)
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        from oracle.oracle import OracleSketch
+        g = syn.rng(96)
+        anc = syn.random_codes(g, 120_000)
+        sk, osk = pf.Sketch(), OracleSketch()
+        for i, d in enumerate((0.01, 0.05, 0.1)):
+            r = syn.to_ascii(syn.mutate_codes(g, anc, d)); sk.add_genome(i, r); osk.add_genome(i, r)
+        m = sk.index(); osk.index()
+        q = syn.to_ascii(syn.mutate_codes(g, anc, 0.03))
+        got = [(h.name, h.identity, h.matches, h.fragments) for h in m.query_genome(q)]
+        assert got == osk.query_draft([q]) and len(got) == 3, got
+        print("OK")
+    """ % ROOT)
+    _run_child(code, {"FA_LOCI_CAP_MIN": "7"})
+
+
+def test_long_locus_and_reference_exceptions():
+    # a tandem array in the reference merges dozens of overlapping candidates into one locus whose event stream is far
+    # longer than the 2048 events staged in LDS; N runs and IUPAC codes in the reference take the byte path of K1
+    g = syn.rng(97)
+    unit = syn.random_codes(g, 1000)
+    flank = syn.random_codes(g, 40_000)
+    ref = np.concatenate([flank[:20_000]] + [syn.mutate_codes(g, unit, 0.01) for _ in range(40)] + [flank[20_000:]])
+    ref_ascii = bytearray(bytes(syn.to_ascii(ref)))
+    ref_ascii[5_000:5_060] = b"N" * 60
+    ref_ascii[30_500:30_503] = b"RYK"
+    ref_ascii[2048 + 23] = ord("n")                          # right at a tile boundary
+    other = bytes(syn.to_ascii(syn.mutate_codes(g, ref, 0.06)))
+    query = np.concatenate([flank[18_000:20_000]] + [unit] * 4 + [flank[20_000:22_000]] + [unit] * 3)
+    mapper, hits, ohits, det = run_both({}, [[bytes(ref_ascii)], [other]], [syn.to_ascii(query)])
+    ms = (C.c_float * 16)()
+    lib.fa_mapper_last_timings(mapper._h, ms, 16)
+    assert ms[7] / max(ms[6], 1) > 2048, "expected loci with more than 2048 slide events"
+    assert gpu_mappings(mapper) == oracle_mappings(det) and len(ohits) == 2
+    assert hit_tuples(hits) == ohits
