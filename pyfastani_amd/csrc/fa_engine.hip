@@ -237,7 +237,16 @@ struct fa_mapper {
   DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
   DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
   DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
-  DevBuf<uint32_t> l_items, l_ioff, f_loci_lo, f_loci_n;
+  DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
+  DevBuf<unsigned long long> pinfo;
+  // data-dependent sizes speculated from earlier passes (see run_query_pass)
+  struct Spec {
+    bool init = false;
+    int smax = 0;
+    uint32_t seed_slots = 0;
+    uint64_t scratch_words = 0, items_cap = 0;
+    int64_t l_cap = 0;
+  } spec;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo;
   uint64_t last_items = 0;
@@ -403,7 +412,25 @@ static void ensure_luts(fa_mapper &m, int smax) {
 
 static const uint32_t LDS_SEED_CAP = 32768;   // 128 KiB of seed indices per workgroup at most
 
-// returns the number of rows written at rows_dev[row_base ...]
+static uint64_t env_u64(const char *name, uint64_t dflt) {
+  const char *e = getenv(name);
+  long long x = e ? atoll(e) : 0;
+  return x > 0 ? (uint64_t)x : dflt;
+}
+
+// FA_DEBUG_SYNC=1: synchronise after every stage of a query pass and name the stage that failed
+static void debug_sync(hipStream_t st, const char *stage) {
+  static const bool on = getenv("FA_DEBUG_SYNC") != nullptr;
+  if (!on) return;
+  fprintf(stderr, "[fa] %s ...\n", stage);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) throw Error(FA_ERR_NO_DEVICE, std::string("stage ") + stage + " failed: " + hipGetErrorString(e));
+}
+
+// One pass of the hot path over genomes [g0, g1) of a resident batch.  Everything between the first kernel and the
+// final read-back is asynchronous on one stream: sizes that depend on the data (largest sketch, seed hits per
+// fragment, loci, slide events) are *speculated* from earlier passes (fa_mapper::spec), checked on the device, and the
+// pass is repeated with larger bounds if a check fails.  Returns the number of rows written at rows_dev[row_base ...].
 static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
                               int64_t row_base) {
   hipStream_t st = m.stream;
@@ -412,218 +439,223 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   const int NQ = g1 - g0;
   m.last_F = F; m.last_f0 = f0; m.last_loci = 0; m.last_genomes = &g;
   for (int i = 0; i < 6; i++) if (!m.ev[i]) FA_HIP(hipEventCreate(&m.ev[i]));
-  FA_HIP(hipEventRecord(m.ev[0], st));
-  if (F == 0) {
-    for (int i = 1; i < 6; i++) FA_HIP(hipEventRecord(m.ev[i], st));
-    return 0;
-  }
+  if (F == 0) return 0;
   FA_REQUIRE(m.P.fragment_length > 20, FA_ERR_UNSUPPORTED, "fragment_length must exceed 20 (the reference bins by fragment_length - 20)");
   const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
   const int ntiles = t1 - t0;
   const int qcap = m.qcap;
-  // ---- K1 + per-fragment sort/unique ----
+  const IndexView ix = m.view();
+  const int64_t npairs = (int64_t)NQ * m.G;
+  fa_mapper::Spec &sp = m.spec;
+  if (!sp.init) {
+    sp.init = true;
+    sp.smax = 256;
+    sp.seed_slots = 16384;
+    sp.scratch_words = 0;
+    sp.l_cap = (int64_t)env_u64("FA_LOCI_CAP_MIN", 1u << 18);   // the tests force the retry path with a tiny value
+    sp.items_cap = env_u64("FA_EVENTS_CAP_MIN", 1u << 26);
+  }
+  // buffers whose size depends only on the pass geometry
   m.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
   m.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
   m.sk.tile_count.ensure((size_t)ntiles + 1);
-  launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, m.sk.stage_hash.p, m.sk.stage_wpos.p, m.sk.tile_count.p, st);
   m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
   m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
   m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
-  m.stats_dev.ensure(4); m.totals.ensure(4); m.counters.ensure(4);
-  FA_HIP(hipMemsetAsync(m.stats_dev.p, 0, 4 * sizeof(int32_t), st));
-  FA_HIP(hipMemsetAsync(m.totals.p, 0, 4 * sizeof(uint64_t), st));
-  FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
-  {
-    QuerySketchArgs a;
-    a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
-    a.tile_count = m.sk.tile_count.p - t0;       // indexed by global tile number
-    a.stage_hash = m.sk.stage_hash.p - (size_t)t0 * TILE;
-    a.stage_wpos = m.sk.stage_wpos.p - (size_t)t0 * TILE;
-    a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = m.stats_dev.p; a.qcap = qcap;
-    a.sort_cap = (int32_t)next_pow2((uint32_t)std::max(qcap, 2));
-    size_t lds = (size_t)a.sort_cap * 4;
-    FA_REQUIRE(lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
-    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), lds, st, a);
-    FA_HIP(hipGetLastError());
-  }
-  FA_HIP(hipEventRecord(m.ev[1], st));
-  // ---- lookup ----
-  const IndexView ix = m.view();
-  {
-    LookupArgs a;
-    a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
-    a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = LDS_SEED_CAP;
-    hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
-    hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, LDS_SEED_CAP, m.totals.p, m.ovf_off.p);
-    FA_HIP(hipGetLastError());
-  }
-  int32_t h_stats[4];
-  uint64_t h_totals[4];
-  m.stats_dev.download(h_stats, 4, st);
-  m.totals.download(h_totals, 4, st);
-  FA_HIP(hipStreamSynchronize(st));
-  const int smax = h_stats[0];
-  ensure_luts(m, smax);
-  const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1], ovf_words = h_totals[2];
-  FA_REQUIRE(total_seeds < (1ULL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 seed hits in one pass; query fewer genomes per call");
-  m.ovf_buf.ensure((size_t)ovf_words + 4);
-  // ---- L1 (retry with a larger loci capacity if the first guess overflows) ----
-  // first guess of the loci capacity (FA_LOCI_CAP_MIN lets the tests force the retry path)
-  static const uint64_t loci_cap_min = [] { const char *e = getenv("FA_LOCI_CAP_MIN"); long long x = e ? atoll(e) : 0; return (uint64_t)(x > 0 ? x : (1 << 18)); }();
-  int64_t l_cap = (int64_t)std::min<uint64_t>(total_seeds, std::max<uint64_t>(loci_cap_min, total_seeds / 8));
-  uint32_t h_counters[4] = {0, 0, 0, 0};
-  for (int attempt = 0; attempt < 2 && total_seeds > 0; attempt++) {
+  m.stats_dev.ensure(4); m.totals.ensure(4); m.counters.ensure(4); m.pinfo.ensure(4);
+  m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1));
+  m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
+  m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
+  const size_t qs_lds = (size_t)next_pow2((uint32_t)std::max(qcap, 2)) * 4;
+  FA_REQUIRE(qs_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
+
+  int64_t nrows = 0;
+  for (int attempt = 0;; attempt++) {
+    FA_REQUIRE(attempt < 6, FA_ERR_INTERNAL, "query pass did not converge on its buffer sizes");
+    // ---- buffers and tables sized by the speculated bounds ----
+    const int smax = sp.smax;
+    FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
+    ensure_luts(m, smax);
+    const int64_t l_cap = sp.l_cap;
     m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap);
     m.l_rfirst.ensure((size_t)l_cap); m.l_rlast.ensure((size_t)l_cap);
     m.l_group.ensure((size_t)l_cap); m.l_shared.ensure((size_t)l_cap); m.l_pos.ensure((size_t)l_cap);
     m.group_best.ensure((size_t)l_cap);
+    m.l_beg.ensure((size_t)l_cap); m.l_end0.ensure((size_t)l_cap); m.l_last.ensure((size_t)l_cap); m.l_ndrop.ensure((size_t)l_cap);
+    m.l_nev.ensure((size_t)l_cap); m.l_ioff.ensure((size_t)l_cap); m.l_redo.ensure((size_t)l_cap + 4);
+    m.ovf_buf.ensure((size_t)sp.scratch_words + 4);
+    const bool wide = smax > 1022;                                      // slot = rank + 1 must fit the 10-bit field
+    m.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
+
+    FA_HIP(hipEventRecord(m.ev[0], st));
+    FA_HIP(hipMemsetAsync(m.stats_dev.p, 0, 4 * sizeof(int32_t), st));
+    FA_HIP(hipMemsetAsync(m.totals.p, 0, 4 * sizeof(uint64_t), st));
+    FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
+    FA_HIP(hipMemsetAsync(m.pinfo.p, 0, 4 * sizeof(unsigned long long), st));
+    // ---- K1 + per-fragment sort/unique ----
+    launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, m.sk.stage_hash.p, m.sk.stage_wpos.p, m.sk.tile_count.p, st);
+    {
+      QuerySketchArgs a;
+      a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
+      a.tile_count = m.sk.tile_count.p - t0;       // indexed by global tile number
+      a.stage_hash = m.sk.stage_hash.p - (size_t)t0 * TILE;
+      a.stage_wpos = m.sk.stage_wpos.p - (size_t)t0 * TILE;
+      a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = m.stats_dev.p; a.qcap = qcap;
+      a.sort_cap = (int32_t)(qs_lds / 4);
+      if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
+      hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
+    }
+    debug_sync(st, "sketch");
+    FA_HIP(hipEventRecord(m.ev[1], st));
+    // ---- lookup, seed totals and speculation checks ----
+    {
+      LookupArgs a;
+      a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
+      a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = sp.seed_slots;
+      hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
+      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, sp.seed_slots, m.totals.p, m.ovf_off.p,
+                         m.stats_dev.p, smax, sp.scratch_words, m.pinfo.p);
+    }
+    debug_sync(st, "lookup");
+    // ---- L1 ----
     FA_HIP(hipMemsetAsync(m.l_end.p, 0, (size_t)l_cap * sizeof(int32_t), st));
     FA_HIP(hipMemsetAsync(m.l_rlast.p, 0, (size_t)l_cap * sizeof(int32_t), st));
-    FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
-    L1Args a;
-    a.ix = ix; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p; a.n_seeds = m.n_seeds.p;
-    a.ovf_off = m.ovf_off.p; a.ovf_buf = m.ovf_buf.p; a.min_hits_lut = m.d_min_hits.p;
-    a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
-    a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p;
-    a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
-    a.lds_seed_cap = LDS_SEED_CAP;
-    a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
-    uint32_t seed_slots = std::min<uint32_t>(LDS_SEED_CAP, next_pow2((uint32_t)std::max<uint64_t>(max_seeds, 2)));
-    size_t lds = (size_t)seed_slots * 4;
-    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_l1, dim3((unsigned)F), dim3(MAP_THREADS), lds, st, a);
-    FA_HIP(hipGetLastError());
-    m.counters.download(h_counters, 4, st);
-    FA_HIP(hipStreamSynchronize(st));
-    if (!h_counters[2]) break;
-    FA_REQUIRE(attempt == 0, FA_ERR_INTERNAL, "L1 loci capacity overflow after resize");
-    l_cap = (int64_t)total_seeds;
-  }
-  FA_HIP(hipEventRecord(m.ev[2], st));
-  const uint32_t nloci = h_counters[0], ngroups = h_counters[1];
-  m.last_loci = nloci;
-  // ---- L2: prep (ranges) -> scan of range sizes -> rank items -> sequential slide ----
-  if (nloci > 0) {
-    FA_HIP(hipMemsetAsync(m.group_best.p, 0, (size_t)ngroups * sizeof(unsigned long long), st));
-    m.l_beg.ensure((size_t)nloci + 1); m.l_end0.ensure((size_t)nloci + 1); m.l_last.ensure((size_t)nloci + 1);
-    m.l_items.ensure((size_t)nloci + 2); m.l_ioff.ensure((size_t)nloci + 2); m.l_ndrop.ensure((size_t)nloci + 1);
-    L2Args a;
-    a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
-    a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
-    a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p; a.frag_len = m.P.fragment_length;
-    a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_items = m.l_items.p; a.l_ioff = m.l_ioff.p; a.l_ndrop = m.l_ndrop.p;
-    a.items = nullptr;
-    a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
-    a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
-    a.cnt_slots = smax + 1;
-    a.lanes = L2_THREADS;
-    a.rec_total = (unsigned long long *)(m.totals.p + 3);
-    a.ev_stage = 0;
-    hipLaunchKernelGGL(k_l2_prep, dim3(ceil_div((int64_t)nloci + 1, 256)), dim3(256), 0, st, a);
+    FA_HIP(hipMemsetAsync(m.group_best.p, 0, (size_t)l_cap * sizeof(unsigned long long), st));
     {
-      size_t bytes = 0;
-      FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, m.l_items.p, m.l_ioff.p, (int)nloci + 1, st));
-      m.sk.cub_temp.ensure(bytes + 16);
-      FA_HIP(hipcub::DeviceScan::ExclusiveSum(m.sk.cub_temp.p, bytes, m.l_items.p, m.l_ioff.p, (int)nloci + 1, st));
+      L1Args a;
+      a.ix = ix; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p; a.n_seeds = m.n_seeds.p;
+      a.ovf_off = m.ovf_off.p; a.ovf_buf = m.ovf_buf.p; a.min_hits_lut = m.d_min_hits.p;
+      a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+      a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p;
+      a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
+      a.lds_seed_cap = sp.seed_slots; a.pinfo = m.pinfo.p; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
+      a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
+      const size_t lds = (size_t)sp.seed_slots * 4;
+      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_l1, dim3((unsigned)F), dim3(MAP_THREADS), lds, st, a);
     }
-    uint32_t total_items = 0;
-    uint64_t total_records = 0;
-    FA_HIP(hipMemcpyAsync(&total_items, m.l_ioff.p + nloci, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    FA_HIP(hipMemcpyAsync(&total_records, m.totals.p + 3, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    FA_HIP(hipStreamSynchronize(st));
-    const bool wide = smax > 1022;                                      // slot = rank + 1 must fit the 10-bit field
-    m.items.ensure(((size_t)total_items + 8) * (wide ? 4 : 2));
-    a.items = m.items.p;
-    m.last_items = total_items;
-    m.last_ms[5] += (float)total_records;   // reference records inside the locus ranges of this call (roofline line)
-    m.last_ms[7] += (float)total_items;     // slide events
-    m.last_ms[6] += (float)nloci;
-    a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
-    const size_t rank_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
-    FA_REQUIRE(rank_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
-    m.l_redo.ensure((size_t)nloci + 4);
-    a.l_redo = m.l_redo.p;
-    a.redo_count = m.counters.p + 3;
-    a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
-    // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
-    auto scan_lds = [&](int ln, int bytes) { return ((size_t)(a.cnt_slots + 1) * ln * bytes + 15) / 16 * 16; };
-    auto pick_lanes = [&](int bytes) {
-      int ln = L2_THREADS;
-      while (ln > 1 && scan_lds(ln, bytes) > 144 * 1024) ln >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
-      FA_REQUIRE(scan_lds(ln, bytes) <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state");
-      return ln;
-    };
-    FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
-    const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
-    const size_t lds8 = scan_lds(lanes8, 1), lds16 = scan_lds(lanes16, 2);
-    auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
-      if (rank_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rank_lds));
-      hipLaunchKernelGGL(ev_kernel, dim3((unsigned)F), dim3(EV_THREADS), rank_lds, st, a);
-      a.lanes = lanes8;
-      if (lanes8 == L2_THREADS) {
-        if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        hipLaunchKernelGGL(scan8, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
-      } else {
-        if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-        hipLaunchKernelGGL(scan8_rt, dim3(ceil_div(nloci, lanes8)), dim3(L2_THREADS), lds8, st, a);
-      }
-      a.lanes = lanes16;
-      if (lanes16 == L2_THREADS) {
-        if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        hipLaunchKernelGGL(scan16, dim3(ceil_div(nloci, lanes16)), dim3(L2_THREADS), lds16, st, a);
-      } else {
-        if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-        hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(nloci, lanes16)), dim3(L2_THREADS), lds16, st, a);
-      }
-    };
-    if (wide) launch(k_l2_events<uint32_t>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
-    else launch(k_l2_events<uint16_t>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
-    FA_HIP(hipGetLastError());
-  }
-  FA_HIP(hipEventRecord(m.ev[3], st));
-  // ---- core-genome identity ----
-  const int64_t npairs = (int64_t)NQ * m.G;
-  int64_t nrows = 0;
-  if (nloci > 0 && npairs > 0) {
-    m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1));
-    FA_HIP(hipMemsetAsync(m.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
-    CgiArgs a;
-    a.ix = ix; a.group_best = m.group_best.p; a.counters = m.counters.p; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
-    a.l_pos = m.l_pos.p; a.q_size = m.q_size.p; a.ident_lut = m.d_ident.p;
-    a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = m.bins.p;
-    a.bin_len = m.P.fragment_length - 20;
-    a.query_base = g0;
-    // frag_query holds batch-wide genome numbers; rebase to this pass
-    hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(std::max<uint32_t>(ngroups, 1), 256)), dim3(256), 0, st, a);
-    m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
-    m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
-    hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
-                       m.row_count.p, m.row_ident.p);
-    hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
-    FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
-    exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
+    debug_sync(st, "l1");
+    FA_HIP(hipEventRecord(m.ev[2], st));
+    // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
+    {
+      L2Args a;
+      a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
+      a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
+      a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p; a.frag_len = m.P.fragment_length;
+      a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_nev = m.l_nev.p; a.l_ioff = m.l_ioff.p; a.l_ndrop = m.l_ndrop.p;
+      a.items = m.items.p; a.items_cap = sp.items_cap; a.pinfo = m.pinfo.p; a.l_cap = (int32_t)l_cap;
+      a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
+      a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
+      a.cnt_slots = smax + 1;
+      a.rec_total = (unsigned long long *)(m.totals.p + 3);
+      a.l_redo = m.l_redo.p;
+      a.redo_count = m.counters.p + 3;
+      a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
+      a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
+      const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
+      FA_REQUIRE(ev_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
+      // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
+      auto scan_lds = [&](int ln, int bytes) { return ((size_t)(a.cnt_slots + 1) * ln * bytes + 15) / 16 * 16; };
+      auto pick_lanes = [&](int bytes) {
+        int ln = L2_THREADS;
+        while (ln > 1 && scan_lds(ln, bytes) > 144 * 1024) ln >>= 1;   // large sketches (tiny windows): fewer loci per workgroup
+        FA_REQUIRE(scan_lds(ln, bytes) <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-resident L2 state");
+        return ln;
+      };
+      const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
+      const size_t lds8 = scan_lds(lanes8, 1), lds16 = scan_lds(lanes16, 2);
+      auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
+        if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
+        hipLaunchKernelGGL(ev_kernel, dim3((unsigned)F), dim3(EV_THREADS), ev_lds, st, a);
+        debug_sync(st, "l2 events");
+        // the number of loci is only known on the device: launch for the capacity, surplus workgroups exit at once
+        a.lanes = lanes8;
+        if (lanes8 == L2_THREADS) {
+          if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+          hipLaunchKernelGGL(scan8, dim3(ceil_div(l_cap, lanes8)), dim3(L2_THREADS), lds8, st, a);
+        } else {
+          if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
+          hipLaunchKernelGGL(scan8_rt, dim3(ceil_div(l_cap, lanes8)), dim3(L2_THREADS), lds8, st, a);
+        }
+        a.lanes = lanes16;
+        if (lanes16 == L2_THREADS) {
+          if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+          hipLaunchKernelGGL(scan16, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
+        } else {
+          if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+          hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
+        }
+      };
+      if (wide) launch(k_l2_events<uint32_t>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+      else launch(k_l2_events<uint16_t>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+    }
+    debug_sync(st, "l2 scan");
+    FA_HIP(hipEventRecord(m.ev[3], st));
+    // ---- core-genome identity ----
     int32_t total_rows = 0;
-    uint32_t redo = 0;
-    FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    FA_HIP(hipMemcpyAsync(&redo, m.counters.p + 3, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
-                       npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
+    if (npairs > 0) {
+      FA_HIP(hipMemsetAsync(m.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
+      CgiArgs a;
+      a.ix = ix; a.group_best = m.group_best.p; a.counters = m.counters.p; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
+      a.l_pos = m.l_pos.p; a.q_size = m.q_size.p; a.ident_lut = m.d_ident.p;
+      a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = m.bins.p;
+      a.bin_len = m.P.fragment_length - 20;
+      a.query_base = g0;                             // frag_query holds batch-wide genome numbers
+      hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
+                         m.row_count.p, m.row_ident.p);
+      hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
+      FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
+      exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
+      FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
+                         npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
+    }
     FA_HIP(hipGetLastError());
+    debug_sync(st, "cgi");
     FA_HIP(hipEventRecord(m.ev[4], st));
+    // ---- the one synchronisation of the pass: results, statistics and the speculation verdict ----
+    int32_t h_stats[4];
+    uint64_t h_totals[4];
+    uint32_t h_counters[4];
+    unsigned long long h_pinfo[4];
+    m.stats_dev.download(h_stats, 4, st);
+    m.totals.download(h_totals, 4, st);
+    m.counters.download(h_counters, 4, st);
+    m.pinfo.download(h_pinfo, 4, st);
+    FA_HIP(hipEventRecord(m.ev[5], st));
     FA_HIP(hipStreamSynchronize(st));
+    const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
+    FA_REQUIRE(total_seeds < (1ULL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 seed hits in one pass; query fewer genomes per call");
+    const unsigned long long flags = h_pinfo[1];
+    // bounds for the next pass (or the repeat of this one)
+    if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 16 + 31) / 32 * 32;
+    const uint32_t want_slots = std::min<uint32_t>(LDS_SEED_CAP, std::max<uint32_t>(1024, next_pow2((uint32_t)std::max<uint64_t>(max_seeds, 2))));
+    const bool slots_changed = want_slots != sp.seed_slots;
+    if (flags & SPEC_SCRATCH) sp.scratch_words = std::max<uint64_t>(sp.scratch_words, h_totals[2] + h_totals[2] / 4);
+    if (flags & SPEC_LOCI) sp.l_cap = std::max<int64_t>(sp.l_cap * 2, (int64_t)h_counters[0] + h_counters[0] / 4);
+    FA_REQUIRE(sp.l_cap < (1LL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 candidate loci in one pass; query fewer genomes per call");
+    if (flags & SPEC_EVENTS) sp.items_cap = std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4);
+    FA_REQUIRE(sp.items_cap < (1ULL << 32), FA_ERR_UNSUPPORTED, "more than 2^32 slide events in one pass; query fewer genomes per call");
+    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; continue; }   // void pass: run it again
+    if (slots_changed) {
+      // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
+      sp.seed_slots = want_slots;
+    }
+    // ---- accepted ----
+    float ms;
+    for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, m.ev[i], m.ev[i + 1])); m.last_ms[i] += ms; }
+    FA_HIP(hipEventElapsedTime(&ms, m.ev[0], m.ev[5]));
+    m.last_ms[4] += ms;
+    m.last_loci = h_counters[0];
+    m.last_items = h_pinfo[0];
+    m.last_ms[5] += (float)h_totals[3];   // reference records inside the locus ranges of this call (roofline line)
+    m.last_ms[6] += (float)h_counters[0];
+    m.last_ms[7] += (float)h_pinfo[0];    // slide events
+    m.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
     nrows = total_rows;
-    m.last_ms[8] += (float)redo;   // loci that needed the wide L2 state
-  } else {
-    FA_HIP(hipEventRecord(m.ev[4], st));
-    FA_HIP(hipStreamSynchronize(st));
+    break;
   }
-  FA_HIP(hipEventRecord(m.ev[5], st));
-  FA_HIP(hipEventSynchronize(m.ev[5]));
-  float ms;
-  for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, m.ev[i], m.ev[i + 1])); m.last_ms[i] += ms; }
-  FA_HIP(hipEventElapsedTime(&ms, m.ev[0], m.ev[5]));
-  m.last_ms[4] += ms;
   FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
   return nrows;
 }

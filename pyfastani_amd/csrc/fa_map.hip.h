@@ -300,10 +300,18 @@ __global__ __launch_bounds__(MAP_THREADS) void k_lookup(LookupArgs a) {
   }
 }
 
-// totals[0] = sum of seeds, [1] = largest fragment, [2] = HBM scratch words for fragments whose seeds do not fit LDS
-// (their offsets go to ovf_off).  One workgroup: thousands of same-address atomics from k_lookup cost more than this.
+// Pass-level speculation.  A query pass is launched without intermediate host synchronisation, sized by what earlier
+// passes needed (largest sketch, LDS seed slots, HBM seed scratch, loci and event capacities).  Kernels check those
+// bounds on the device, skip the work that does not fit and raise a flag; the host reads the flags once at the end of
+// the pass and, if any is set, grows the bounds and runs the pass again.
+constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS = 8;
+
+// totals[0] = sum of seeds, [1] = largest fragment, [2] = HBM scratch words for fragments whose seeds do not fit the
+// LDS slots of k_l1 (their offsets go to ovf_off).  One workgroup: thousands of same-address atomics from k_lookup cost
+// more than this.  Also checks the speculated sketch-size and scratch bounds.
 __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
-                                                      uint32_t *ovf_off) {
+                                                      uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
+                                                      uint64_t spec_scratch_words, unsigned long long *pinfo) {
   __shared__ unsigned long long sh_sum;
   __shared__ unsigned int sh_max, sh_any;
   if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; }
@@ -328,6 +336,10 @@ __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, i
       }
     }
     totals[2] = words;
+    unsigned long long flags = 0;
+    if (stats[0] > spec_smax) flags |= SPEC_SMAX;
+    if (words > spec_scratch_words || words >= (1ULL << 32)) flags |= SPEC_SCRATCH;
+    if (flags) atomicOr(&pinfo[1], flags);
   }
 }
 
@@ -349,6 +361,9 @@ struct L1Args {
   int32_t *l_rfirst, *l_rlast;   // record index of the first / last seed of the locus
   uint32_t *counters;            // [0] loci, [1] groups, [2] loci overflow flag
   uint32_t *f_loci_lo, *f_loci_n; // [F] loci of each fragment (contiguous)
+  unsigned long long *pinfo;     // [1] speculation flags
+  int32_t lut_smax;              // sketch sizes the LUTs cover
+  uint64_t scratch_words;        // capacity of ovf_buf
   int32_t qcap, frag_len, l_cap;
   uint32_t lds_seed_cap;
 };
@@ -364,8 +379,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
   const uint32_t n = a.n_seeds[f];
   if (tid == 0) { a.f_loci_lo[f] = 0; a.f_loci_n[f] = 0; }
   if (s == 0 || n == 0) return;
+  if (s > a.lut_smax) return;                    // SPEC_SMAX was raised by k_seed_totals: the pass will be repeated
   uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
   if (n32 < 2) n32 = 2;
+  if (n > a.lds_seed_cap && (uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;   // SPEC_SCRATCH, same
   uint32_t *seeds = (n <= a.lds_seed_cap) ? (uint32_t *)lds : a.ovf_buf + a.ovf_off[f];
 
   // ---- gather the position lists (ordered by query hash; order is irrelevant before the sort) ----
@@ -461,7 +478,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       if (tid == 0) {
         uint32_t cnt = sh_run;
         uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
-        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); cnt = 0; }
+        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
         sh_gbase = cnt;   // reuse: number of loci (0 => skip)
         a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
@@ -514,17 +531,17 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
 // among the s smallest of the union iff f(r) < s, so shared = #{matched r < r*}, r* = min{r : f(r) >= s}.
 // r* moves by at most one per inserted / deleted hash, exactly like the reference's pivot.
 // ----------------------------------------------------------------------------------------------------------
-// The work is split into three launches so that nothing slow sits on the sequential chain:
-//   k_l2_prep   one lane per locus: the searchIndex() binary searches -> record range [beg, last), the end of the
-//               first super-window, and the number of slide events;
-//   k_l2_events one workgroup per locus, query sketch and the locus' window positions staged in LDS: every record is
-//               reduced to its rank in the query sketch (8-step binary search) and written as one or two *events*
-//               (admit / drop) directly at their position in the time-ordered event stream of the locus -- the merge
-//               of the two monotone streams is a binary search per record, so this kernel is fully parallel;
-//   k_l2_scan   one lane per locus: the sequential slide is now a fixed-trip loop over the event stream (one 16-byte
-//               load per 8 events), with cnt[] / the matched bitmap in lane-interleaved LDS.
-// Event layout: rank | found | drop | skip | eval.  `skip` = the duplicate-linking rule says the set does not change;
-// `eval` = last event of its window position, i.e. the point where the reference compares sharedSketchElements.
+// The work is split into two launches so that nothing slow sits on the sequential chain:
+//   k_l2_events one workgroup per fragment.  Prologue, one lane per locus: searchIndex(rangeStart) as a bounded binary
+//               search, the other two searchIndex() calls as rec_fwd lookups, the event count; the workgroup reserves
+//               its slice of the event buffer with one atomicAdd (the order of fragments is irrelevant).  Then one
+//               wave per locus: every reference record is reduced to its rank in the query sketch (bucket table + 2-3
+//               LDS probes, sketch staged once per fragment) and written as one or two *events* (admit / drop) at
+//               its position in the time-ordered event stream, which is plain arithmetic on rec_bwd / rec_fwd;
+//   k_l2_scan   one lane per locus: the sequential slide is a fixed-trip, branch-free loop over the event stream (one
+//               16-byte load per 8 events), with the per-rank state in lane-interleaved LDS.
+// `eval` marks the last event of a window position, i.e. the point where the reference compares
+// sharedSketchElements; events that are no-ops by the duplicate-linking rule carry zero deltas.
 struct L2Args {
   IndexView ix;
   const uint32_t *q_hash;
@@ -533,8 +550,11 @@ struct L2Args {
   int32_t frag_len;
   int32_t *l_beg, *l_end0, *l_last;  // record range of the locus, end of the first super-window
   int32_t *l_ndrop;                  // records dropped before the slide ends
-  uint32_t *l_items;                 // [loci + 1] events of the locus rounded up to a multiple of 8
-  const uint32_t *l_ioff;            // exclusive scan of l_items
+  uint32_t *l_nev;                   // [loci] events of the locus rounded up to a multiple of 8
+  uint32_t *l_ioff;                  // [loci] first event of the locus in `items`
+  unsigned long long *pinfo;         // [0] events reserved so far, [1] speculation flags
+  uint64_t items_cap;                // capacity of `items` in events
+  int32_t l_cap;                     // capacity of the loci arrays
   void *items;                       // uint16 or uint32 per event
   int32_t *l_shared, *l_pos;
   const int32_t *pass_lut;           // [smax+1]
@@ -564,29 +584,6 @@ __device__ __forceinline__ uint32_t ev_word(int rank_bits, int slot, int dM, int
          ((drop ? 1u : 0u) << (rank_bits + 4)) | ((eval ? 1u : 0u) << (rank_bits + 5));
 }
 
-__global__ void k_l2_prep(L2Args a) {
-  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nloci = a.counters[0];
-  if (l > nloci) return;
-  if (l == nloci) { a.l_items[l] = 0; return; }
-  const int lo = a.ix.contig_rec[a.l_seq[l]];
-  const int32_t *wpos = a.ix.rec_wpos;
-  // searchIndex(seqId, rangeStartPos): rangeStartPos <= wpos of the first seed and wpos is strictly increasing, so the
-  // answer lies within fragment_length records before that seed
-  const int rfirst = a.l_rfirst[l], target = a.l_start[l];
-  int x = max(lo, rfirst - a.frag_len), y = rfirst;
-  while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
-  const int beg = x;
-  const int end0 = a.ix.rec_fwd[beg];                  // searchIndex(seqId, first wpos + countMinimizerWindows)
-  const int last = a.ix.rec_fwd[a.l_rlast[l]];         // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
-  // the slide stops at the window position where the last record is admitted; the records dropped by then are the
-  // ones before the record active at that position
-  const int ndrop = last > end0 ? a.ix.rec_bwd[last - 1] - beg : 0;
-  a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last; a.l_ndrop[l] = ndrop;
-  a.l_items[l] = (uint32_t)((last - beg + ndrop + 7) & ~7);
-  atomicAdd(a.rec_total, (unsigned long long)(last - beg));
-}
-
 template <typename T>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
@@ -597,7 +594,58 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   if (l_n == 0) return;
   const int s = a.q_size[f];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (a.counters[2] || s > a.cnt_slots - 1) return;                  // loci overflowed / sketch larger than speculated: void pass
   for (int i = threadIdx.x; i < s; i += EV_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  // ---- record range of every locus (the three searchIndex calls of computeL2MappedRegions) and its event count ----
+  __shared__ uint32_t sh_wave[EV_THREADS / 64];
+  __shared__ uint32_t sh_run, sh_base, sh_ok;
+  __shared__ unsigned long long sh_records;
+  if (threadIdx.x == 0) { sh_run = 0; sh_records = 0; }
+  __syncthreads();
+  const int32_t *wpos = a.ix.rec_wpos;
+  for (uint32_t c0 = 0; c0 < l_n; c0 += EV_THREADS) {
+    const uint32_t l = l_lo + c0 + threadIdx.x;
+    uint32_t nev = 0, records = 0;
+    if (c0 + threadIdx.x < l_n) {
+      const int lo = a.ix.contig_rec[a.l_seq[l]];
+      // searchIndex(seqId, rangeStartPos): rangeStartPos <= wpos of the first seed and wpos is strictly increasing, so
+      // the answer lies within fragment_length records before that seed
+      const int rfirst = a.l_rfirst[l], target = a.l_start[l];
+      int x = max(lo, rfirst - a.frag_len), y = rfirst;
+      while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+      const int beg = x;
+      const int end0 = a.ix.rec_fwd[beg];                  // searchIndex(seqId, first wpos + countMinimizerWindows)
+      const int last = a.ix.rec_fwd[a.l_rlast[l]];         // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
+      // the slide stops at the window position where the last record is admitted; the records dropped by then are
+      // the ones before the record active at that position
+      const int ndrop = last > end0 ? a.ix.rec_bwd[last - 1] - beg : 0;
+      a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last; a.l_ndrop[l] = ndrop;
+      nev = (uint32_t)((last - beg + ndrop + 7) & ~7);
+      records = (uint32_t)(last - beg);
+      a.l_nev[l] = nev;
+    }
+    // exclusive scan of the event counts inside the workgroup
+    uint32_t incl = nev;
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) sh_wave[wv] = incl;
+    uint32_t rsum = records;
+    for (int d = 32; d > 0; d >>= 1) rsum += __shfl_down(rsum, d);
+    if (lane == 0) atomicAdd(&sh_records, (unsigned long long)rsum);
+    __syncthreads();
+    uint32_t off = sh_run + incl - nev;
+    for (int q = 0; q < wv; q++) off += sh_wave[q];
+    if (c0 + threadIdx.x < l_n) a.l_ioff[l] = off;           // relative to the fragment for now
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t tot = 0; for (int q = 0; q < EV_THREADS / 64; q++) tot += sh_wave[q]; sh_run += tot; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long base = atomicAdd(&a.pinfo[0], (unsigned long long)sh_run);   // order of fragments is irrelevant
+    sh_ok = base + sh_run <= a.items_cap;
+    if (!sh_ok) atomicOr(&a.pinfo[1], (unsigned long long)SPEC_EVENTS);
+    sh_base = (uint32_t)base;
+    atomicAdd(a.rec_total, sh_records);
+  }
   __syncthreads();
   // bucket table over the top 8 hash bits: QT[b] = first query rank whose hash is >= b << 24
   for (int b = threadIdx.x; b <= 256; b += EV_THREADS) {
@@ -607,13 +655,20 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     QT[b] = (uint16_t)x;
   }
   __syncthreads();
+  if (!sh_ok) {                                                      // the event buffer is too small: void pass
+    for (uint32_t i = threadIdx.x; i < l_n; i += EV_THREADS) a.l_nev[l_lo + i] = 0;
+    return;
+  }
   // the waves of the workgroup take the loci of the fragment round-robin
   for (uint32_t l = l_lo + wv; l < l_lo + l_n; l += EV_THREADS / 64) {
     const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
     const int n_init = end0 - beg;
     const uint32_t total = (uint32_t)(last - beg + ndrop);
     const uint32_t padded = (total + 7u) & ~7u;
-    T *gout = (T *)a.items + a.l_ioff[l];
+    const uint32_t ioff = sh_base + a.l_ioff[l];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) a.l_ioff[l] = ioff;                               // absolute, for k_l2_scan
+    T *gout = (T *)a.items + ioff;
     // events land at scattered 2-byte positions: build the stream of a locus in LDS and stream it out in 16-byte
     // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
     const bool staged = padded <= (uint32_t)a.ev_stage;
@@ -686,12 +741,13 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   const int lane = threadIdx.x;
   if (lane >= LN) return;
   const uint32_t l = blockIdx.x * LN + lane;
-  if (l >= a.counters[0]) return;
+  if (a.counters[2] || l >= a.counters[0]) return;
   if (REDO) { if (!a.l_redo[l]) return; }
   else a.l_redo[l] = 0;
   const int s = a.q_size[a.l_frag[l]];
+  if (s + 1 > a.cnt_slots) return;                                  // SPEC_SMAX was raised: void pass
   const int beg0 = a.l_beg[l];
-  const uint32_t nev = a.l_ioff[l + 1] - a.l_ioff[l];               // multiple of 8
+  const uint32_t nev = a.l_nev[l];                                  // multiple of 8
   constexpr int PER = 16 / sizeof(T);                               // events per 16-byte load
   const uint4 *ev = (const uint4 *)((const T *)a.items + a.l_ioff[l]);
   constexpr int RB = EvBits<T>::RANK;
@@ -778,7 +834,7 @@ struct CgiArgs {
 
 __global__ void k_cgi_bins(CgiArgs a) {
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= a.counters[1]) return;
+  if (a.counters[2] || g >= a.counters[1]) return;
   unsigned long long best = a.group_best[g];
   if (best == 0) return;
   uint32_t l = 0xFFFFFFFFu - (uint32_t)(best & 0xFFFFFFFFu);

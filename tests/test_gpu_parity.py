@@ -456,8 +456,9 @@ def test_seed_overflow_to_hbm_scratch():
     assert hit_tuples(hits) == ohits
 
 
-def test_loci_capacity_retry():
-    # forces the first guess of the loci capacity below the real number so that k_l1 reports overflow and is re-run
+def test_speculated_capacities_retry():
+    # forces the speculated loci / event capacities below the real numbers: the device raises a flag, the pass is void
+    # and is run again with larger buffers (sketch-size and scratch speculation are exercised by the other tests)
     import textwrap
     code = textwrap.dedent("""
         import sys, warnings
@@ -477,6 +478,8 @@ def test_loci_capacity_retry():
         print("OK")
     """ % ROOT)
     _run_child(code, {"FA_LOCI_CAP_MIN": "7"})
+    _run_child(code, {"FA_EVENTS_CAP_MIN": "1000"})          # same for the slide-event buffer
+    _run_child(code, {"FA_LOCI_CAP_MIN": "3", "FA_EVENTS_CAP_MIN": "64"})
 
 
 def test_long_locus_and_reference_exceptions():
