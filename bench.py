@@ -146,10 +146,10 @@ def main():
         # every reference record inside a locus range is one 12-byte MinimizerInfo of the reference's layout
         l2_bytes = l2_records * 12.0
         l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
-        l2_name = "k_l2_prep+k_l2_events+k_l2_scan"
+        l2_name = "k_l2_events+k_l2_scan"
         dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
         roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
-        traffic = profiled_traffic(["k_l2_prep", "k_l2_events<unsigned short>", "k_l2_scan<unsigned short, unsigned char, 64>"]
+        traffic = profiled_traffic(["k_l2_events<unsigned short>", "k_l2_scan<unsigned short, unsigned char, 64>"]
                                    if dominant == l2_name else ["k_sketch_tiles<16>"]) if args.batch == 1 and args.refs == 100 else None
         result = {
             "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
