@@ -501,3 +501,70 @@ def test_long_locus_and_reference_exceptions():
     assert ms[7] / max(ms[6], 1) > 2048, "expected loci with more than 2048 slide events"
     assert gpu_mappings(mapper) == oracle_mappings(det) and len(ohits) == 2
     assert hit_tuples(hits) == ohits
+
+
+def test_degenerate_and_unusual_parameter_cells():
+    g = syn.rng(98)
+    anc = syn.random_codes(g, 60_000)
+    refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.01, 0.06)]
+    query = [syn.to_ascii(syn.mutate_codes(g, anc, 0.03))]
+    # (k=21, fragment_length=1000): recommendedWindowSize returns the fragment length itself, no fragment holds a full
+    # window, nothing maps -- must be handled without error on both sides
+    mapper, hits, ohits, det = run_both({"k": 21, "fragment_length": 1000}, refs, query)
+    assert mapper.window_size == 1000 and hits == [] and ohits == []
+    # short fragments and a small k
+    for params in ({"k": 11, "fragment_length": 500}, {"k": 16, "fragment_length": 333}, {"k": 24, "fragment_length": 2000}):
+        mapper, hits, ohits, det = run_both(params, refs, query)
+        assert gpu_mappings(mapper) == oracle_mappings(det), params
+        assert hit_tuples(hits) == ohits, params
+    with pytest.raises(NotImplementedError):
+        quiet_sketch(pf.Sketch, fragment_length=20).add_genome("r", refs[0][0]).index().query_genome(query[0])
+
+
+def test_protein_small_k_and_wide_strings(golden_dir):
+    b1 = read_fasta(os.path.join(golden_dir, "BGC0001425.faa"))
+    b2 = read_fasta(os.path.join(golden_dir, "BGC0001427.faa"))
+    b3 = read_fasta(os.path.join(golden_dir, "BGC0001428.faa"))
+    for k, frag in ((5, 60), (9, 150)):
+        sk, osk = pf.Sketch(k=k, fragment_length=frag, protein=True), OracleSketch(k=k, fragment_length=frag, protein=True)
+        for name, prots in (("a", b1), ("b", b2)):
+            sk.add_draft(name, prots)
+            osk.add_draft(name, prots)
+        m = sk.index()
+        osk.index()
+        assert len(m.lookup_index) == osk.index_size
+        assert hit_tuples(m.query_draft(b3)) == osk.query_draft(b3)
+    # UCS2 / UCS4 str carriers read the same characters (_fastani.pyx:144-148)
+    g = syn.rng(99)
+    ref = bytes(syn.to_ascii(syn.random_codes(g, 30_000))).decode()
+    sk = pf.Sketch()
+    sk.add_genome("r", ref)
+    m = sk.index()
+    want = hit_tuples(m.query_genome(ref))
+    assert want == [("r", 100.0, 10, 10)]
+    wide = ref[:12_000] + "\u0394" + ref[12_001:]          # one non-Latin-1 character forces the UCS2 representation
+    wide4 = ref[:12_000] + "\U0001F9EC" + ref[12_001:]     # UCS4
+    for q in (wide, wide4):
+        got = m.query_genome(q)
+        assert len(got) == 1 and got[0].matches >= 9
+
+
+def test_sharding_all_vs_all_single_rank():
+    from pyfastani_amd import sharding
+    g = syn.rng(100)
+    anc = syn.random_codes(g, 90_000)
+    genomes = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.0, 0.02, 0.05)] + [[syn.to_ascii(syn.random_codes(g, 90_000))]]
+    sk = pf.Sketch()
+    for i, c in enumerate(genomes):
+        sk.add_draft(i, c)
+    mapper = sk.index()
+    rows = sharding.all_vs_all(mapper, genomes, rank=0, world_size=1)
+    pairs = {(int(r["query_id"]), int(r["ref_genome_id"])) for r in rows if r["count_seq"] >= 6}
+    assert pairs == {(a, b) for a in range(3) for b in range(3)} | {(3, 3)}
+    # the strided shard of a 2-rank job sees exactly its own queries
+    rows0 = sharding.all_vs_all(mapper, genomes, rank=0, world_size=1)
+    assert rows0.tobytes() == rows.tobytes()
+    owned = sharding.shard_indices(len(genomes), 1, 2)
+    batch = mapper.upload_genomes([genomes[i] for i in owned])
+    part = sharding.remap_query_ids(batch.query_rows(), owned)
+    assert sorted(map(tuple, part.tolist())) == sorted(t for t in map(tuple, rows.tolist()) if t[0] in owned)
