@@ -531,8 +531,9 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.lds_seed_cap = sp.seed_slots; a.pinfo = m.pinfo.p; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
       const size_t lds = (size_t)sp.seed_slots * 4;
-      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_l1, dim3((unsigned)F), dim3(MAP_THREADS), lds, st, a);
+      constexpr int L1_THREADS = 256;   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
+      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(k_l1<L1_THREADS>, dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
     }
     debug_sync(st, "l1");
     FA_HIP(hipEventRecord(m.ev[2], st));

@@ -368,9 +368,11 @@ struct L1Args {
   uint32_t lds_seed_cap;
 };
 
-__global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
+// NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  __shared__ uint32_t sh_scan[MAP_THREADS / 64];
+  __shared__ uint32_t sh_scan[NT / 64];
   __shared__ uint32_t sh_run;       // running offset (gather) / running head count
   __shared__ int sh_prev_seq, sh_prev_wa, sh_has_prev;
   __shared__ uint32_t sh_base, sh_gbase;
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       for (uint32_t t = 0; t < cnt; t++) seeds[off + t] = a.ix.pos_ridx[src + t];
     }
     __syncthreads();
-    if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+    if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
     __syncthreads();
   }
   for (uint32_t i = n + tid; i < n32; i += blockDim.x) seeds[i] = SEED_PAD;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       }
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
-      __shared__ int w_last_seq[MAP_THREADS / 64], w_last_wa[MAP_THREADS / 64], w_any[MAP_THREADS / 64];
+      __shared__ int w_last_seq[NT / 64], w_last_wa[NT / 64], w_any[NT / 64];
       uint64_t below = bal & ((1ULL << lane) - 1ULL);
       int src_lane = below ? 63 - __clzll(below) : -1;
       int p_seq = __shfl(seq, src_lane < 0 ? 0 : src_lane), p_wa = __shfl(wa, src_lane < 0 ? 0 : src_lane);
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       bool head = flag && !(has_prev && p_seq == seq && p_wa >= start);
       // inclusive scan of heads -> slot of the locus every flagged candidate belongs to
       uint64_t hb = __ballot(head);
-      __shared__ uint32_t w_heads[MAP_THREADS / 64];
+      __shared__ uint32_t w_heads[NT / 64];
       if (lane == 0) w_heads[wv] = __popcll(hb);
       __syncthreads();
       uint32_t slot = sh_run + __popcll(hb & ((2ULL << lane) - 1ULL));
@@ -468,9 +470,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_l1(L1Args a) {
       __syncthreads();
       if (tid == 0) {
         uint32_t tot = 0;
-        for (int q = 0; q < MAP_THREADS / 64; q++) tot += w_heads[q];
+        for (int q = 0; q < NT / 64; q++) tot += w_heads[q];
         sh_run += tot;
-        for (int q = MAP_THREADS / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_seq = w_last_seq[q]; sh_prev_wa = w_last_wa[q]; break; }
+        for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_seq = w_last_seq[q]; sh_prev_wa = w_last_wa[q]; break; }
       }
       __syncthreads();
     }
