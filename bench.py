@@ -103,7 +103,7 @@ def main():
     def step():
         n = batch.query_rows_device(0, args.batch, rows.data_ptr(), rows.shape[0])
         if world > 1:
-            return sharding.all_gather_rows(rows[:n].cpu() if share_gpu else rows[:n])
+            return sharding.all_gather_rows(rows[:n].cpu() if share_gpu else rows[:n], max_rows=n_pairs_step)
         return rows[:n]
 
     def fence():

@@ -29,23 +29,39 @@ def tensor_to_rows(t):
     return a.reshape(-1).view(ROW_DTYPE)
 
 
-def all_gather_rows(local, group=None):
+def all_gather_rows(local, group=None, max_rows=None):
     """All-gather a variable number of rows per rank.
 
     ``local`` is an int32 tensor [n_local, 5] on the device the process group communicates on (HBM for nccl).
     Returns an int32 tensor [sum n, 5] holding the rows of rank 0, 1, ... in order.
+
+    With ``max_rows`` (an upper bound on the rows of any rank, e.g. queries x references) the exchange is ONE
+    collective on a fixed-size buffer whose first row carries the count; without it the counts are gathered first
+    and the payload is padded to the largest count (two collectives).
     """
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
-    counts = [torch.zeros_like(n_local) for _ in range(world)]
-    dist.all_gather(counts, n_local, group=group)
+    n_local = int(local.shape[0])
+    if max_rows is not None:
+        if n_local > max_rows:
+            raise ValueError(f"{n_local} rows exceed max_rows={max_rows}")
+        buf = torch.zeros((max_rows + 1, 5), dtype=torch.int32, device=local.device)
+        buf[0, 0] = n_local
+        buf[1: n_local + 1] = local
+        out = torch.empty((world * (max_rows + 1), 5), dtype=torch.int32, device=local.device)
+        dist.all_gather_into_tensor(out, buf, group=group)
+        out = out.view(world, max_rows + 1, 5)
+        counts = out[:, 0, 0].tolist()
+        return torch.cat([out[r, 1: counts[r] + 1] for r in range(world)], dim=0)
+    n = torch.tensor([n_local], dtype=torch.int64, device=local.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
     counts = [int(c.item()) for c in counts]
     n_max = max(max(counts), 1)
     padded = torch.zeros((n_max, 5), dtype=torch.int32, device=local.device)
-    padded[: local.shape[0]] = local
+    padded[:n_local] = local
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded, group=group)
     return torch.cat([g[:c] for g, c in zip(gathered, counts)], dim=0)

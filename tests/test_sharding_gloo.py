@@ -52,6 +52,8 @@ WORKER = textwrap.dedent("""
     rows = np.array(rows, dtype=ROW_DTYPE) if rows else np.zeros(0, ROW_DTYPE)
     rows = sharding.remap_query_ids(rows, owned)
     out = sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows)))
+    one = sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows), max_rows=16))   # single-collective form
+    assert one.tobytes() == out.tobytes()
     out = out[np.lexsort((out["ref_genome_id"], out["query_id"]))]
     want = [(q, r, 10 + q, 100, 90.0 + q) for q in range(7) for r in ([q % 3] + ([q % 3 + 1] if q % 2 == 0 else []))]
     assert out.tolist() == [tuple(w) for w in np.array(want, dtype=ROW_DTYPE).tolist()], (rank, out.tolist())
