@@ -418,6 +418,25 @@ static uint64_t env_u64(const char *name, uint64_t dflt) {
   return x > 0 ? (uint64_t)x : dflt;
 }
 
+// zero several device ranges with one launch (every DevBuf is at least 16-byte aligned; sizes are rounded up to 16 bytes,
+// which stays inside the allocation because ensure() callers below add slack)
+struct ClearList {
+  ClearArgs a;
+  ClearList() { a.count = 0; }
+  void add(void *p, size_t bytes) {
+    if (!bytes) return;
+    a.ptr[a.count] = (uint4 *)p; a.n16[a.count] = (bytes + 15) / 16; a.count++;
+  }
+  void launch(hipStream_t st) {
+    if (!a.count) return;
+    uint64_t most = 0;
+    for (int i = 0; i < a.count; i++) most = std::max(most, a.n16[i]);
+    int blocks = (int)std::min<uint64_t>(2048, std::max<uint64_t>(1, (most + 255) / 256));
+    hipLaunchKernelGGL(k_clear, dim3(blocks), dim3(256), 0, st, a);
+    a.count = 0;
+  }
+};
+
 // FA_DEBUG_SYNC=1: synchronise after every stage of a query pass and name the stage that failed
 static void debug_sync(hipStream_t st, const char *stage) {
   static const bool on = getenv("FA_DEBUG_SYNC") != nullptr;
@@ -462,8 +481,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
   m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
   m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
-  m.stats_dev.ensure(4); m.totals.ensure(4); m.counters.ensure(4); m.pinfo.ensure(4);
-  m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1));
+  m.stats_dev.ensure(8); m.totals.ensure(8); m.counters.ensure(8); m.pinfo.ensure(8);
+  m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1) + 2);
   m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
   m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
   const size_t qs_lds = (size_t)next_pow2((uint32_t)std::max(qcap, 2)) * 4;
@@ -477,10 +496,10 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
     ensure_luts(m, smax);
     const int64_t l_cap = sp.l_cap;
-    m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap);
-    m.l_rfirst.ensure((size_t)l_cap); m.l_rlast.ensure((size_t)l_cap);
+    m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap + 4);
+    m.l_rfirst.ensure((size_t)l_cap); m.l_rlast.ensure((size_t)l_cap + 4);
     m.l_group.ensure((size_t)l_cap); m.l_shared.ensure((size_t)l_cap); m.l_pos.ensure((size_t)l_cap);
-    m.group_best.ensure((size_t)l_cap);
+    m.group_best.ensure((size_t)l_cap + 2);
     m.l_beg.ensure((size_t)l_cap); m.l_end0.ensure((size_t)l_cap); m.l_last.ensure((size_t)l_cap); m.l_ndrop.ensure((size_t)l_cap);
     m.l_nev.ensure((size_t)l_cap); m.l_ioff.ensure((size_t)l_cap); m.l_redo.ensure((size_t)l_cap + 4);
     m.ovf_buf.ensure((size_t)sp.scratch_words + 4);
@@ -488,10 +507,15 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
 
     FA_HIP(hipEventRecord(m.ev[0], st));
-    FA_HIP(hipMemsetAsync(m.stats_dev.p, 0, 4 * sizeof(int32_t), st));
-    FA_HIP(hipMemsetAsync(m.totals.p, 0, 4 * sizeof(uint64_t), st));
-    FA_HIP(hipMemsetAsync(m.counters.p, 0, 4 * sizeof(uint32_t), st));
-    FA_HIP(hipMemsetAsync(m.pinfo.p, 0, 4 * sizeof(unsigned long long), st));
+    {
+      ClearList cl;
+      cl.add(m.stats_dev.p, 4 * sizeof(int32_t)); cl.add(m.totals.p, 4 * sizeof(uint64_t));
+      cl.add(m.counters.p, 4 * sizeof(uint32_t)); cl.add(m.pinfo.p, 4 * sizeof(unsigned long long));
+      cl.add(m.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(m.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
+      cl.add(m.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
+      if (npairs > 0) cl.add(m.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
+      cl.launch(st);
+    }
     // ---- K1 + per-fragment sort/unique ----
     launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, m.sk.stage_hash.p, m.sk.stage_wpos.p, m.sk.tile_count.p, st);
     {
@@ -518,9 +542,6 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     }
     debug_sync(st, "lookup");
     // ---- L1 ----
-    FA_HIP(hipMemsetAsync(m.l_end.p, 0, (size_t)l_cap * sizeof(int32_t), st));
-    FA_HIP(hipMemsetAsync(m.l_rlast.p, 0, (size_t)l_cap * sizeof(int32_t), st));
-    FA_HIP(hipMemsetAsync(m.group_best.p, 0, (size_t)l_cap * sizeof(unsigned long long), st));
     {
       L1Args a;
       a.ix = ix; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p; a.n_seeds = m.n_seeds.p;
@@ -595,7 +616,6 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     // ---- core-genome identity ----
     int32_t total_rows = 0;
     if (npairs > 0) {
-      FA_HIP(hipMemsetAsync(m.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
       CgiArgs a;
       a.ix = ix; a.group_best = m.group_best.p; a.counters = m.counters.p; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
       a.l_pos = m.l_pos.p; a.q_size = m.q_size.p; a.ident_lut = m.d_ident.p;
@@ -605,12 +625,18 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
       hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
                          m.row_count.p, m.row_ident.p);
-      hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
-      FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
-      exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
-      FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
-                         npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
+      if (npairs <= 16384) {
+        hipLaunchKernelGGL(k_emit_rows_small, dim3(1), dim3(1024), 0, st, m.row_count.p, m.row_ident.p, m.G, (int)npairs,
+                           g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base, m.row_off.p);
+        FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      } else {
+        hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
+        FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
+        exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
+        FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
+                           npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
+      }
     }
     FA_HIP(hipGetLastError());
     debug_sync(st, "cgi");

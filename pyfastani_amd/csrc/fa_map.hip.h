@@ -901,4 +901,50 @@ __global__ void k_flag_nonzero(const int32_t *row_count, int64_t n, int32_t *fla
   if (i < n) flag[i] = row_count[i] != 0;
 }
 
+
+// One launch instead of a dozen hipMemsetAsync calls: zero up to 8 device ranges (sizes in 16-byte units).
+struct ClearArgs {
+  uint4 *ptr[8];
+  uint64_t n16[8];
+  int count;
+};
+__global__ __launch_bounds__(256) void k_clear(ClearArgs a) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (int r = 0; r < a.count; r++)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n16[r]; i += stride) a.ptr[r][i] = make_uint4(0, 0, 0, 0);
+}
+
+// Rows of a small pass (one workgroup): flag the non-empty (query, genome) pairs, scan, emit -- in (query, genome) order.
+__global__ __launch_bounds__(1024) void k_emit_rows_small(const int32_t *row_count, const float *row_ident, int G, int n,
+                                                          const int32_t *query_total_frag, int32_t query_id_base, fa_cgi_row *rows,
+                                                          int64_t cap, int32_t *total_rows) {
+  __shared__ int sh_wave[16];
+  __shared__ int sh_run;
+  if (threadIdx.x == 0) sh_run = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int i0 = 0; i0 < n; i0 += 1024) {
+    const int i = i0 + threadIdx.x;
+    const bool keep = i < n && row_count[i] != 0;
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) sh_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = sh_run + __popcll(bal & ((1ULL << lane) - 1ULL));
+    for (int q = 0; q < wv; q++) off += sh_wave[q];
+    if (keep && off < cap) {
+      fa_cgi_row r;
+      r.query_id = query_id_base + i / G;
+      r.ref_genome_id = i % G;
+      r.count_seq = row_count[i];
+      r.total_query_fragments = query_total_frag[i / G];
+      r.identity = row_ident[i];
+      rows[off] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { int tot = 0; for (int q = 0; q < 16; q++) tot += sh_wave[q]; sh_run += tot; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_rows = sh_run;
+}
+
 }  // namespace fa
