@@ -521,9 +521,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     {
       QuerySketchArgs a;
       a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
-      a.tile_count = m.sk.tile_count.p - t0;       // indexed by global tile number
-      a.stage_hash = m.sk.stage_hash.p - (size_t)t0 * TILE;
-      a.stage_wpos = m.sk.stage_wpos.p - (size_t)t0 * TILE;
+      a.tile_count = m.sk.tile_count.p; a.stage_hash = m.sk.stage_hash.p; a.stage_wpos = m.sk.stage_wpos.p;
+      a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
       a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = m.stats_dev.p; a.qcap = qcap;
       a.sort_cap = (int32_t)(qs_lds / 4);
       if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));

@@ -61,6 +61,7 @@ struct QuerySketchArgs {
   int32_t *stats;               // [0] max sketch size
   int32_t qcap;
   int32_t sort_cap;             // power of two >= max records of a fragment
+  int32_t tile_base;            // first tile of this pass (staging is indexed pass-locally)
 };
 
 __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   __shared__ uint32_t sh_h0;
   __shared__ int sh_wpos0;
   const int f = blockIdx.x, tid = threadIdx.x;
-  const int t0 = a.frag_tile_lo[f], t1 = a.frag_tile_lo[f + 1];
+  const int t0 = a.frag_tile_lo[f] - a.tile_base, t1 = a.frag_tile_lo[f + 1] - a.tile_base;
   // gather in order
   int n = 0;
   for (int t = t0; t < t1; t++) {
