@@ -550,7 +550,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = sp.seed_slots; a.pinfo = m.pinfo.p; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
-      const size_t lds = (size_t)sp.seed_slots * 4;
+      const size_t lds = (size_t)sp.seed_slots * 4 + (size_t)L1_STAGE * 5 * 4;   // seed buffer + the loci staged per fragment
       constexpr int L1_THREADS = 256;   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
       if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_l1<L1_THREADS>, dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);

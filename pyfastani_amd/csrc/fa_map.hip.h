@@ -26,6 +26,7 @@
 namespace fa {
 
 constexpr int MAP_THREADS = 256;
+constexpr int L1_STAGE = 512;     // loci of one fragment merged in LDS by k_l1 (more fall back to a second pass)
 constexpr uint32_t SEED_PAD = 0xFFFFFFFFu;
 
 // ----------------------------------------------------------------------------------------------------------
@@ -419,24 +420,25 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   const uint32_t ncand = n - (uint32_t)m + 1;
   const int len = a.frag_len;
 
-  // ---- two ordered passes over the candidates: 0 = count merged loci, 1 = write them ----
+  // ---- ordered passes over the candidates.  Pass 0 merges them into loci held in LDS (up to L1_STAGE per fragment) and
+  //      is normally the only one; if a fragment has more loci, pass 0 only counted and pass 1 writes them to HBM. ----
+  int32_t *st_seq = (int32_t *)(lds + (size_t)a.lds_seed_cap * 4);       // [L1_STAGE] each
+  int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
+  for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
+  bool staged = true;
   for (int pass = 0; pass < 2; pass++) {
     if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < ncand; i0 += blockDim.x) {
+    for (uint32_t i0 = 0; i0 < ncand; i0 += NT) {
       uint32_t i = i0 + tid;
       bool flag = false;
       int seq = -1, wa = 0, start = 0;
       uint32_t ra = 0;
-      if (i < ncand) {
-        ra = seeds[i];
-        uint32_t rb = seeds[i + m - 1];
-        seq = a.ix.rec_seq[ra];
-        int seqb = a.ix.rec_seq[rb];
-        wa = a.ix.rec_wpos[ra];
-        int wb = a.ix.rec_wpos[rb];
-        if (seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
-      }
+      // every lane fetches (contig, window) of its own seed once; the partner seed i+m-1 comes from a neighbour lane
+      if (i < n) { ra = seeds[i]; seq = a.ix.rec_seq[ra]; wa = a.ix.rec_wpos[ra]; }
+      int seqb = __shfl(seq, (lane + m - 1) & 63), wb = __shfl(wa, (lane + m - 1) & 63);
+      if (lane + m - 1 >= 64 && i < ncand) { const uint32_t rb = seeds[i + m - 1]; seqb = a.ix.rec_seq[rb]; wb = a.ix.rec_wpos[rb]; }
+      if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
       __shared__ int w_last_seq[NT / 64], w_last_wa[NT / 64], w_any[NT / 64];
@@ -459,14 +461,21 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       __syncthreads();
       uint32_t slot = sh_run + __popcll(hb & ((2ULL << lane) - 1ULL));
       for (int q = 0; q < wv; q++) slot += w_heads[q];
-      if (pass == 1 && flag) {
-        uint32_t li = sh_base + slot - 1;
-        if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; a.l_rfirst[li] = (int32_t)ra; }
+      if (flag) {
         // the end of a locus is its last flagged seed; only the last flagged lane of a locus inside this wave
         // touches memory (same-address atomics from every lane would serialise)
         const uint64_t above = (lane == 63) ? 0ULL : (bal & ~((2ULL << lane) - 1ULL));
         const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
-        if (last_here) { atomicMax(&a.l_end[li], wa); atomicMax(&a.l_rlast[li], (int32_t)ra); }
+        if (pass == 0) {
+          if (slot <= (uint32_t)L1_STAGE) {
+            if (head) { st_seq[slot - 1] = seq; st_start[slot - 1] = start; st_rfirst[slot - 1] = (int32_t)ra; }
+            if (last_here) { atomicMax(&st_end[slot - 1], wa); atomicMax(&st_rlast[slot - 1], (int32_t)ra); }
+          }
+        } else {
+          uint32_t li = sh_base + slot - 1;
+          if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; a.l_rfirst[li] = (int32_t)ra; }
+          if (last_here) { atomicMax(&a.l_end[li], wa); atomicMax(&a.l_rlast[li], (int32_t)ra); }
+        }
       }
       __syncthreads();
       if (tid == 0) {
@@ -488,6 +497,16 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       }
       __syncthreads();
       if (sh_gbase == 0) return;
+      staged = sh_gbase <= (uint32_t)L1_STAGE;
+      if (staged) {
+        // the common case: copy the loci from LDS to their reserved place
+        for (uint32_t q = tid; q < sh_gbase; q += NT) {
+          const uint32_t li = sh_base + q;
+          a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
+          a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q];
+        }
+        break;
+      }
     }
   }
   // ---- groups: consecutive loci of this fragment on the same reference genome ----

@@ -444,14 +444,15 @@ def _run_child(code, env_extra):
 
 
 def test_seed_overflow_to_hbm_scratch():
-    # 200 copies of one small genome: every query minimizer hits 200 positions, so a fragment gathers ~48 000 seed
-    # hits -- more than the 32 768 that fit the LDS sort -- and takes the HBM scratch path of k_l1
+    # 560 copies of one small genome: every query minimizer hits 560 positions, so a fragment gathers ~130 000 seed
+    # hits -- more than the 32 768 that fit the LDS sort -- and takes the HBM scratch path of k_l1; its 560 loci also
+    # exceed the 512 that k_l1 merges in LDS, which exercises the second (write) pass
     g = syn.rng(95)
     base = syn.random_codes(g, 21_000)
-    refs = [[syn.to_ascii(base)] for _ in range(200)]
+    refs = [[syn.to_ascii(base)] for _ in range(560)]
     query = [syn.to_ascii(syn.mutate_codes(g, base, 0.01))]
     mapper, hits, ohits, det = run_both({}, refs, query, threads=8)
-    assert mapper.occurences_threshold == 2**31 - 1 and len(ohits) == 200
+    assert mapper.occurences_threshold == 2**31 - 1 and len(ohits) == 560
     assert gpu_mappings(mapper) == oracle_mappings(det)
     assert hit_tuples(hits) == ohits
 
