@@ -87,15 +87,15 @@ static void launch_sketch_tiles(const fa_params &P, const DevStore &store, const
   a.protein = P.alphabet_size != 4;
   a.npos_cap = TILE + 2 * P.window_size - 2;
   size_t lds = sketch_lds_bytes(P.kmer_size, P.window_size);
-  size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16);
+  size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 2 * 256 * 8);
   a.code_words = (int32_t)(image / 4);
-  if (P.kmer_size == 16) {
-    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_sketch_tiles<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sketch_tiles<16>, dim3(ntiles), dim3(SK_THREADS), lds, st, a);
-  } else {
-    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_sketch_tiles<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_sketch_tiles<0>, dim3(ntiles), dim3(SK_THREADS), lds, st, a);
-  }
+  auto launch = [&](auto kernel) {
+    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(SK_THREADS), lds, st, a);
+  };
+  // plain-ACGT tiles from the 2-bit image; protein tiles and tiles with other bytes through the byte image
+  if (!a.protein) { if (P.kmer_size == 16) launch(k_sketch_tiles<16, false>); else launch(k_sketch_tiles<0, false>); }
+  if (a.protein || store.n_exc > 0) launch(k_sketch_tiles<0, true>);
   FA_HIP(hipGetLastError());
 }
 

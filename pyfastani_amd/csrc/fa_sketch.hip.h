@@ -299,6 +299,35 @@ __device__ __forceinline__ bool hash_codes(const uint32_t *codes, int b, int k_r
   return hf != hb;
 }
 
+// k = 16 fast path.  The first multiply of each 8-byte half of the MurmurHash3 block is linear in the key bytes:
+// with A(g) the four ASCII bytes of the 8-bit code group g,  key*c = A(g0)*c + (A(g1)*c mod 2^32) << 32.
+// TC1[g] = A(g) * c1 and TC2[g] = A(g) * c2 (mod 2^64) sit in LDS (2 x 2 KiB, built once per workgroup), so the ASCII
+// bytes are never materialised and 4 of the 16 64-bit multiplies per base become two LDS reads and an add each.
+__device__ __forceinline__ uint64_t premix(const uint64_t *tab, uint32_t codes16) {
+  const uint64_t lo = tab[codes16 & 0xFFu];
+  const uint32_t hi = (uint32_t)tab[(codes16 >> 8) & 0xFFu];
+  return lo + ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint32_t murmur16_premixed(uint64_t k1c1, uint64_t k2c2) {
+  Murmur m;
+  m.init();
+  uint64_t k1 = Murmur::rotl(k1c1, 31) * 0x4cf5ad432745937fULL;
+  m.h1 ^= k1;
+  m.h1 = Murmur::rotl(m.h1, 27); m.h1 += m.h2; m.h1 = m.h1 * 5 + 0x52dce729;
+  uint64_t k2 = Murmur::rotl(k2c2, 33) * 0x87c37b91114253d5ULL;
+  m.h2 ^= k2;
+  m.h2 = Murmur::rotl(m.h2, 31); m.h2 += m.h1; m.h2 = m.h2 * 5 + 0x38495ab5;
+  return m.finish(16);
+}
+__device__ __forceinline__ bool hash_codes16(const uint32_t *codes, int b, const uint64_t *tc1, const uint64_t *tc2, uint32_t &out) {
+  const uint32_t cf = get16(codes, b);
+  const uint32_t cr = revcomp16(cf);
+  const uint32_t hf = murmur16_premixed(premix(tc1, cf & 0xFFFFu), premix(tc2, cf >> 16));
+  const uint32_t hb = murmur16_premixed(premix(tc1, cr & 0xFFFFu), premix(tc2, cr >> 16));
+  out = hf < hb ? hf : hb;
+  return hf != hb;
+}
+
 // scalar complement of an upper-cased byte: A<->T, C<->G, IUPAC pairs, everything else unchanged
 // (semantics of the reference's scalar table, src/pyfastani/_sequtils/complement.h)
 __device__ __forceinline__ uint32_t complement_byte(uint32_t c) {
@@ -359,14 +388,18 @@ inline size_t sketch_lds_bytes(int k, int w) {
   size_t span = npos_cap + (size_t)k - 1 + 64;            // bases (or bytes) staged, with slack for get16 over-read
   size_t image = ((span + 3) / 4 + 4) * 4;                // byte image is the larger of the two
   image = (image + 15) / 16 * 16;
-  return image + npos_cap * 16 + (npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16;
+  return image + npos_cap * 16 + (npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 2 * 256 * 8;
 }
 
-template <int KT>
-__global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(SketchArgs a) {
+// BYTES = false: tiles of plain ACGT, hashed from the 2-bit image (the hot kernel, kept free of the byte path so that it
+// fits 4+ waves per SIMD); BYTES = true: protein tiles and nucleotide tiles that contain other bytes.  Both are launched
+// over the same tile range and each skips the tiles of the other kind.
+template <int KT, bool BYTES>
+__global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(SketchArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Tile t = a.tiles[blockIdx.x];
+  if (BYTES ? (!a.protein && t.exc_n == 0) : (t.exc_n > 0)) return;
   const int k = KT ? KT : a.k, w = a.w;
 
   uint32_t *codes = (uint32_t *)lds;
@@ -376,17 +409,23 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(SketchArgs a) {
   uint64_t *valid = keyB + a.npos_cap;
   uint64_t *emit = valid + (a.npos_cap / 64 + 1);
   uint32_t *prefix = (uint32_t *)(emit + TILE / 64);
+  uint64_t *tc1 = (uint64_t *)(((uintptr_t)(prefix + TILE / 64 + 1) + 15) & ~(uintptr_t)15), *tc2 = tc1 + 256;
 
   const int hb = min(t.pos0, 2 * w - 2);          // halo of k-mer positions in front of the tile
   const int jlo = t.pos0 - hb;                    // first k-mer position computed (sequence-local)
   const int npt = hb + t.npos;                    // k-mer positions computed
   const int nb = npt + k - 1;                     // bases staged
   const int64_t base0 = t.base + jlo;             // store offset of the first staged base
-  const bool byte_mode = a.protein || t.exc_n > 0;
+  const bool byte_mode = BYTES;
   int shift = 0;
+  if (!BYTES && KT == 16 && tid < 256) {
+    const uint64_t A = expand4((uint32_t)tid);
+    tc1[tid] = A * 0x87c37b91114253d5ULL;
+    tc2[tid] = A * 0x4cf5ad432745937fULL;
+  }
 
   // ---- 1. stage the sequence image ----
-  if (a.protein) {
+  if (BYTES && a.protein) {
     for (int i = tid; i < nb; i += SK_THREADS) img[i] = a.bytes[base0 + i];
   } else {
     const int64_t w0 = base0 >> 4;
@@ -417,7 +456,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_sketch_tiles(SketchArgs a) {
     bool ok = false;
     uint32_t h = 0xFFFFFFFFu;
     if (j < npt) {
-      if (byte_mode) ok = hash_bytes(img, j, k, a.protein != 0, h);
+      if (BYTES) ok = hash_bytes(img, j, k, a.protein != 0, h);
+      else if (KT == 16) ok = hash_codes16(codes, shift + j, tc1, tc2, h);
       else ok = hash_codes<KT>(codes, shift + j, k, h);
     }
     uint64_t key = ok ? (((uint64_t)h << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)j)) : ~0ULL;
