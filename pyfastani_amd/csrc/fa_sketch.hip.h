@@ -36,7 +36,7 @@
 
 namespace fa {
 
-constexpr int TILE = 2048;         // k-mer positions per workgroup
+constexpr int TILE = 1024;         // k-mer positions per workgroup
 constexpr int SK_THREADS = 256;
 constexpr int SK_ITERS = TILE / SK_THREADS;
 
