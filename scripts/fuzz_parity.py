@@ -55,7 +55,38 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 g = syn.rng(seed)
 bad = 0
 t0 = time.time()
+AMINO = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+
+def protein_case(g, case):
+    k = int(g.choice([5, 7, 9, 12, 16])); frag = int(g.choice([60, 100, 150, 300]))
+    params = dict(k=k, fragment_length=frag, protein=True, minimum_fraction=float(g.choice([0.0, 0.2])))
+    sk, osk = pf.Sketch(**params), OracleSketch(**params)
+    n_prot = int(g.integers(3, 12))
+    anc = [g.integers(0, 20, int(g.integers(80, 900))) for _ in range(n_prot)]
+    def mutate(p, d):
+        p = p.copy(); m = g.random(len(p)) < d; p[m] = g.integers(0, 20, int(m.sum())); return p
+    for i in range(int(g.integers(1, 4))):
+        d = float(g.choice([0.0, 0.05, 0.15, 0.3]))
+        prots = [bytes(AMINO[mutate(p, d)]) for p in anc]
+        if g.random() < 0.3: prots.append(b"MK")
+        sk.add_draft(i, prots); osk.add_draft(i, prots)
+    mapper = sk.index(); osk.index()
+    query = [bytes(AMINO[mutate(p, 0.08)]).lower() if g.random() < 0.2 else bytes(AMINO[mutate(p, 0.08)]) for p in anc]
+    hits = [(h.name, h.identity, h.matches, h.fragments) for h in mapper.query_draft(query)]
+    ohits, det = osk.query_draft(query, threads=4, details=True)
+    om = det["mappings"]
+    omm = sorted(zip(om["qseq"].tolist(), om["rseq"].tolist(), om["rstart"].tolist(), om["sketch"].tolist(), om["shared"].tolist()))
+    ok = hits == ohits and mappings(mapper) == omm and len(mapper.lookup_index) == osk.index_size
+    if not ok:
+        print(f"MISMATCH protein case {case} seed {seed} params {params}: {hits} vs {ohits}")
+    return ok
+
 for case in range(cases):
+    if case % 10 == 9:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bad += 0 if protein_case(g, case) else 1
+        continue
     k = int(g.choice([8, 11, 12, 14, 16, 16, 16, 17, 21, 24]))
     frag = int(g.choice([200, 500, 1000, 1500, 3000, 3000, 5000]))
     pid = float(g.choice([70, 75, 80, 80, 85, 90, 95]))
@@ -79,8 +110,19 @@ for case in range(cases):
         if g.random() < 0.5:
             r = to_bytes(g, syn.random_codes(g, length)); sk.add_draft(n_ref, [r]); osk.add_draft(n_ref, [r])
         mapper = sk.index(); osk.index()
-        q = scramble(g, syn.mutate_codes(g, anc, float(g.choice([0.0, 0.02, 0.05, 0.1])))) if g.random() < 0.5 else syn.mutate_codes(g, anc, 0.03)
-        query = [to_bytes(g, x) for x in syn.split_contigs(g, q, int(g.integers(1, 4)))]
+        queries = []
+        for _ in range(int(g.integers(1, 4)) if case % 4 == 0 else 1):
+            q = scramble(g, syn.mutate_codes(g, anc, float(g.choice([0.0, 0.02, 0.05, 0.1])))) if g.random() < 0.5 else syn.mutate_codes(g, anc, 0.03)
+            queries.append([to_bytes(g, x) for x in syn.split_contigs(g, q, int(g.integers(1, 4)))])
+        if len(queries) > 1:
+            # the resident-batch API must give, per genome, what one query_draft call gives
+            got = [[(h.name, h.identity, h.matches, h.fragments) for h in hs] for hs in mapper.upload_genomes(queries).query()]
+            want = [osk.query_draft(q, threads=8) for q in queries]
+            if got != want:
+                bad += 1
+                print(f"MISMATCH batch case {case} seed {seed} params {params}: {got} vs {want}")
+            continue
+        query = queries[0]
         hits = [(h.name, h.identity, h.matches, h.fragments) for h in mapper.query_draft(query)]
         ohits, det = osk.query_draft(query, threads=8, details=True)
     om = det["mappings"]
