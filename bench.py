@@ -150,7 +150,7 @@ def main():
         dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
         roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
         traffic = profiled_traffic(["k_l2_events<unsigned short>", "k_l2_scan<unsigned short, unsigned char, 64>"]
-                                   if dominant == l2_name else ["k_sketch_tiles<16>"]) if args.batch == 1 and args.refs == 100 else None
+                                   if dominant == l2_name else ["k_sketch_tiles<16, false>"]) if args.batch == 1 and args.refs == 100 else None
         result = {
             "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
             "value": value,

@@ -4,11 +4,15 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
 
 #include "fa_common.h"
 #include "fa_map.hip.h"
@@ -76,6 +80,30 @@ struct SketchWork {
   DevBuf<unsigned char> cub_temp;
 };
 
+// FA_TRACE=1: wall-clock of the host-visible stages of sketching and index construction on stderr
+struct StageTrace {
+  bool on;
+  const char *what;
+  std::chrono::steady_clock::time_point t0, t;
+  std::vector<std::pair<std::string, double>> acc;
+  explicit StageTrace(const char *w) : on(getenv("FA_TRACE") != nullptr), what(w) { t0 = t = std::chrono::steady_clock::now(); }
+  void mark(const char *stage, hipStream_t st) {
+    if (!on) return;
+    (void)hipStreamSynchronize(st);
+    auto now = std::chrono::steady_clock::now();
+    double ms = std::chrono::duration<double, std::milli>(now - t).count();
+    t = now;
+    for (auto &a : acc) if (a.first == stage) { a.second += ms; return; }
+    acc.emplace_back(stage, ms);
+  }
+  ~StageTrace() {
+    if (!on) return;
+    fprintf(stderr, "[fa trace] %s: %.1f ms total;", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    for (auto &a : acc) fprintf(stderr, " %s %.1f", a.first.c_str(), a.second);
+    fprintf(stderr, "\n");
+  }
+};
+
 static void launch_sketch_tiles(const fa_params &P, const DevStore &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
                                 int32_t *stage_wpos, int32_t *tile_count, hipStream_t st) {
   if (ntiles <= 0) return;
@@ -135,8 +163,10 @@ struct fa_sketch {
     if (pending.seq_off.empty()) return;
     require_device();
     if (!stream) FA_HIP(hipStreamCreate(&stream));
+    StageTrace tr("sketch flush");
     DevStore store;
     store.upload(pending, stream);
+    tr.mark("upload", stream);
     const int64_t nseq_all = (int64_t)pending.seq_off.size();
     const int64_t chunk_positions = 96LL << 20;   // staging is 8 B per k-mer position: <= 768 MiB per chunk
     int64_t s0 = 0;
@@ -154,6 +184,7 @@ struct fa_sketch {
       }
       seq_tile_lo.push_back((int32_t)tiles.size());
       const int nseq = (int)(s1 - s0), ntiles = (int)tiles.size();
+      tr.mark("host_tiles", stream);
       if (ntiles > 0) {
         work.tiles.upload(tiles, stream);
         work.stage_hash.ensure((size_t)ntiles * TILE);
@@ -161,7 +192,9 @@ struct fa_sketch {
         work.tile_count.ensure(ntiles + 1);
         work.tile_off.ensure(ntiles + 1);
         FA_HIP(hipMemsetAsync(work.tile_count.p + ntiles, 0, sizeof(int32_t), stream));
+        tr.mark("alloc_tiles", stream);
         launch_sketch_tiles(P, store, work.tiles.p, ntiles, work.stage_hash.p, work.stage_wpos.p, work.tile_count.p, stream);
+        tr.mark("k_sketch", stream);
         d_seq_tile_lo.upload(seq_tile_lo, stream);
         d_seq_ids.upload(seq_ids, stream);
         d_drop.ensure(nseq + 1);
@@ -176,14 +209,17 @@ struct fa_sketch {
         FA_HIP(hipMemcpyAsync(&dropped, d_drop_off.p + nseq, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         FA_HIP(hipStreamSynchronize(stream));
         const int64_t nout = (int64_t)total - dropped;
+        tr.mark("scan", stream);
         rec_hash.ensure((size_t)(nrec + nout), true, stream, (size_t)nrec);
         rec_seq.ensure((size_t)(nrec + nout), true, stream, (size_t)nrec);
         rec_wpos.ensure((size_t)(nrec + nout), true, stream, (size_t)nrec);
+        tr.mark("grow", stream);
         hipLaunchKernelGGL(k_compact_records, dim3(ntiles), dim3(256), 0, stream, work.tiles.p, work.tile_count.p,
                            work.tile_off.p, d_seq_tile_lo.p, d_drop.p, d_drop_off.p, work.stage_hash.p, work.stage_wpos.p,
                            d_seq_ids.p, nrec, rec_hash.p, rec_seq.p, rec_wpos.p);
         FA_HIP(hipGetLastError());
         FA_HIP(hipStreamSynchronize(stream));
+        tr.mark("compact", stream);
         nrec += nout;
       }
       s0 = s1;
@@ -293,6 +329,7 @@ static void build_index(fa_mapper &m) {
   m.qcap = std::max(1, m.P.fragment_length - m.P.kmer_size + 1 - (m.P.window_size - 1));
   const int bin_len = m.P.fragment_length - 20;
   DevBuf<unsigned char> temp;
+  StageTrace tr("build_index");
   // contig tables
   std::vector<int32_t> cg((size_t)m.C + 1, 0);
   {
@@ -321,6 +358,7 @@ static void build_index(fa_mapper &m) {
     gb[g] = cb[std::min(c, m.C)];
   }
   m.genome_bin.upload(gb, st);
+  tr.mark("contigs", st);
 
   // hash-grouped order (stable radix sort keeps record order inside a hash group)
   m.pos_ridx.ensure((size_t)N + 4);
@@ -335,11 +373,13 @@ static void build_index(fa_mapper &m) {
     DevBuf<uint32_t> iota, sorted_hash, counts, counts_sorted;
     DevBuf<int32_t> num_runs;
     iota.ensure((size_t)N); sorted_hash.ensure((size_t)N); counts.ensure((size_t)N + 1); num_runs.ensure(1);
+    tr.mark("alloc", st);
     hipLaunchKernelGGL(k_iota, dim3(ceil_div(N, 256)), dim3(256), 0, st, iota.p, N);
     size_t bytes = 0;
     FA_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (int)N, 0, 32, st));
     temp.ensure(bytes + 16);
     FA_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (int)N, 0, 32, st));
+    tr.mark("sort", st);
     m.uniq_hash.ensure((size_t)N + 1);
     bytes = 0;
     FA_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, sorted_hash.p, m.uniq_hash.p, counts.p, num_runs.p, (int)N, st));
@@ -355,6 +395,7 @@ static void build_index(fa_mapper &m) {
     FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, counts.p, m.uniq_off.p, U + 1, st));
     temp.ensure(bytes + 16);
     FA_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, counts.p, m.uniq_off.p, U + 1, st));
+    tr.mark("rle_scan", st);
     // frequency threshold (computeFreqHist): walk the distinct list lengths from the most frequent down
     int64_t to_ignore = (int64_t)((float)(int64_t)U * 0.001f / 100);
     int64_t M = std::min<int64_t>(U, to_ignore + 1);
@@ -374,6 +415,7 @@ static void build_index(fa_mapper &m) {
       else if (j == to_ignore) { m.freq_threshold = (int)top[i]; break; }
       else break;
     }
+    tr.mark("threshold", st);
     // lookup table at load factor <= 1/2
     m.table_bits = std::max(4, floor_log2(std::max(U, 1)) + 2);
     FA_REQUIRE(m.table_bits <= 31, FA_ERR_UNSUPPORTED, "too many distinct minimizers for the lookup table");
@@ -386,6 +428,7 @@ static void build_index(fa_mapper &m) {
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(st));
+    tr.mark("table_links", st);
   } else {
     m.table_bits = 4;
     m.table.ensure(16);
