@@ -282,6 +282,7 @@ struct fa_mapper {
     uint32_t seed_slots = 0;
     uint64_t scratch_words = 0, items_cap = 0;
     int64_t l_cap = 0;
+    int64_t part_frags = 0;   // fragments per part of a pass (shrinks when a part overflows the 32-bit workspace)
   } spec;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo;
@@ -325,7 +326,9 @@ static void build_index(fa_mapper &m) {
   FA_REQUIRE(N < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "more than 2^31 minimizers in one index");
   m.C = m.seqs_by_file.empty() ? 0 : m.seqs_by_file.back();
   m.G = (int32_t)m.seqs_by_file.size();
-  m.cmw = m.P.fragment_length - (m.P.window_size - 1) - (m.P.kmer_size - 1);
+  // minimizer windows per fragment.  When it is <= 0 no fragment holds a window, query sketches are empty and L2 never
+  // runs (the degenerate (k=21, fragment 1000) cell); the window links are then built for 1 and never read
+  m.cmw = std::max(1, m.P.fragment_length - (m.P.window_size - 1) - (m.P.kmer_size - 1));
   m.qcap = std::max(1, m.P.fragment_length - m.P.kmer_size + 1 - (m.P.window_size - 1));
   const int bin_len = m.P.fragment_length - 20;
   DevBuf<unsigned char> temp;
@@ -489,22 +492,34 @@ static void debug_sync(hipStream_t st, const char *stage) {
   if (e != hipSuccess) throw Error(FA_ERR_NO_DEVICE, std::string("stage ") + stage + " failed: " + hipGetErrorString(e));
 }
 
+// fragments mapped per pass (bounds the workspace); FA_PASS_FRAGMENTS overrides it (tests force several passes)
+static int64_t pass_fragments() {
+  static const int64_t v = [] {
+    const char *e = getenv("FA_PASS_FRAGMENTS");
+    long long x = e ? atoll(e) : 0;
+    return (int64_t)(x > 0 ? x : 48 * 1024);
+  }();
+  return v;
+}
+
 // One pass of the hot path over genomes [g0, g1) of a resident batch.  Everything between the first kernel and the
 // final read-back is asynchronous on one stream: sizes that depend on the data (largest sketch, seed hits per
 // fragment, loci, slide events) are *speculated* from earlier passes (fa_mapper::spec), checked on the device, and the
 // pass is repeated with larger bounds if a check fails.  Returns the number of rows written at rows_dev[row_base ...].
+//
+// A pass normally covers all fragments of its genomes at once.  It is cut into *parts* (fragment ranges) when a genome
+// alone holds more fragments than pass_fragments(), or when the loci / seeds / slide events of the range exceed what
+// the 32-bit offsets of the workspace can address: the parts share the CGI bin table (step 2 of computeCGI is an
+// atomicMax, so it simply accumulates) and the rows are formed after the last part.
 static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
                               int64_t row_base) {
   hipStream_t st = m.stream;
-  const int64_t f0 = g.genome_frag_lo[g0], f1 = g.genome_frag_lo[g1];
-  const int64_t F = f1 - f0;
+  const int64_t range_f0 = g.genome_frag_lo[g0], range_f1 = g.genome_frag_lo[g1];
   const int NQ = g1 - g0;
-  m.last_F = F; m.last_f0 = f0; m.last_loci = 0; m.last_genomes = &g;
+  m.last_F = 0; m.last_f0 = range_f0; m.last_loci = 0; m.last_genomes = &g;
   for (int i = 0; i < 6; i++) if (!m.ev[i]) FA_HIP(hipEventCreate(&m.ev[i]));
-  if (F == 0) return 0;
+  if (range_f1 == range_f0) return 0;
   FA_REQUIRE(m.P.fragment_length > 20, FA_ERR_UNSUPPORTED, "fragment_length must exceed 20 (the reference bins by fragment_length - 20)");
-  const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
-  const int ntiles = t1 - t0;
   const int qcap = m.qcap;
   const IndexView ix = m.view();
   const int64_t npairs = (int64_t)NQ * m.G;
@@ -516,15 +531,10 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     sp.scratch_words = 0;
     sp.l_cap = (int64_t)env_u64("FA_LOCI_CAP_MIN", 1u << 18);   // the tests force the retry path with a tiny value
     sp.items_cap = env_u64("FA_EVENTS_CAP_MIN", 1u << 26);
+    sp.part_frags = pass_fragments();
   }
-  // buffers whose size depends only on the pass geometry
-  m.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
-  m.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
-  m.sk.tile_count.ensure((size_t)ntiles + 1);
-  m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
-  m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
-  m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
-  m.stats_dev.ensure(8); m.totals.ensure(8); m.counters.ensure(8); m.pinfo.ensure(8);
+  // event offsets are 32-bit: at most this many slide events per part (FA_EVENTS_CAP_MAX: the tests force the split)
+  const uint64_t items_max = env_u64("FA_EVENTS_CAP_MAX", (1ULL << 32) - 64);
   m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1) + 2);
   m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
   m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
@@ -532,8 +542,25 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   FA_REQUIRE(qs_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
 
   int64_t nrows = 0;
-  for (int attempt = 0;; attempt++) {
-    FA_REQUIRE(attempt < 6, FA_ERR_INTERNAL, "query pass did not converge on its buffer sizes");
+  int64_t f0 = range_f0;
+  int attempt = 0;
+  while (f0 < range_f1) {
+    FA_REQUIRE(attempt < 40, FA_ERR_INTERNAL, "query pass did not converge on its buffer sizes");
+    attempt++;
+    const int64_t f1 = std::min(range_f1, f0 + std::max<int64_t>(1, sp.part_frags));
+    const int64_t F = f1 - f0;
+    const bool first_part = f0 == range_f0, last_part = f1 == range_f1;
+    m.last_F = F; m.last_f0 = f0;
+    const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
+    const int ntiles = t1 - t0;
+    // buffers whose size depends only on the geometry of the part
+    m.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
+    m.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
+    m.sk.tile_count.ensure((size_t)ntiles + 1);
+    m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
+    m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
+    m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
+    m.stats_dev.ensure(8); m.totals.ensure(8); m.counters.ensure(8); m.pinfo.ensure(8);
     // ---- buffers and tables sized by the speculated bounds ----
     const int smax = sp.smax;
     FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
@@ -556,7 +583,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       cl.add(m.counters.p, 4 * sizeof(uint32_t)); cl.add(m.pinfo.p, 4 * sizeof(unsigned long long));
       cl.add(m.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(m.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(m.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
-      if (npairs > 0) cl.add(m.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
+      if (npairs > 0 && first_part) cl.add(m.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
       cl.launch(st);
     }
     // ---- K1 + per-fragment sort/unique ----
@@ -665,6 +692,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.bin_len = m.P.fragment_length - 20;
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
+    }
+    if (npairs > 0 && last_part) {
       hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
                          m.row_count.p, m.row_ident.p);
       if (npairs <= 16384) {
@@ -695,18 +724,29 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_HIP(hipEventRecord(m.ev[5], st));
     FA_HIP(hipStreamSynchronize(st));
     const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
-    FA_REQUIRE(total_seeds < (1ULL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 seed hits in one pass; query fewer genomes per call");
     const unsigned long long flags = h_pinfo[1];
+    // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
+    auto shrink_part = [&](double have, double limit, const char *what) {
+      FA_REQUIRE(F > 1, FA_ERR_UNSUPPORTED, std::string("a single query fragment produces too many ") + what);
+      sp.part_frags = std::max<int64_t>(1, std::min<int64_t>(F / 2, (int64_t)((double)F * limit / have * 0.8)));
+    };
+    if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); continue; }
     // bounds for the next pass (or the repeat of this one)
     if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 16 + 31) / 32 * 32;
     const uint32_t want_slots = std::min<uint32_t>(LDS_SEED_CAP, std::max<uint32_t>(1024, next_pow2((uint32_t)std::max<uint64_t>(max_seeds, 2))));
     const bool slots_changed = want_slots != sp.seed_slots;
     if (flags & SPEC_SCRATCH) sp.scratch_words = std::max<uint64_t>(sp.scratch_words, h_totals[2] + h_totals[2] / 4);
-    if (flags & SPEC_LOCI) sp.l_cap = std::max<int64_t>(sp.l_cap * 2, (int64_t)h_counters[0] + h_counters[0] / 4);
-    FA_REQUIRE(sp.l_cap < (1LL << 31), FA_ERR_UNSUPPORTED, "more than 2^31 candidate loci in one pass; query fewer genomes per call");
-    if (flags & SPEC_EVENTS) sp.items_cap = std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4);
-    FA_REQUIRE(sp.items_cap < (1ULL << 32), FA_ERR_UNSUPPORTED, "more than 2^32 slide events in one pass; query fewer genomes per call");
-    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; continue; }   // void pass: run it again
+    if (flags & SPEC_LOCI) {
+      const int64_t want = std::max<int64_t>(sp.l_cap * 2, (int64_t)h_counters[0] + h_counters[0] / 4);
+      const int64_t l_max = (1LL << 31) - 64;
+      if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); continue; }
+      sp.l_cap = std::min(want, l_max);
+    }
+    if (flags & SPEC_EVENTS) {
+      if (h_pinfo[0] > items_max) { shrink_part((double)h_pinfo[0], (double)items_max, "slide events"); continue; }
+      sp.items_cap = std::min<uint64_t>(items_max, std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4));
+    }
+    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; continue; }   // void part: run it again
     if (slots_changed) {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;
@@ -722,21 +762,12 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.last_ms[6] += (float)h_counters[0];
     m.last_ms[7] += (float)h_pinfo[0];    // slide events
     m.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
-    nrows = total_rows;
-    break;
+    if (last_part) nrows = total_rows;
+    f0 = f1;
+    attempt = 0;
   }
   FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
   return nrows;
-}
-
-// fragments mapped per pass (bounds the workspace); FA_PASS_FRAGMENTS overrides it (tests force several passes)
-static int64_t pass_fragments() {
-  static const int64_t v = [] {
-    const char *e = getenv("FA_PASS_FRAGMENTS");
-    long long x = e ? atoll(e) : 0;
-    return (int64_t)(x > 0 ? x : 48 * 1024);
-  }();
-  return v;
 }
 
 static int64_t run_query(fa_mapper &m, const fa_genomes &g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap, bool rows_device) {

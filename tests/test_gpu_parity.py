@@ -483,6 +483,63 @@ def test_speculated_capacities_retry():
     _run_child(code, {"FA_LOCI_CAP_MIN": "3", "FA_EVENTS_CAP_MIN": "64"})
 
 
+def test_random_seed_regime():
+    # short fragments against a larger index (48 Mb, k=16, fragment 1000): every fragment picks up chance seed hits in
+    # unrelated genomes, each of which becomes a one-seed locus that passes the relaxed identity bound -- the regime
+    # BASELINE config 5 runs in at full size.  minimum_fraction=0 keeps every row so that all of them are compared.
+    g = syn.rng(100)
+    genomes = []
+    for fam in range(4):
+        anc = syn.random_codes(g, 2_000_000)
+        for d in (0.0, 0.01, 0.04, 0.08, 0.13, 0.2):
+            genomes.append(syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc))
+    params = {"k": 16, "fragment_length": 1000, "minimum_fraction": 0.0}
+    sk, osk = quiet_sketch(pf.Sketch, **params), OracleSketch(**params)
+    for i, s in enumerate(genomes):
+        sk.add_genome(i, s)
+        osk.add_genome(i, s)
+    mapper = sk.index()
+    osk.index()
+    assert mapper.occurences_threshold == osk.freq_threshold
+    queries = [[genomes[1]], [genomes[8]], [syn.to_ascii(syn.random_codes(g, 1_000_000))]]
+    got = [hit_tuples(h) for h in mapper.upload_genomes(queries).query()]
+    want = [osk.query_draft(q, threads=8) for q in queries]
+    assert got == want
+    assert len(want[0]) > 6 and len(want[2]) > 0           # rows outside the family, and for a query related to nothing
+
+
+def test_pass_cut_into_parts():
+    # a genome with more fragments than one pass takes, and a pass whose slide events exceed what the 32-bit event
+    # offsets can address (both limits lowered through the environment): the pass is cut into fragment ranges that
+    # share the CGI bin table; results must not depend on the cut
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, warnings
+        sys.path.insert(0, %r)
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        from oracle.oracle import OracleSketch
+        g = syn.rng(99)
+        anc = syn.random_codes(g, 200_000)
+        sk, osk = pf.Sketch(), OracleSketch()
+        for i, d in enumerate((0.0, 0.02, 0.06, 0.12)):
+            r = syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc), 3)
+            sk.add_draft(i, r); osk.add_draft(i, r)
+        m = sk.index(); osk.index()
+        queries = [syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, d)), 4) for d in (0.03, 0.09)] + [[syn.to_ascii(anc)]]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = [[(h.name, h.identity, h.matches, h.fragments) for h in hits] for hits in m.upload_genomes(queries).query()]
+            one = [(h.name, h.identity, h.matches, h.fragments) for h in m.query_draft(queries[0])]
+        want = [osk.query_draft(q, threads=8) for q in queries]
+        assert got == want and one == want[0] and all(len(w) == 4 for w in want), (got, want)
+        print("OK")
+    """ % ROOT)
+    _run_child(code, {"FA_PASS_FRAGMENTS": "16"})                                   # ~65 fragments per genome: 5 parts each
+    _run_child(code, {"FA_EVENTS_CAP_MAX": "60000", "FA_EVENTS_CAP_MIN": "1000"})   # ~4000 events per fragment
+    _run_child(code, {"FA_EVENTS_CAP_MAX": "9000", "FA_PASS_FRAGMENTS": "50"})      # parts of one or two fragments
+
+
 def test_long_locus_and_reference_exceptions():
     # a tandem array in the reference merges dozens of overlapping candidates into one locus whose event stream is far
     # longer than the 2048 events staged in LDS; N runs and IUPAC codes in the reference take the byte path of K1
@@ -520,6 +577,36 @@ def test_degenerate_and_unusual_parameter_cells():
         assert hit_tuples(hits) == ohits, params
     with pytest.raises(NotImplementedError):
         quiet_sketch(pf.Sketch, fragment_length=20).add_genome("r", refs[0][0]).index().query_genome(query[0])
+
+
+@pytest.mark.parametrize("k", [14, 16, 21])
+@pytest.mark.parametrize("frag", [1000, 3000, 5000])
+def test_config5_cells_all_vs_all(k, frag):
+    """BASELINE config 5 scaled down: every (k, fragment_length) cell, all-vs-all through a resident batch, against the oracle."""
+    g = syn.rng(4000 + k * 10 + frag // 1000)
+    genomes = []
+    for fam in range(2):
+        anc = syn.random_codes(g, 120_000)
+        for d in (0.0, 0.02, 0.07, 0.15):
+            genomes.append([syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc)])
+    params = {"k": k, "fragment_length": frag}
+    sk, osk = quiet_sketch(pf.Sketch, **params), OracleSketch(**params)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for i, c in enumerate(genomes):
+            sk.add_draft(i, c)
+            osk.add_draft(i, c)
+        mapper = sk.index()
+        osk.index()
+        assert mapper.window_size == osk.window_size
+        got = [hit_tuples(h) for h in mapper.upload_genomes(genomes).query()]
+    want = [osk.query_draft(c, threads=8) for c in genomes]
+    assert got == want
+    if mapper.window_size < frag:
+        # (not exactly 100.0: a fragment that ends at the contig end can miss one minimizer, in the oracle too)
+        assert all(any(n == i and ident >= 99.99 for n, ident, m, f in w) for i, w in enumerate(want))
+    else:
+        assert all(w == [] for w in want)       # (21, 1000): no window fits a fragment
 
 
 def test_protein_small_k_and_wide_strings(golden_dir):
