@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--batch", type=int, default=1, help="query genomes mapped per step and per GPU (1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--replicated-index", action="store_true", help="N>1: every rank sketches all references itself")
     ap.add_argument("--cpu-refs", type=int, default=10, help="references in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -80,19 +81,42 @@ def main():
     n_related = int(round(args.refs * 0.6))
     g = syn.rng(1000)
     anc = syn.random_codes(g, args.length)
-    t0 = time.time()
-    sk = pf.Sketch()
+    names, refs = [], []
     for i in range(args.refs):
         if i < n_related:
             d = syn.DIVERGENCES[i % len(syn.DIVERGENCES)]
-            sk.add_genome(f"A{i:03d}", syn.to_ascii(syn.mutate_codes(g, anc, d)))
+            names.append(f"A{i:03d}"); refs.append([syn.to_ascii(syn.mutate_codes(g, anc, d))])
         else:
-            sk.add_genome(f"U{i:03d}", syn.to_ascii(syn.random_codes(g, args.length)))
-    t_pack = time.time() - t0
-    t0 = time.time()
-    n_min = len(sk.minimizers)
-    mapper = sk.index()
-    t_index = time.time() - t0
+            names.append(f"U{i:03d}"); refs.append([syn.to_ascii(syn.random_codes(g, args.length))])
+    mapper, index_mode, t_pack, t_index = None, "single sketch", 0.0, 0.0
+    if world > 1 and not args.replicated_index:
+        # every rank packs and sketches references rank, rank+world, ...; the minimizer shards are
+        # all-gathered (RCCL) and every rank indexes the merged records -- the same index a single Sketch builds
+        try:
+            t0 = time.time()
+            mapper = sharding.build_index_sharded(refs, names, rank, world, device="cpu" if share_gpu else "cuda")
+            t_index = time.time() - t0
+            index_mode = f"sharded sketching x{world} + all-gather of minimizer shards"
+            check_t = torch.tensor([len(mapper.minimizers), mapper.occurences_threshold, len(mapper.lookup_index)], dtype=torch.int64,
+                                   device="cpu" if share_gpu else "cuda")
+            lo, hi = check_t.clone(), check_t.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if not torch.equal(lo, hi):
+                raise RuntimeError("ranks disagree on the merged index")
+        except Exception as e:                     # never lose the bench line to the setup phase: fall back to replicas
+            print(f"[bench] sharded index build failed on rank {rank}: {e!r}; building replicas", file=sys.stderr)
+            mapper, index_mode = None, "replicated (sharded build failed)"
+    if mapper is None:
+        t0 = time.time()
+        sk = pf.Sketch()
+        for name, contigs in zip(names, refs):
+            sk.add_draft(name, contigs)
+        t_pack = time.time() - t0
+        t0 = time.time()
+        mapper = sk.index()
+        t_index = time.time() - t0
+    n_min = len(mapper.minimizers)
+    del refs
     gq = syn.rng(5000 + rank)
     queries = [[syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))] for _ in range(args.batch)]
     batch = mapper.upload_genomes(queries)
@@ -166,7 +190,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.batch} query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
                        "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
-                       "index_minimizers": n_min, "index_build_s": t_index, "host_pack_s": t_pack},
+                       "index_minimizers": n_min, "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": roof[1],
                          "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes},

@@ -108,6 +108,14 @@ int fa_sketch_get_state(fa_sketch *s, uint64_t *lengths, int32_t *sequences_by_f
 int fa_sketch_set_state(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths, const int32_t *sequences_by_file,
                         int64_t counter, int64_t n_minimizers, const uint32_t *hash, const int32_t *seq_id,
                         const int32_t *wpos);
+/* Device-pointer variants of fa_sketch_get_minimizers / fa_sketch_set_state (same record layout as the pickled state,
+ * _fastani.pyx:572-591): the three arrays live in HBM buffers owned by the caller (e.g. torch tensors), so the
+ * multi-GPU index build can all-gather minimizer shards over RCCL without a host round trip.
+ * `cap` is the capacity of the destination arrays in records. */
+int fa_sketch_get_minimizers_device(fa_sketch *s, int64_t cap, uint32_t *d_hash, int32_t *d_seq_id, int32_t *d_wpos);
+int fa_sketch_set_state_device(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths, const int32_t *sequences_by_file,
+                               int64_t counter, int64_t n_minimizers, const uint32_t *d_hash, const int32_t *d_seq_id,
+                               const int32_t *d_wpos);
 /* Sketch.index, _fastani.pyx:769-806: Sketch_t::index() + computeFreqHist(); ownership of the data moves to the
  * mapper and the sketch is left cleared but usable. */
 int fa_sketch_index(fa_sketch *s, fa_mapper **out);

@@ -459,6 +459,52 @@ class Sketch(_Parameterized):
             check(lib.fa_sketch_get_minimizers(self._h, h.ctypes.data, s.ctypes.data, w.ctypes.data))
         return h, s, w
 
+    # -- record exchange for the multi-GPU index build (pyfastani_amd.sharding) ------
+    def _export_records(self, device):
+        """Minimizer records as one ``int32`` torch tensor ``[3, n]`` (hash bits, contig id, window position) on
+        ``device`` plus the host-side state ``(lengths, sequencesByFileInfo, counter)``.  On a CUDA/HIP device the
+        records are copied HBM to HBM."""
+        import torch
+        n = self._num_minimizers()
+        ng = C.c_int64(0)
+        check(lib.fa_sketch_num_genomes(self._h, C.byref(ng)))
+        lengths = np.zeros(ng.value, np.uint64)
+        sbf = np.zeros(ng.value, np.int32)
+        counter = C.c_int64(0)
+        check(lib.fa_sketch_get_state(self._h, lengths.ctypes.data, sbf.ctypes.data, C.byref(counter)))
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            rec = torch.empty((3, max(n, 1)), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            base, row = rec.data_ptr(), rec.stride(0) * 4
+            check(lib.fa_sketch_get_minimizers_device(self._h, rec.shape[1], base, base + row, base + 2 * row))
+            rec = rec[:, :n]
+        else:
+            h, sq, w = self._read_minimizers()
+            rec = torch.from_numpy(np.stack([h.view(np.int32), sq, w]))
+        return rec, (lengths, sbf, counter.value)
+
+    def _import_records(self, names, lengths, sbf, counter, rec):
+        """Replace the content of this sketch by merged records (``rec`` as returned by `_export_records`)."""
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint64)
+        sbf = np.ascontiguousarray(sbf, dtype=np.int32)
+        n = int(rec.shape[1])
+        with self._lock:
+            if rec.device.type == "cuda":
+                import torch
+                rec = rec.contiguous()
+                torch.cuda.synchronize(rec.device)
+                base, row = rec.data_ptr(), rec.stride(0) * 4
+                check(lib.fa_sketch_set_state_device(self._h, len(lengths), lengths.ctypes.data, sbf.ctypes.data, int(counter),
+                                                     n, base, base + row, base + 2 * row))
+            else:
+                a = np.ascontiguousarray(rec.numpy())
+                h, sq, w = np.ascontiguousarray(a[0]).view(np.uint32), np.ascontiguousarray(a[1]), np.ascontiguousarray(a[2])
+                check(lib.fa_sketch_set_state(self._h, len(lengths), lengths.ctypes.data, sbf.ctypes.data, int(counter), n,
+                                              h.ctypes.data, sq.ctypes.data, w.ctypes.data))
+            self._names = list(names)
+            self._version += 1
+
     # -- pickling (_fastani.pyx:572-591) -----------------------------------------------------------
     def __getstate__(self):
         n = C.c_int64(0)

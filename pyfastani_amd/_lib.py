@@ -70,6 +70,8 @@ SIGNATURES = {
     "fa_sketch_num_genomes": (_i32, [_vp, _P(_i64)]),
     "fa_sketch_get_state": (_i32, [_vp, _vp, _vp, _P(_i64)]),
     "fa_sketch_set_state": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "fa_sketch_get_minimizers_device": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "fa_sketch_set_state_device": (_i32, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "fa_sketch_index": (_i32, [_vp, _P(_vp)]),
     "fa_mapper_free": (None, [_vp]),
     "fa_mapper_freq_threshold": (_i32, [_vp, _P(_i32)]),
@@ -101,6 +103,34 @@ if not os.path.exists(LIB_PATH):
         "(hipcc --offload-arch=gfx950). pyfastani_amd has no CPU fallback."
     )
 
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and two HIP runtimes in one process cannot
+    both drive the GPU (whichever initialises second sees no device).  The multi-GPU layer hands torch tensors to this
+    library, so both must sit on ONE runtime: load torch's copies first -- without importing torch -- and the
+    DT_NEEDED entries of libfastani_hip.so resolve to them by SONAME, whatever the import order.
+    ``FA_SYSTEM_HIP=1`` keeps the system runtime (no torch interoperability in that process)."""
+    if os.environ.get("FA_SYSTEM_HIP"):
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
+_share_hip_runtime_with_torch()
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here means the library and the header disagree

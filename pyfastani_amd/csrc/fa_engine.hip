@@ -998,6 +998,46 @@ int fa_sketch_set_state(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths
   });
 }
 
+// Device-pointer variants of the two calls above: the minimizer records never leave HBM.  Used by the multi-GPU index
+// build (every rank sketches a share of the references, the shards are all-gathered over RCCL into
+// tensors the caller owns, and every rank loads the merged records).  The caller synchronises its own stream before
+// the call; the library synchronises its stream before returning.
+int fa_sketch_get_minimizers_device(fa_sketch *s, int64_t cap, uint32_t *d_hash, int32_t *d_seq_id, int32_t *d_wpos) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    s->flush();
+    FA_REQUIRE(cap >= s->nrec, FA_ERR_INVALID, "destination holds fewer records than the sketch");
+    if (s->nrec == 0) return;
+    const size_t n = (size_t)s->nrec;
+    FA_HIP(hipMemcpyAsync(d_hash, s->rec_hash.p, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+    FA_HIP(hipMemcpyAsync(d_seq_id, s->rec_seq.p, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    FA_HIP(hipMemcpyAsync(d_wpos, s->rec_wpos.p, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+    FA_HIP(hipStreamSynchronize(s->stream));
+  });
+}
+int fa_sketch_set_state_device(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths, const int32_t *sbf, int64_t counter,
+                               int64_t n_min, const uint32_t *d_hash, const int32_t *d_seq_id, const int32_t *d_wpos) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(s->mtx);
+    FA_REQUIRE(n_min >= 0 && n_genomes >= 0, FA_ERR_INVALID, "negative count");
+    s->reset_data();
+    s->lengths.assign(lengths, lengths + n_genomes);
+    s->seqs_by_file.assign(sbf, sbf + n_genomes);
+    s->counter = counter;
+    if (n_min > 0) {
+      require_device();
+      if (!s->stream) FA_HIP(hipStreamCreate(&s->stream));
+      const size_t n = (size_t)n_min;
+      s->rec_hash.ensure(n); s->rec_seq.ensure(n); s->rec_wpos.ensure(n);
+      FA_HIP(hipMemcpyAsync(s->rec_hash.p, d_hash, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s->stream));
+      FA_HIP(hipMemcpyAsync(s->rec_seq.p, d_seq_id, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+      FA_HIP(hipMemcpyAsync(s->rec_wpos.p, d_wpos, n * sizeof(int32_t), hipMemcpyDeviceToDevice, s->stream));
+      FA_HIP(hipStreamSynchronize(s->stream));
+    }
+    s->nrec = n_min;
+  });
+}
+
 int fa_sketch_index(fa_sketch *s, fa_mapper **out) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);

@@ -656,3 +656,101 @@ def test_sharding_all_vs_all_single_rank():
     batch = mapper.upload_genomes([genomes[i] for i in owned])
     part = sharding.remap_query_ids(batch.query_rows(), owned)
     assert sorted(map(tuple, part.tolist())) == sorted(t for t in map(tuple, rows.tolist()) if t[0] in owned)
+
+
+def _sharded_index_genomes():
+    g = syn.rng(123)
+    genomes = []
+    for fam in range(2):
+        anc = syn.random_codes(g, 90_000)
+        for d in (0.0, 0.03, 0.1):
+            genomes.append(syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc), 4))
+    genomes.append([b"ACGT" * 3])                          # a genome whose only contig is too short: no records
+    genomes.insert(2, [syn.to_ascii(syn.random_codes(g, 50_000)), b"ACGTACGT"])
+    return genomes
+
+
+def test_sharded_index_build_single_rank_and_device_merge():
+    """build_index_sharded at world size 1 goes through the HBM-to-HBM record export / import and must give the index a
+    single Sketch builds; merge_record_shards is run on device tensors against the same records dealt to 3 ranks."""
+    import torch
+    from pyfastani_amd import sharding
+    genomes = _sharded_index_genomes()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sk = pf.Sketch()
+        for i, c in enumerate(genomes):
+            sk.add_draft(f"g{i}", c)
+        want_min = tuple(a.copy() for a in sk._read_minimizers())
+        direct = sk.index()
+        sharded = sharding.build_index_sharded(genomes, names=[f"g{i}" for i in range(len(genomes))], rank=0, world_size=1, device="cuda")
+        assert sharded.occurences_threshold == direct.occurences_threshold and len(sharded.lookup_index) == len(direct.lookup_index)
+        got_min = sharded._read_minimizers()
+        assert all(np.array_equal(a, b) for a, b in zip(got_min, want_min))
+        for q in (genomes[1], genomes[4]):
+            assert hit_tuples(sharded.query_draft(q)) == hit_tuples(direct.query_draft(q))
+        # the same records dealt round-robin to 3 "ranks", merged on the device
+        world, n = 3, len(genomes)
+        shards, rec_off, ctg = [], [], []
+        for r in range(world):
+            local = pf.Sketch()
+            for i in sharding.shard_indices(n, r, world):
+                local.add_draft(i, genomes[i])
+            rec, (lengths, sbf, counter) = local._export_records("cuda")
+            sbf64 = np.asarray(sbf, np.int64)
+            c = np.diff(np.concatenate([[0], sbf64]))
+            first = torch.as_tensor((sbf64 - c).astype(np.int32), device="cuda")
+            off = torch.searchsorted(rec[1].contiguous(), first).to(torch.int64).cpu()
+            rec_off.append(torch.cat([off, torch.tensor([rec.shape[1]])]))
+            ctg.append(torch.as_tensor(c))
+            shards.append(rec)
+        n_max = max(int(s.shape[1]) for s in shards)
+        gathered = torch.zeros((world, 3, n_max), dtype=torch.int32, device="cuda")
+        for r, s in enumerate(shards):
+            gathered[r, :, : s.shape[1]] = s
+        merged, sbf = sharding.merge_record_shards(gathered, rec_off, ctg)
+        m = merged.cpu().numpy()
+        assert np.array_equal(m[0].view(np.uint32), want_min[0]) and np.array_equal(m[1], want_min[1]) and np.array_equal(m[2], want_min[2])
+
+
+def test_sharded_index_build_two_ranks_one_gpu(tmp_path):
+    """Two gloo ranks share GPU 0: each sketches half of the references, the shards are exchanged (through host tensors,
+    gloo has no device all-gather) and both ranks must end up with the index of a single Sketch."""
+    import socket
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, warnings
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, torch.distributed as dist
+        import pyfastani_amd as pf
+        from pyfastani_amd import sharding
+        from test_gpu_parity import _sharded_index_genomes
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        genomes = _sharded_index_genomes()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = pf.Sketch()
+            for i, c in enumerate(genomes):
+                sk.add_draft(i, c)
+            want = tuple(a.copy() for a in sk._read_minimizers())
+            direct = sk.index()
+            m = sharding.build_index_sharded(genomes, rank=rank, world_size=world, device="cpu")
+            assert all(np.array_equal(a, b) for a, b in zip(m._read_minimizers(), want))
+            assert m.occurences_threshold == direct.occurences_threshold
+            tup = lambda hits: [(h.name, h.identity, h.matches, h.fragments) for h in hits]
+            assert tup(m.query_draft(genomes[1])) == tup(direct.query_draft(genomes[1]))
+        dist.barrier(); dist.destroy_process_group()
+        open(os.path.join(%r, f"idx{rank}.ok"), "w").write("OK")
+    """ % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path)))
+    script = tmp_path / "worker.py"
+    script.write_text(code)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "idx0.ok").exists() and (tmp_path / "idx1.ok").exists()

@@ -75,3 +75,93 @@ def test_all_gather_rows_world2(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert (tmp_path / "rank0.ok").read_text() == "11" and (tmp_path / "rank1.ok").read_text() == "11"
+
+
+def _fake_genome_records(seed, n_genomes):
+    """Deterministic fake minimizer records of n_genomes reference genomes in GLOBAL numbering:
+    per genome a list of (hash bits, global contig id, window position), the contig counts and the lengths."""
+    rng = np.random.default_rng(seed)
+    contigs = [int(rng.integers(1, 4)) for _ in range(n_genomes)]
+    lengths = [int(rng.integers(1, 50)) * 3000 for _ in range(n_genomes)]
+    per_genome, gseq = [], 0
+    for g in range(n_genomes):
+        rows = []
+        for _ in range(contigs[g]):
+            k = int(rng.integers(0, 6))            # some contigs contribute no minimizer
+            for x in np.sort(rng.choice(1000, k, replace=False)):
+                rows.append((int(rng.integers(-2**31, 2**31 - 1)), gseq, int(x)))
+            gseq += 1
+        per_genome.append(rows)
+    return per_genome, contigs, lengths
+
+
+def test_merge_record_shards_single_process():
+    import torch
+    per_genome, contigs, _ = _fake_genome_records(3, 11)
+    world = 4
+    shards, rec_off, ctg = [], [], []
+    for r in range(world):
+        rows, off, cs, lbase = [], [0], [], 0
+        for g in range(r, len(per_genome), world):
+            gb = sum(contigs[:g])
+            rows += [(h, s - gb + lbase, w) for h, s, w in per_genome[g]]
+            lbase += contigs[g]
+            cs.append(contigs[g])
+            off.append(len(rows))
+        shards.append(np.array(rows, dtype=np.int32).reshape(-1, 3).T)
+        rec_off.append(torch.tensor(off))
+        ctg.append(torch.tensor(cs, dtype=torch.int64))
+    n_max = max(s.shape[1] for s in shards)
+    gathered = torch.zeros((world, 3, n_max), dtype=torch.int32)
+    for r, s in enumerate(shards):
+        gathered[r, :, : s.shape[1]] = torch.from_numpy(np.ascontiguousarray(s))
+    out, sbf = sharding.merge_record_shards(gathered, rec_off, ctg)
+    assert out.T.tolist() == [list(t) for g in per_genome for t in g]
+    assert sbf.tolist() == np.cumsum(contigs).tolist()
+
+
+SHARD_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    sys.path.insert(0, {tests!r})
+    import numpy as np, torch, torch.distributed as dist
+    from pyfastani_amd import sharding
+    from test_sharding_gloo import _fake_genome_records
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = 7
+    per_genome, contigs, lengths = _fake_genome_records(5, n)
+    # what this rank's local Sketch would hold: its genomes, contig ids numbered locally
+    rows, sbf, lens, lbase = [], [], [], 0
+    for g in sharding.shard_indices(n, rank, world):
+        gb = sum(contigs[:g])
+        rows += [(h, s - gb + lbase, w) for h, s, w in per_genome[g]]
+        lbase += contigs[g]
+        sbf.append(lbase)
+        lens.append(lengths[g])
+    rec = torch.from_numpy(np.ascontiguousarray(np.array(rows, dtype=np.int32).reshape(-1, 3).T))
+    gathered, rec_off, ctg, lens_global = sharding.exchange_record_shards(rec, np.array(lens, np.uint64), np.array(sbf, np.int32), n, rank, world)
+    out, sbf_global = sharding.merge_record_shards(gathered, rec_off, ctg)
+    assert out.T.tolist() == [list(t) for g in per_genome for t in g], rank
+    assert sbf_global.tolist() == np.cumsum(contigs).tolist() and lens_global.tolist() == lengths
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join({out!r}, f"shard{{rank}}.ok"), "w").write(str(out.shape[1]))
+""")
+
+
+def test_exchange_and_merge_record_shards_world2(tmp_path):
+    """The multi-GPU index build on CPU: two gloo ranks exchange fabricated minimizer shards and
+    both rebuild the records of the single-Sketch order."""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), out=str(tmp_path)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    total = str(sum(len(g) for g in _fake_genome_records(5, 7)[0]))
+    assert (tmp_path / "shard0.ok").read_text() == total and (tmp_path / "shard1.ok").read_text() == total
