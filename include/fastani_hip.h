@@ -34,6 +34,8 @@ extern "C" {
 #define FA_ERR_NOMEM 3       /* host or device allocation failed (MemoryError)  */
 #define FA_ERR_UNSUPPORTED 4 /* parameter regime outside the HIP path           */
 #define FA_ERR_INTERNAL 5
+#define FA_ERR_IO 6          /* file could not be opened / mapped (OSError)      */
+#define FA_ERR_BUFFER 7      /* FASTA header longer than the reference's line buffer (BufferError) */
 
 typedef struct fa_sketch fa_sketch;   /* skch::Sketch under construction + pyfastani bookkeeping */
 typedef struct fa_mapper fa_mapper;   /* indexed reference, resident in HBM (skch::Sketch after index() + skch::Map) */
@@ -142,6 +144,22 @@ int fa_mapper_get_state(fa_mapper *m, uint64_t *lengths, int32_t *sequences_by_f
 int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *lengths, int n_contigs, int char_width,
                     fa_cgi_row *rows, int64_t cap, int64_t *n_rows, int *n_short, uint64_t *total_fragments,
                     uint64_t *total_length);
+
+/* ---- host ingest: FASTA files ------------------------------------------ */
+/* Record reader with the semantics of pyfastani._fasta.Parser (src/pyfastani/_fasta.pyx:41-103): records exist only
+ * if the first line starts with '>'; id = header line without '>' and newline; sequence lines joined, ASCII letters
+ * upper-cased (copy_upper); a header that does not end in '\n' within 2047 bytes fails with FA_ERR_BUFFER.  The
+ * pointers returned by fa_fasta_next stay valid until the next call on the same handle. */
+typedef struct fa_fasta fa_fasta;
+int fa_fasta_open(const char *path, fa_fasta **out);                          /* Parser.__cinit__, _fasta.pyx:49-58 */
+int fa_fasta_next(fa_fasta *f, int *has_record, const char **id, int64_t *id_length, const unsigned char **seq,
+                  int64_t *seq_length);                                         /* Parser.__next__, _fasta.pyx:66-103 */
+void fa_fasta_close(fa_fasta *f);
+/* Parser + Sketch._add_draft (_fastani.pyx:610-690) in one native call: every record of the file is a contig of ONE
+ * reference genome; records are split and upper-cased by host threads and packed without passing through Python. */
+int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int64_t *n_short);
+/* One query genome per FASTA file, packed and uploaded as a resident batch (fa_genomes_upload semantics). */
+int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_paths, fa_genomes **out);
 
 /* ---- resident batches (many-to-many; inputs stay in HBM) -------------- */
 /* Pack + upload a batch of query genomes.  contig_genome[i] is the genome (0..n_genomes-1, non-decreasing)

@@ -459,6 +459,22 @@ class Sketch(_Parameterized):
             check(lib.fa_sketch_get_minimizers(self._h, h.ctypes.data, s.ctypes.data, w.ctypes.data))
         return h, s, w
 
+    def add_fasta(self, name, path):
+        """Add every record of a FASTA file as the contigs of ONE reference genome (`add_draft` semantics,
+        _fastani.pyx:692-717), read and packed natively without building Python objects (host ingest)."""
+        import os
+        n_rec, n_short = C.c_int64(0), C.c_int64(0)
+        with self._lock:
+            check(lib.fa_sketch_add_fasta(self._h, os.fsencode(path), C.byref(n_rec), C.byref(n_short)))
+            self._names.append(name)
+            self._version += 1
+        for _ in range(n_short.value):
+            warnings.warn(
+                "Sketch received a short contig relative to parameters, minimizers will not be added.",
+                UserWarning,
+            )
+        return self
+
     # -- record exchange for the multi-GPU index build (pyfastani_amd.sharding, SURVEY.md 8e) ------
     def _export_records(self, device):
         """Minimizer records as one ``int32`` torch tensor ``[3, n]`` (hash bits, contig id, window position) on
@@ -750,6 +766,11 @@ class Mapper(_Parameterized):
         """Pack a list of draft genomes (each an iterable of contigs) into HBM and return a `GenomeBatch`."""
         from ._batch import GenomeBatch
         return GenomeBatch(self, genomes)
+
+    def upload_fasta(self, paths):
+        """One query genome per FASTA file (its records are the contigs), read, packed and uploaded natively."""
+        from ._batch import GenomeBatch
+        return GenomeBatch.from_fasta(self, paths)
 
     def query_batch(self, batch, first=0, count=None):
         """Map genomes ``[first, first+count)`` of a resident batch; returns one hit list per genome."""

@@ -42,8 +42,26 @@ class GenomeBatch:
         h = C.c_void_p()
         check(lib.fa_genomes_upload(mapper._h, c_ptrs, c_lens, cg.ctypes.data if n else None, n, self.n_genomes, width,
                                     C.byref(h)))
-        self._h = h
         del owners
+        self._finish(h)
+
+    @classmethod
+    def from_fasta(cls, mapper, paths):
+        """One genome per FASTA file, parsed and packed by the library (``fa_genomes_upload_fasta``)."""
+        import os
+        self = cls.__new__(cls)
+        self._mapper = mapper
+        self._h = None
+        paths = [os.fsencode(p) for p in paths]
+        self.n_genomes = len(paths)
+        arr = (C.c_char_p * max(len(paths), 1))(*paths)
+        h = C.c_void_p()
+        check(lib.fa_genomes_upload_fasta(mapper._h, arr, len(paths), C.byref(h)))
+        self._finish(h)
+        return self
+
+    def _finish(self, h):
+        self._h = h
         self.total_fragments = np.zeros(self.n_genomes, np.uint64)
         self.total_length = np.zeros(self.n_genomes, np.uint64)
         self.n_short = np.zeros(self.n_genomes, np.int32)

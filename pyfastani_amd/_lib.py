@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfastani_hip.so")
 
-FA_OK, FA_ERR_INVALID, FA_ERR_NO_DEVICE, FA_ERR_NOMEM, FA_ERR_UNSUPPORTED, FA_ERR_INTERNAL = range(6)
+FA_OK, FA_ERR_INVALID, FA_ERR_NO_DEVICE, FA_ERR_NOMEM, FA_ERR_UNSUPPORTED, FA_ERR_INTERNAL, FA_ERR_IO, FA_ERR_BUFFER = range(8)
 
 
 class Params(C.Structure):
@@ -92,6 +92,11 @@ SIGNATURES = {
     "fa_mapper_debug_l1": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _P(_i64)]),
     "fa_mapper_debug_query_sketch": (_i32, [_vp, _i64, _vp, _i32, _P(_i32)]),
     "fa_debug_sketch_sequence": (_i32, [_P(Params), _vp, _i64, _i32, _vp, _vp, _i64, _P(_i64)]),
+    "fa_fasta_open": (_i32, [C.c_char_p, _P(_vp)]),
+    "fa_fasta_next": (_i32, [_vp, _P(_i32), _P(_vp), _P(_i64), _P(_vp), _P(_i64)]),
+    "fa_fasta_close": (None, [_vp]),
+    "fa_sketch_add_fasta": (_i32, [_vp, C.c_char_p, _P(_i64), _P(_i64)]),
+    "fa_genomes_upload_fasta": (_i32, [_vp, _P(C.c_char_p), _i32, _P(_vp)]),
     "fa_mapper_last_timings": (_i32, [_vp, _P(_f32), _i32]),
     "fa_mapper_stream": (_i32, [_vp, _P(_vp)]),
     "fa_bench_sketch_kernel": (_i32, [_vp, _vp, _i32, _P(_f32), _P(_u64), _P(_u64)]),
@@ -154,6 +159,10 @@ def check(code):
         raise MemoryError(msg)
     if code == FA_ERR_UNSUPPORTED:
         raise NotImplementedError(msg)
+    if code == FA_ERR_IO:
+        raise OSError(msg)
+    if code == FA_ERR_BUFFER:
+        raise BufferError(msg)
     raise RuntimeError(msg)
 
 

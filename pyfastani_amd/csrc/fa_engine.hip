@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "fa_common.h"
+#include "fa_fasta.h"
 #include "fa_map.hip.h"
 #include "fa_sketch.hip.h"
 #include "fa_stats.h"
@@ -943,6 +944,55 @@ int fa_sketch_add_contig(fa_sketch *s, const void *data, int64_t length, int cha
     if (added) *added = ok;
   });
 }
+struct fa_fasta { FastaFile f; };
+int fa_fasta_open(const char *path, fa_fasta **out) {
+  return guarded([&] {
+    FA_REQUIRE(path && out, FA_ERR_INVALID, "null argument");
+    std::unique_ptr<fa_fasta> h(new fa_fasta());
+    h->f.open(path);
+    *out = h.release();
+  });
+}
+int fa_fasta_next(fa_fasta *f, int *has_record, const char **id, int64_t *id_length, const unsigned char **seq, int64_t *seq_length) {
+  return guarded([&] {
+    const bool ok = f->f.next();
+    *has_record = ok ? 1 : 0;
+    if (!ok) return;
+    *id = f->f.id.data(); *id_length = (int64_t)f->f.id.size();
+    *seq = f->f.seq.data(); *seq_length = (int64_t)f->f.seq.size();
+  });
+}
+void fa_fasta_close(fa_fasta *f) { delete f; }
+
+int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int64_t *n_short) {
+  return guarded([&] {
+    FA_REQUIRE(path, FA_ERR_INVALID, "null path");
+    std::vector<std::vector<uint8_t>> seqs;
+    read_fasta_records(path, seqs, host_threads());
+    std::lock_guard<std::mutex> lock(s->mtx);
+    std::vector<const void *> ptrs;
+    std::vector<int64_t> lens;
+    int64_t shorts = 0;
+    for (auto &q : seqs) {
+      const int64_t length = (int64_t)q.size();
+      FA_REQUIRE(length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
+      if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
+        ptrs.push_back(q.data()); lens.push_back(length);
+        s->pending_contig.push_back((int32_t)s->counter);
+      } else {
+        shorts++;
+      }
+      s->cur_total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
+      s->counter += 1;                                                                     // :683
+    }
+    if (!ptrs.empty()) s->pending.append_many(ptrs.data(), lens.data(), (int64_t)ptrs.size(), 1);
+    s->lengths.push_back(s->cur_total);                  // :687
+    s->cur_total = 0;
+    s->seqs_by_file.push_back((int32_t)s->counter);      // :690
+    if (n_records) *n_records = (int64_t)seqs.size();
+    if (n_short) *n_short = shorts;
+  });
+}
 int fa_sketch_end_genome(fa_sketch *s) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
@@ -1139,6 +1189,21 @@ int fa_genomes_upload(fa_mapper *m, const void *const *contigs, const int64_t *l
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
     *out = upload_genomes(m->P, m->stream, contigs, lengths, contig_genome, n_contigs, n_genomes, char_width).release();
+  });
+}
+int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_paths, fa_genomes **out) {
+  return guarded([&] {
+    FA_REQUIRE(n_paths >= 0, FA_ERR_INVALID, "negative count");
+    std::vector<std::vector<std::vector<uint8_t>>> files((size_t)n_paths);
+    std::vector<const void *> ptrs;
+    std::vector<int64_t> lens;
+    std::vector<int32_t> genome;
+    for (int32_t i = 0; i < n_paths; i++) {
+      read_fasta_records(paths[i], files[i], host_threads());
+      for (auto &q : files[i]) { ptrs.push_back(q.data()); lens.push_back((int64_t)q.size()); genome.push_back(i); }
+    }
+    std::lock_guard<std::mutex> lock(m->mtx);
+    *out = upload_genomes(m->P, m->stream, ptrs.data(), lens.data(), genome.data(), (int64_t)ptrs.size(), n_paths, 1).release();
   });
 }
 void fa_genomes_free(fa_genomes *g) { delete g; }

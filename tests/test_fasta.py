@@ -1,0 +1,68 @@
+"""Host ingest: the FASTA reader mirrors pyfastani._fasta.Parser (_fasta.pyx:33-103).  CPU only."""
+import os
+
+import pytest
+
+from pyfastani_amd._fasta import Parser, Record
+
+
+def write(tmp_path, name, data):
+    p = tmp_path / name
+    p.write_bytes(data)
+    return str(p)
+
+
+def test_records_ids_and_upper_casing(tmp_path):
+    path = write(tmp_path, "a.fna", b">seq1 some description\nacgtNNac\nGGTT\n\n>seq2\nA\n>empty\n>last\nacgu-*\nTT")
+    recs = list(Parser(path))
+    assert [r.id for r in recs] == ["seq1 some description", "seq2", "empty", "last"]
+    assert [r.seq for r in recs] == [b"ACGTNNACGGTT", b"A", b"", b"ACGU-*TT"]
+    assert all(isinstance(r, Record) and isinstance(r.seq, bytes) and isinstance(r.id, str) for r in recs)
+
+
+def test_crlf_is_kept_like_the_reference(tmp_path):
+    # only the '\n' is stripped (_fasta.pyx:95-96): a carriage return stays in the id and in the sequence
+    recs = list(Parser(write(tmp_path, "crlf.fa", b">id\r\nAC\r\nGT\r\n")))
+    assert recs[0].id == "id\r" and recs[0].seq == b"AC\rGT\r"
+
+
+def test_file_not_starting_with_header_yields_nothing(tmp_path):
+    assert list(Parser(write(tmp_path, "x.fa", b"ACGT\n>late\nACGT\n"))) == []
+    assert list(Parser(write(tmp_path, "empty.fa", b""))) == []
+
+
+def test_long_lines_and_large_record(tmp_path):
+    body = (b"acgt" * 5000 + b"\n") * 30 + b"ACGT" * 100        # 20 000-character lines, no trailing newline
+    recs = list(Parser(write(tmp_path, "long.fa", b">big\n" + body + b"\n>next\nTT\n")))
+    assert recs[0].seq == b"ACGT" * (5000 * 30 + 100) and recs[1].seq == b"TT"
+
+
+def test_header_longer_than_the_line_buffer(tmp_path):
+    ok = b">" + b"x" * 2045 + b"\nACGT\n"                        # 2047 characters including the newline: fits
+    assert list(Parser(write(tmp_path, "ok.fa", ok)))[0].id == "x" * 2045
+    with pytest.raises(BufferError):
+        list(Parser(write(tmp_path, "bad.fa", b">" + b"x" * 2046 + b"\nACGT\n")))
+    with pytest.raises(BufferError):
+        list(Parser(write(tmp_path, "eof.fa", b">header without newline")))
+
+
+def test_errors(tmp_path):
+    with pytest.raises(OSError):
+        Parser(os.path.join(str(tmp_path), "missing.fa"))
+    with pytest.raises(TypeError):
+        Parser(b"bytes-path")
+    with pytest.raises(TypeError):
+        Record("id", "not bytes")
+
+
+def test_protein_fixture_matches_plain_python_reader(golden_dir):
+    path = os.path.join(golden_dir, "BGC0001425.faa")
+    want, cur = [], None
+    for line in open(path, "rb"):
+        if line.startswith(b">"):
+            cur = [line[1:-1].decode("latin-1"), b""]
+            want.append(cur)
+        else:
+            cur[1] += line.rstrip(b"\n").upper()
+    got = [(r.id, r.seq) for r in Parser(path)]
+    assert got == [tuple(w) for w in want] and len(got) > 10

@@ -754,3 +754,45 @@ def test_sharded_index_build_two_ranks_one_gpu(tmp_path):
     res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout + res.stderr
     assert (tmp_path / "idx0.ok").exists() and (tmp_path / "idx1.ok").exists()
+
+
+def test_fasta_ingest_matches_python_path(tmp_path):
+    """Sketch.add_fasta / Mapper.upload_fasta (native parse + pack) against the same records fed through add_draft /
+    query_draft: lower case, N runs, wrapped lines, a short contig, CRLF-free files."""
+    from pyfastani_amd._fasta import Parser
+    g = syn.rng(321)
+    anc = syn.random_codes(g, 160_000)
+
+    def write_fasta(path, contigs, width):
+        with open(path, "wb") as f:
+            for i, c in enumerate(contigs):
+                f.write(b">contig_%d some text\n" % i)
+                b = bytes(c)
+                for j in range(0, len(b), width):
+                    f.write(b[j:j + width] + b"\n")
+
+    files = []
+    for gi, d in enumerate((0.0, 0.04, 0.11)):
+        seq = bytearray(bytes(syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc)))
+        seq[1000:1100] = b"N" * 100
+        seq[50_000:51_000] = bytes(seq[50_000:51_000]).lower()
+        contigs = syn.split_contigs(g, np.frombuffer(bytes(seq), np.uint8), 5) + [b"ACGTAC"]
+        path = str(tmp_path / f"g{gi}.fna")
+        write_fasta(path, contigs, 60 + 10 * gi)
+        files.append(path)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        native, plain = pf.Sketch(), pf.Sketch()
+        for i, path in enumerate(files):
+            native.add_fasta(i, path)
+            plain.add_draft(i, [r.seq for r in Parser(path)])
+        a, b = native._read_minimizers(), plain._read_minimizers()
+        assert all(np.array_equal(x, y) for x, y in zip(a, b)) and len(a[0]) > 10_000
+        m1, m2 = native.index(), plain.index()
+        got = [hit_tuples(h) for h in m1.upload_fasta(files).query()]
+        want = [hit_tuples(m2.query_draft([r.seq for r in Parser(path)])) for path in files]
+    assert got == want and all(len(w) == 3 for w in want)
+    with pytest.warns(UserWarning):
+        pf.Sketch().add_fasta("x", files[0])                 # the 6-base contig is reported like add_draft does
+    with pytest.raises(OSError):
+        pf.Sketch().add_fasta("x", str(tmp_path / "missing.fna"))
