@@ -113,26 +113,17 @@ if not os.path.exists(LIB_PATH):
 def _share_hip_runtime_with_torch():
     """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and two HIP runtimes in one process cannot
     both drive the GPU (whichever initialises second sees no device).  The multi-GPU layer hands torch tensors to this
-    library, so both must sit on ONE runtime: load torch's copies first -- without importing torch -- and the
-    DT_NEEDED entries of libfastani_hip.so resolve to them by SONAME, whatever the import order.
-    ``FA_SYSTEM_HIP=1`` keeps the system runtime (no torch interoperability in that process)."""
+    library, so both must sit on ONE runtime: torch is imported first -- its copies are then the ones the DT_NEEDED
+    entries of libfastani_hip.so resolve to by SONAME.  Importing torch only AFTER this library has initialised HIP
+    also works but is pathologically slow (torch then registers its thousands of kernels with a live runtime: 10 s to
+    minutes, measured), hence the eager import.  ``FA_SYSTEM_HIP=1`` skips it and keeps the system runtime (no torch
+    interoperability in that process)."""
     if os.environ.get("FA_SYSTEM_HIP"):
         return
-    import importlib.util
     try:
-        spec = importlib.util.find_spec("torch")
-    except (ImportError, ValueError):
-        spec = None
-    if spec is None or not spec.submodule_search_locations:
-        return
-    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
-    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
-        path = os.path.join(libdir, name)
-        if os.path.exists(path):
-            try:
-                C.CDLL(path, mode=C.RTLD_GLOBAL)
-            except OSError:
-                return
+        import torch  # noqa: F401
+    except ImportError:
+        pass
 
 
 _share_hip_runtime_with_torch()

@@ -457,7 +457,11 @@ static void ensure_luts(fa_mapper &m, int smax) {
   }
 }
 
-static const uint32_t LDS_SEED_CAP = 32768;   // 128 KiB of seed indices per workgroup at most
+// seed hits of one fragment sorted in LDS by k_l1 (12 bytes each: two buffers + list ids); more go through HBM scratch
+static uint32_t lds_seed_cap_max(int smax) {
+  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 5 * 4 - ((int64_t)smax + 2) * 4 - 16;
+  return (uint32_t)std::max<int64_t>(256, room / 12 / 256 * 256);
+}
 
 static uint64_t env_u64(const char *name, uint64_t dflt) {
   const char *e = getenv(name);
@@ -528,7 +532,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   if (!sp.init) {
     sp.init = true;
     sp.smax = 256;
-    sp.seed_slots = 16384;
+    sp.seed_slots = 4096;
     sp.scratch_words = 0;
     sp.l_cap = (int64_t)env_u64("FA_LOCI_CAP_MIN", 1u << 18);   // the tests force the retry path with a tiny value
     sp.items_cap = env_u64("FA_EVENTS_CAP_MIN", 1u << 26);
@@ -567,6 +571,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
     ensure_luts(m, smax);
     const int64_t l_cap = sp.l_cap;
+    const uint32_t seed_slots = std::min(sp.seed_slots, lds_seed_cap_max(smax));   // LDS also holds smax list offsets
     m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap + 4);
     m.l_rfirst.ensure((size_t)l_cap); m.l_rlast.ensure((size_t)l_cap + 4);
     m.l_group.ensure((size_t)l_cap); m.l_shared.ensure((size_t)l_cap); m.l_pos.ensure((size_t)l_cap);
@@ -605,9 +610,9 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     {
       LookupArgs a;
       a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
-      a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = sp.seed_slots;
+      a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
       hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
-      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, sp.seed_slots, m.totals.p, m.ovf_off.p,
+      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, seed_slots, m.totals.p, m.ovf_off.p,
                          m.stats_dev.p, smax, sp.scratch_words, m.pinfo.p);
     }
     debug_sync(st, "lookup");
@@ -619,10 +624,10 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
       a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p;
       a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
-      a.lds_seed_cap = sp.seed_slots; a.pinfo = m.pinfo.p; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
+      a.lds_seed_cap = seed_slots; a.pinfo = m.pinfo.p; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
-      const size_t lds = (size_t)sp.seed_slots * 4 + (size_t)L1_STAGE * 5 * 4;   // seed buffer + the loci staged per fragment
-      constexpr int L1_THREADS = 256;   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
+      constexpr int L1_THREADS = 256;
+      const size_t lds = l1_lds_bytes(seed_slots, smax, L1_THREADS);   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
       if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       hipLaunchKernelGGL(k_l1<L1_THREADS>, dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
     }
@@ -734,7 +739,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); continue; }
     // bounds for the next pass (or the repeat of this one)
     if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 16 + 31) / 32 * 32;
-    const uint32_t want_slots = std::min<uint32_t>(LDS_SEED_CAP, std::max<uint32_t>(1024, next_pow2((uint32_t)std::max<uint64_t>(max_seeds, 2))));
+    // LDS slots for the seed sort: a quarter of headroom over the largest fragment seen, (LDS per workgroup sets how many fragments a CU works on at once)
+    uint32_t want_slots = std::min<uint32_t>(lds_seed_cap_max(sp.smax), std::max<uint32_t>(1024, (uint32_t)((std::min<uint64_t>(max_seeds + max_seeds / 4, 1u << 30) + 255) / 256 * 256)));
     const bool slots_changed = want_slots != sp.seed_slots;
     if (flags & SPEC_SCRATCH) sp.scratch_words = std::max<uint64_t>(sp.scratch_words, h_totals[2] + h_totals[2] / 4);
     if (flags & SPEC_LOCI) {

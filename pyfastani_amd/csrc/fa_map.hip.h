@@ -26,7 +26,7 @@
 namespace fa {
 
 constexpr int MAP_THREADS = 256;
-constexpr int L1_STAGE = 512;     // loci of one fragment merged in LDS by k_l1 (more fall back to a second pass)
+constexpr int L1_STAGE = 256;     // loci of one fragment merged in LDS by k_l1 (more fall back to a second pass)
 constexpr uint32_t SEED_PAD = 0xFFFFFFFFu;
 
 // ----------------------------------------------------------------------------------------------------------
@@ -370,6 +370,19 @@ struct L1Args {
   uint32_t lds_seed_cap;
 };
 
+// dynamic LDS of k_l1: seeds [cap] + their list ids [cap, 16-bit], the list offsets [lut_smax + 2], the staged loci (5 arrays
+// of L1_STAGE), and -- only when a fragment can exceed what the in-place merge holds in registers -- a second pair of
+// seed / list-id buffers
+constexpr int L1_INPLACE = 16;    // elements per thread the in-place merge keeps in registers
+__host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 6 + 15) / 16 * 16; }
+__host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax) {
+  return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 4 + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int threads) {
+  const size_t base = l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 5 * 4;
+  return seed_cap > (uint32_t)(L1_INPLACE * threads) ? base + (size_t)seed_cap * 6 : base;
+}
+
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
 template <int NT>
 __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
@@ -386,33 +399,120 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   if (s > a.lut_smax) return;                    // SPEC_SMAX was raised by k_seed_totals: the pass will be repeated
   uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
   if (n32 < 2) n32 = 2;
-  if (n > a.lds_seed_cap && (uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;   // SPEC_SCRATCH, same
-  uint32_t *seeds = (n <= a.lds_seed_cap) ? (uint32_t *)lds : a.ovf_buf + a.ovf_off[f];
-
-  // ---- gather the position lists (ordered by query hash; order is irrelevant before the sort) ----
-  if (tid == 0) sh_run = 0;
-  __syncthreads();
-  for (int j0 = 0; j0 < s; j0 += blockDim.x) {
-    int j = j0 + tid;
-    uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
-    uint32_t incl = cnt;
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-    if (lane == 63) sh_scan[wv] = incl;
+  const bool in_lds = n <= a.lds_seed_cap;
+  if (!in_lds && (uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;   // SPEC_SCRATCH, same
+  uint32_t *seeds;
+  if (in_lds) {
+    // ---- the position lists of the query minimizers are each sorted already (CSR order = record order): gather them
+    //      back to back and merge them pairwise, bottom-up.  Every element finds its place in the merged run by its rank
+    //      in its own run plus a binary search in the sibling run (record indices are unique: no ties); a run is a group
+    //      of 2^k consecutive lists, so its bounds come from the prefix sums of the list lengths. ----
+    const uint32_t cap = a.lds_seed_cap;
+    uint32_t *A = (uint32_t *)lds;
+    uint16_t *R = (uint16_t *)(A + cap);                                 // list every element came from
+    uint32_t *off = (uint32_t *)(lds + l1_off_offset(cap));             // [s + 1] first seed of every list
+    if (tid == 0) sh_run = 0;
     __syncthreads();
-    uint32_t off = sh_run + incl - cnt;
-    for (int q = 0; q < wv; q++) off += sh_scan[q];
-    if (cnt) {
-      uint32_t src = a.q_off[(size_t)f * a.qcap + j];
-      for (uint32_t t = 0; t < cnt; t++) seeds[off + t] = a.ix.pos_ridx[src + t];
+    for (int j0 = 0; j0 < s; j0 += NT) {
+      const int j = j0 + tid;
+      const uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
+      uint32_t incl = cnt;
+      for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) sh_scan[wv] = incl;
+      __syncthreads();
+      uint32_t o = sh_run + incl - cnt;
+      for (int q = 0; q < wv; q++) o += sh_scan[q];
+      if (j < s) off[j] = o;
+      __syncthreads();
+      if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+      __syncthreads();
+    }
+    if (tid == 0) off[s] = n;
+    __syncthreads();
+    const uint32_t *qoff = a.q_off + (size_t)f * a.qcap;
+    for (uint32_t i = tid; i < n; i += NT) {
+      int lo = 0, hi = s - 1;                                            // the list j with off[j] <= i < off[j + 1]
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+      A[i] = a.ix.pos_ridx[qoff[lo] + (i - off[lo])];
+      R[i] = (uint16_t)lo;
     }
     __syncthreads();
-    if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+    // one merge step for the element at position i: where it lands in the run merged from its own and the sibling run
+    auto place = [&](const uint32_t *src, uint32_t i, int k, uint32_t x, int j) __attribute__((always_inline)) {
+      const int r = j >> k, r0 = r & ~1;
+      const uint32_t a0 = off[min(r0 << k, s)], a1 = off[min((r0 + 1) << k, s)], a2 = off[min((r0 + 2) << k, s)];
+      const bool left = (r & 1) == 0;
+      uint32_t lo = left ? a1 : a0;
+      uint32_t hi = left ? a2 : a1;
+      const uint32_t sib = lo, own = left ? a0 : a1;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (src[mid] < x) lo = mid + 1; else hi = mid; }
+      return a0 + (i - own) + (lo - sib);
+    };
+    if (n <= (uint32_t)(L1_INPLACE * NT)) {
+      // in place: every thread keeps its (at most L1_INPLACE) elements in registers across the barrier that separates
+      // the reads of a level from its writes -- 6 bytes of LDS per seed, which keeps 6-7 workgroups on a CU
+      for (int k = 0; (1 << k) < s; k++) {
+        uint32_t xs[L1_INPLACE], ds[L1_INPLACE];
+        int js[L1_INPLACE];
+#pragma unroll
+        for (int e = 0; e < L1_INPLACE; e++) {
+          const uint32_t i = tid + e * NT;
+          xs[e] = 0; ds[e] = 0; js[e] = 0;
+          if (i < n) { xs[e] = A[i]; js[e] = R[i]; ds[e] = place(A, i, k, xs[e], js[e]); }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < L1_INPLACE; e++) {
+          const uint32_t i = tid + e * NT;
+          if (i < n) { A[ds[e]] = xs[e]; R[ds[e]] = (uint16_t)js[e]; }
+        }
+        __syncthreads();
+      }
+    } else {
+      // larger fragments: ping-pong between two buffers (12 bytes of LDS per seed)
+      uint32_t *B = (uint32_t *)(lds + l1_stage_offset(cap, a.lut_smax) + (size_t)L1_STAGE * 5 * 4);
+      uint16_t *R2 = (uint16_t *)(B + cap);
+      for (int k = 0; (1 << k) < s; k++) {
+        for (uint32_t i = tid; i < n; i += NT) {
+          const uint32_t x = A[i];
+          const int j = R[i];
+          const uint32_t dst = place(A, i, k, x, j);
+          B[dst] = x;
+          R2[dst] = (uint16_t)j;
+        }
+        __syncthreads();
+        uint32_t *t = A; A = B; B = t;
+        uint16_t *u = R; R = R2; R2 = u;
+      }
+    }
+    seeds = A;
+  } else {
+    // ---- more seed hits than LDS holds: lists gathered into HBM scratch and sorted there ----
+    seeds = a.ovf_buf + a.ovf_off[f];
+    if (tid == 0) sh_run = 0;
     __syncthreads();
+    for (int j0 = 0; j0 < s; j0 += blockDim.x) {
+      int j = j0 + tid;
+      uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
+      uint32_t incl = cnt;
+      for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) sh_scan[wv] = incl;
+      __syncthreads();
+      uint32_t off = sh_run + incl - cnt;
+      for (int q = 0; q < wv; q++) off += sh_scan[q];
+      if (cnt) {
+        uint32_t src = a.q_off[(size_t)f * a.qcap + j];
+        for (uint32_t t = 0; t < cnt; t++) seeds[off + t] = a.ix.pos_ridx[src + t];
+      }
+      __syncthreads();
+      if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+      __syncthreads();
+    }
+    for (uint32_t i = n + tid; i < n32; i += blockDim.x) seeds[i] = SEED_PAD;
+    __syncthreads();
+    // a record index identifies (seqId, wpos) and the record array is ordered by it: sorting indices == std::sort of hits
+    block_bitonic_sort(seeds, n32);
   }
-  for (uint32_t i = n + tid; i < n32; i += blockDim.x) seeds[i] = SEED_PAD;
-  __syncthreads();
-  // a record index identifies (seqId, wpos) and the record array is ordered by it: sorting indices == std::sort of hits
-  block_bitonic_sort(seeds, n32);
 
   int m = a.min_hits_lut[s];
   if (m < 1) m = 1;
@@ -422,7 +522,7 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
 
   // ---- ordered passes over the candidates.  Pass 0 merges them into loci held in LDS (up to L1_STAGE per fragment) and
   //      is normally the only one; if a fragment has more loci, pass 0 only counted and pass 1 writes them to HBM. ----
-  int32_t *st_seq = (int32_t *)(lds + (size_t)a.lds_seed_cap * 4);       // [L1_STAGE] each
+  int32_t *st_seq = (int32_t *)(lds + l1_stage_offset(a.lds_seed_cap, a.lut_smax));   // [L1_STAGE] each
   int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
   for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
   bool staged = true;
@@ -747,16 +847,21 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   }
 }
 
-// State of one lane: ST[r] = (query rank r currently matched) << (bits-1) | number of distinct window-only hashes of
-// insertion rank r.  ST is uint8 on the fast path (one byte per rank keeps 8 waves per CU resident); if a count would
-// reach 128 the lane flags its locus and the uint16 instantiation redoes it (l_redo).  The array is shifted by one
-// slot so that the boundary rank r*-1 needs no clamp when r* = 0.  LNT = lanes per workgroup at compile time (64) or
-// 0 for the run-time value used when a huge sketch forces fewer lanes per workgroup.
+// State of one lane: ST[r] = number of distinct window-only hashes of insertion rank r << 1 | (query rank r currently
+// matched).  ST is uint8 on the fast path (one byte per rank keeps 8 waves per CU resident); a count that reaches 128
+// carries out of the byte (seen in the 32-bit value before it is stored), the lane flags its locus and the uint16
+// instantiation redoes it (l_redo).  The array is shifted by one slot so that the boundary rank r*-1 needs no clamp
+// when r* = 0.  LNT = lanes per workgroup at compile time (64) or 0 for the run-time value used when a huge sketch
+// forces fewer lanes per workgroup.
+//
+// The loop is VALU-issue bound (one lane per locus, ~1000 dependent events), so the state is kept in the form that
+// needs the fewest instructions: the pivot as the LDS address of its slot (rl = r* x LN + lane: comparisons against
+// the event's slot address need no conversion), F = r* + #window-only hashes below r* (the quantity both pivot tests
+// use) instead of the two terms, and pivot moves as one signed step `delta` applied with multiply-adds.
 template <typename T, typename ST, int LNT>
 __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   constexpr int SBITS = 8 * (int)sizeof(ST);
-  constexpr uint32_t MATCH = 1u << (SBITS - 1), CMASK = MATCH - 1u;
   constexpr bool REDO = sizeof(ST) > 1;
   const int LN = LNT ? LNT : a.lanes;
   ST *st = (ST *)lds;                                              // [cnt_slots + 1][LN], lane-interleaved
@@ -775,8 +880,14 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   constexpr int RB = EvBits<T>::RANK;
   constexpr uint32_t RANK_MASK = (1u << RB) - 1u;
   for (int i = 0; i <= s + 1; i++) st[i * LN + lane] = 0;
+  // LDS byte addresses as plain integers: `extern __shared__` has a link-time base the compiler would add on every access
+  typedef __attribute__((address_space(3))) ST *lds_ptr;
+  constexpr int STB = (int)sizeof(ST);
+  const int lbase = (int)(uint32_t)(uintptr_t)(lds_ptr)st + lane * STB;
+  const int LNB = LN * STB;                                         // bytes between consecutive slots of one lane
 
-  int rstar = s, P = 0, shared = 0, beg = beg0;
+  int rl = s * LNB + lbase;                                         // address of slot r* (= state of rank r*-1)
+  int F = s, shared = 0, beg = beg0;                                // F = r* + sum of cnt[c] for c < r*  (= f(r*-1) + 1)
   int best = -1, opt_s = beg0, opt_e = beg0;
   uint32_t overflow = 0;
   const uint32_t ngroups = nev / PER;
@@ -786,34 +897,35 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
 #pragma unroll
     for (int q = 0; q < PER; q++) {
       constexpr int WPE = (int)sizeof(T);
-      uint32_t word = (q * WPE / 4 == 0) ? cur.x : (q * WPE / 4 == 1) ? cur.y : (q * WPE / 4 == 2) ? cur.z : cur.w;
-      const uint32_t e = sizeof(T) == 2 ? ((q & 1) ? (word >> 16) : (word & 0xFFFFu)) : word;
+      const uint32_t word = (q * WPE / 4 == 0) ? cur.x : (q * WPE / 4 == 1) ? cur.y : (q * WPE / 4 == 2) ? cur.z : cur.w;
+      const int SH = (sizeof(T) == 2 && (q & 1)) ? 16 : 0;         // position of the event inside its 32-bit word (a constant after unrolling)
       // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
-      const int slot = (int)(e & RANK_MASK);                       // query rank + 1 (0 = padding)
-      const int dM = __builtin_amdgcn_sbfe(e, RB, 2), dW = __builtin_amdgcn_sbfe(e, RB + 2, 2);
-      const int drp = (int)((e >> (RB + 4)) & 1u);
-      const bool evl = ((e >> (RB + 5)) & 1u) != 0;
+      const int slot = (int)__builtin_amdgcn_ubfe(word, SH, RB);   // query rank + 1 (0 = padding)
+      const int dM = __builtin_amdgcn_sbfe(word, SH + RB, 2), dW = __builtin_amdgcn_sbfe(word, SH + RB + 2, 2);
+      const int drp = (int)__builtin_amdgcn_ubfe(word, SH + RB + 4, 1);
+      const bool evl = ((word >> (SH + RB + 5)) & 1u) != 0;
       // both LDS reads are issued together: the touched rank, and the rank at the boundary the pivot may move across
-      const int rbs = rstar + drp;                                 // slot of rank r* (drop) or r*-1 (admit)
-      const uint32_t v = st[slot * LN + lane];
-      const uint32_t vb0 = st[rbs * LN + lane];
-      const uint32_t cv = v + (uint32_t)dW;                        // count lives in the low bits
-      overflow |= (cv ^ v) & MATCH;                                // a carry into the MATCH bit = count overflow
-      const uint32_t nv = cv ^ (((uint32_t)dM & 1u) << (SBITS - 1));   // admits of a matched rank set the bit, drops clear it
-      st[slot * LN + lane] = (ST)nv;
-      const bool below = slot <= rstar;                            // rank < r*
+      const int addr = slot * LNB + lbase;
+      const int addrb = rl + drp * LNB;                            // slot of rank r* (drop) or r*-1 (admit)
+      const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
+      const uint32_t vb0 = *(lds_ptr)(uintptr_t)(uint32_t)addrb;
+      // admits of a matched rank set bit 0, drops clear it; window-only hashes count in the bits above
+      const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+      overflow |= nv;                                              // bit SBITS set = the count left its field
+      *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
+      const bool below = addr <= rl;                               // rank < r*
       shared += below ? dM : 0;
-      P += below ? dW : 0;
-      const uint32_t vb = (rbs == slot) ? nv : vb0;
-      const int cb = (int)(vb & CMASK), mb = (int)((vb >> (SBITS - 1)) & 1u);
-      const int f = rstar + P;                                     // f(r*-1) + 1
-      // a window-only hash left and query rank r* re-enters the s smallest of the union (f + cb < s implies r* < s) ...
-      const bool up = dW < 0 && f + cb < s;
+      F += below ? dW : 0;
+      const uint32_t vb = (addrb == addr) ? nv : vb0;
+      const int cb = (int)(vb >> 1), mb = (int)(vb & 1u);
+      // a window-only hash left and query rank r* re-enters the s smallest of the union (F + cb < s implies r* < s) ...
+      const bool up = ((dW & (F + cb - s)) < 0);                   // dW < 0 and F + cb < s: both sign bits set
       // ... or one arrived below r* and f(r*-1) reached s: the largest query rank falls out
-      const bool down = dW > 0 && below && f > s;
-      P += up ? cb : (down ? -cb : 0);
-      shared += up ? mb : (down ? -mb : 0);
-      rstar += up ? 1 : (down ? -1 : 0);
+      const bool down = dW > 0 && below && F > s;
+      const int delta = up ? 1 : (down ? -1 : 0);
+      F += __mul24(delta, cb + 1);                                 // r* moves by delta, the count of the crossed rank changes sides
+      shared += __mul24(delta, mb);
+      rl += __mul24(delta, LNB);
       beg += drp;
       const bool gt = evl && shared > best, ge = evl && shared >= best;
       best = gt ? shared : best;
@@ -822,7 +934,7 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
     }
     cur = nxt;
   }
-  if (overflow) {
+  if (overflow >> SBITS) {
     if (!REDO) { a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u); return; }
   }
   a.l_shared[l] = best < 0 ? 0 : best;
