@@ -260,6 +260,9 @@ struct fa_mapper {
   DevBuf<uint4> table;
   DevBuf<int32_t> rec_seq, rec_wpos, rec_prev, rec_fwd, rec_bwd, contig_rec, contig_genome, contig_bin, genome_bin;
   DevBuf<uint8_t> rec_flags;
+  DevBuf<uint32_t> rec_geo;       // packed window geometry + flags for k_l2_events (empty when cmw >= 8191)
+  DevBuf<uint16_t> rec_prev16;
+  bool packed_geo = false;
   int64_t N = 0, U = 0;
   int32_t C = 0, G = 0, table_bits = 4, freq_threshold = INT_MAX, total_bins = 0;
   std::vector<uint64_t> lengths;
@@ -302,6 +305,7 @@ struct fa_mapper {
   IndexView view() const {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
+    v.rec_geo = packed_geo ? rec_geo.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr;
     v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.table = table.p;
     v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
     v.N = N; v.U = U; v.C = C; v.G = G; v.table_bits = table_bits; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
@@ -430,6 +434,12 @@ static void build_index(fa_mapper &m) {
                        m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
     hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, m.contig_rec.p, N, m.cmw,
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
+    m.packed_geo = m.cmw + 1 < (1 << GEO_BITS);
+    if (m.packed_geo) {
+      m.rec_geo.ensure((size_t)N + 4); m.rec_prev16.ensure((size_t)N + 4);
+      hipLaunchKernelGGL(k_pack_geometry, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_prev.p, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p, N,
+                         m.rec_geo.p, m.rec_prev16.p);
+    }
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(st));
     tr.mark("table_links", st);
@@ -683,8 +693,14 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
           hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
         }
       };
-      if (wide) launch(k_l2_events<uint32_t>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
-      else launch(k_l2_events<uint16_t>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+      const bool pk = m.packed_geo && !getenv("FA_NO_PACKED_GEO");
+      if (wide) {
+        if (pk) launch(k_l2_events<uint32_t, true>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+        else launch(k_l2_events<uint32_t, false>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+      } else {
+        if (pk) launch(k_l2_events<uint16_t, true>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+        else launch(k_l2_events<uint16_t, false>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+      }
     }
     debug_sync(st, "l2 scan");
     FA_HIP(hipEventRecord(m.ev[3], st));

@@ -226,6 +226,22 @@ __global__ void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, 
   }
 }
 
+// The same geometry packed for the hot loop of k_l2_events (fewer bytes per record, fewer loads): one 32-bit word
+//   geo[i] = (rec_fwd[i+1] - (i+1)) | (i - rec_bwd[i]) << 13 | flags << 26,   both distances are <= cmw < 8192,
+// and prev16[i] = min(i - rec_prev[i], 65535) (65535 also for "no earlier record with this hash in the contig": only
+// compared against distances < 8192).  Built only when cmw + 1 < 8192; otherwise the kernels read the plain arrays.
+constexpr int GEO_BITS = 13;
+__global__ void k_pack_geometry(const int32_t *rec_prev, const int32_t *rec_fwd, const int32_t *rec_bwd, const uint8_t *rec_flags, int64_t N,
+                                uint32_t *rec_geo, uint16_t *rec_prev16) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t fwd1 = i + 1 < N ? (uint32_t)(rec_fwd[i + 1] - (int32_t)(i + 1)) : 0u;
+  const uint32_t bwd = (uint32_t)((int32_t)i - rec_bwd[i]);
+  rec_geo[i] = (fwd1 & ((1u << GEO_BITS) - 1u)) | ((bwd & ((1u << GEO_BITS) - 1u)) << GEO_BITS) | ((uint32_t)rec_flags[i] << (2 * GEO_BITS));
+  const int32_t pv = rec_prev[i];
+  rec_prev16[i] = (uint16_t)(pv < 0 ? 65535 : min((int32_t)i - pv, 65535));
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // resident index view passed to the mapping kernels
 // ----------------------------------------------------------------------------------------------------------
@@ -236,6 +252,8 @@ struct IndexView {
   const int32_t *rec_prev;
   const int32_t *rec_fwd, *rec_bwd;
   const uint8_t *rec_flags;
+  const uint32_t *rec_geo;      // packed geometry (k_pack_geometry), null when cmw is too large for it
+  const uint16_t *rec_prev16;
   const uint32_t *uniq_hash;
   const uint32_t *uniq_off;
   const uint32_t *pos_ridx;
@@ -706,11 +724,12 @@ __device__ __forceinline__ uint32_t ev_word(int rank_bits, int slot, int dM, int
          ((drop ? 1u : 0u) << (rank_bits + 4)) | ((eval ? 1u : 0u) << (rank_bits + 5));
 }
 
-template <typename T>
+template <typename T, bool PACKED>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   uint32_t *Q = (uint32_t *)lds;                                     // [smax], staged once per fragment
-  __shared__ uint16_t QT[258];
+  constexpr int QT_BITS = 10;                                        // bucket table resolution
+  __shared__ uint16_t QT[(1 << QT_BITS) + 2];
   const int f = blockIdx.x;
   const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
   if (l_n == 0) return;
@@ -769,13 +788,18 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     atomicAdd(a.rec_total, sh_records);
   }
   __syncthreads();
-  // bucket table over the top 8 hash bits: QT[b] = first query rank whose hash is >= b << 24
-  for (int b = threadIdx.x; b <= 256; b += EV_THREADS) {
+  // Bucket table over the hash range the query sketch actually spans: minimizer hashes are window minima, i.e. heavily
+  // skewed towards 0, so the buckets divide [0, 2^bits) with 2^bits > the largest query hash rather than the full 32-bit
+  // range.  QT[b] = first query rank whose hash is >= b << qshift; a reference hash beyond the range ranks after all.
+  const uint32_t hmax = s > 0 ? Q[s - 1] : 0u;
+  const int qshift = max(0, (32 - __clz((int)(hmax | 1u))) - QT_BITS);   // hmax < 2^(qshift + QT_BITS)
+  for (int b = threadIdx.x; b <= (1 << QT_BITS); b += EV_THREADS) {
     int x = 0, y = s;
-    const uint64_t key = (uint64_t)b << 24;
+    const uint64_t key = (uint64_t)b << qshift;
     while (x < y) { int mid = (x + y) >> 1; if ((uint64_t)Q[mid] < key) x = mid + 1; else y = mid; }
     QT[b] = (uint16_t)x;
   }
+  if (threadIdx.x == 0) QT[(1 << QT_BITS) + 1] = (uint16_t)s;
   __syncthreads();
   if (!sh_ok) {                                                      // the event buffer is too small: void pass
     for (uint32_t i = threadIdx.x; i < l_n; i += EV_THREADS) a.l_nev[l_lo + i] = 0;
@@ -796,14 +820,15 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     const bool staged = padded <= (uint32_t)a.ev_stage;
     T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
     for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)0;
-    auto emit = [&](int i, uint32_t h, uint8_t rf, int32_t prev, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
-      int x = QT[h >> 24], y = QT[(h >> 24) + 1];
+    auto emit = [&](int i, uint32_t h, uint32_t rf, bool prev_in, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
+      const uint32_t qb = min(h >> qshift, (uint32_t)(1 << QT_BITS));     // the last bucket is [2^bits, inf): rank s
+      int x = QT[qb], y = QT[qb + 1];
       while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
       const bool found = x < s && Q[x] == h;
       constexpr int RB = EvBits<T>::RANK;
       if (i < end0) {
         // first super-window: inserted in record order, compared once after the last one
-        const int on = prev >= beg ? 0 : 1;
+        const int on = prev_in ? 0 : 1;                    // the hash is already in the first window
         out[i - beg] = (T)ev_word(RB, x + 1, found ? on : 0, found ? 0 : on, false, i == end0 - 1);
       } else {
         // admitted after the drops of all records before the one active at its window position (rec_bwd)
@@ -822,19 +847,37 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     };
     // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
     for (int i0 = beg + lane; i0 < last; i0 += 256) {
-      uint32_t h[4]; uint8_t rf[4]; int32_t pv[4], bw[4], fw[4];
+      if (PACKED) {
+        uint32_t h[4], geo[4]; uint32_t pd[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + 64 * u;
-        const bool ok = i < last;
-        h[u] = ok ? a.ix.rec_hash[i] : 0u;
-        rf[u] = ok ? a.ix.rec_flags[i] : (uint8_t)0;
-        pv[u] = (ok && i < end0) ? a.ix.rec_prev[i] : -1;
-        bw[u] = (ok && i >= end0) ? a.ix.rec_bwd[i] : 0;
-        fw[u] = (ok && i - beg < ndrop) ? a.ix.rec_fwd[i + 1] : 0;
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + 64 * u;
+          const bool ok = i < last;
+          h[u] = ok ? a.ix.rec_hash[i] : 0u;
+          geo[u] = ok ? a.ix.rec_geo[i] : 0u;
+          pd[u] = (ok && i < end0) ? (uint32_t)a.ix.rec_prev16[i] : 65535u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + 64 * u;
+          if (i < last) emit(i, h[u], geo[u] >> (2 * GEO_BITS), pd[u] <= (uint32_t)(i - beg),
+                             i - (int32_t)((geo[u] >> GEO_BITS) & ((1u << GEO_BITS) - 1u)), i + 1 + (int32_t)(geo[u] & ((1u << GEO_BITS) - 1u)));
+        }
+      } else {
+        uint32_t h[4]; uint8_t rf[4]; int32_t pv[4], bw[4], fw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + 64 * u;
+          const bool ok = i < last;
+          h[u] = ok ? a.ix.rec_hash[i] : 0u;
+          rf[u] = ok ? a.ix.rec_flags[i] : (uint8_t)0;
+          pv[u] = (ok && i < end0) ? a.ix.rec_prev[i] : -1;
+          bw[u] = (ok && i >= end0) ? a.ix.rec_bwd[i] : 0;
+          fw[u] = (ok && i - beg < ndrop) ? a.ix.rec_fwd[i + 1] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u] >= beg, bw[u], fw[u]);
       }
-#pragma unroll
-      for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u], bw[u], fw[u]);
     }
     if (staged) {
       __builtin_amdgcn_wave_barrier();
