@@ -287,6 +287,7 @@ struct fa_mapper {
     uint64_t scratch_words = 0, items_cap = 0;
     int64_t l_cap = 0;
     int64_t part_frags = 0;   // fragments per part of a pass (shrinks when a part overflows the 32-bit workspace)
+    bool redo = false;        // launch the wide-state scan as well (set once a locus overflowed the one-byte state)
   } spec;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo;
@@ -596,7 +597,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     {
       ClearList cl;
       cl.add(m.stats_dev.p, 4 * sizeof(int32_t)); cl.add(m.totals.p, 4 * sizeof(uint64_t));
-      cl.add(m.counters.p, 4 * sizeof(uint32_t)); cl.add(m.pinfo.p, 4 * sizeof(unsigned long long));
+      cl.add(m.counters.p, 8 * sizeof(uint32_t)); cl.add(m.pinfo.p, 4 * sizeof(unsigned long long));
       cl.add(m.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(m.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(m.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
       if (npairs > 0 && first_part) cl.add(m.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
@@ -684,6 +685,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
           if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
           hipLaunchKernelGGL(scan8_rt, dim3(ceil_div(l_cap, lanes8)), dim3(L2_THREADS), lds8, st, a);
         }
+        // the wide-state pass is only launched once some locus has needed it (a part that finds out too late is repeated)
+        if (!sp.redo) return;
         a.lanes = lanes16;
         if (lanes16 == L2_THREADS) {
           if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
@@ -716,11 +719,14 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
     }
     if (npairs > 0 && last_part) {
-      hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, m.bins.p, m.genome_bin.p, m.total_bins, m.G, NQ,
-                         m.row_count.p, m.row_ident.p);
-      if (npairs <= 16384) {
-        hipLaunchKernelGGL(k_emit_rows_small, dim3(1), dim3(1024), 0, st, m.row_count.p, m.row_ident.p, m.G, (int)npairs,
-                           g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base, m.row_off.p);
+      RowsArgs ra;
+      ra.bins = m.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
+      ra.row_count = m.row_count.p; ra.row_ident = m.row_ident.p;
+      ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
+      ra.done = m.counters.p + 4; ra.query_total_frag = g.d_total_frag.p + g0; ra.query_id_base = g0;
+      ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = m.row_off.p;
+      hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
+      if (ra.emit) {
         FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       } else {
         hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
@@ -770,6 +776,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       sp.items_cap = std::min<uint64_t>(items_max, std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4));
     }
     if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; continue; }   // void part: run it again
+    if (h_counters[3] > 0 && !sp.redo) { sp.redo = true; continue; }   // loci overflowed the byte state and the wide pass was not launched
     if (slots_changed) {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;

@@ -1027,31 +1027,93 @@ __global__ void k_cgi_bins(CgiArgs a) {
 }
 
 // One wave per (query genome, reference genome) pair: coalesced 64-bin reads, then the non-empty bins are added one
-// by one in bin order (readlane + add), which reproduces the reference's sequential float32 sum bit for bit.
-__global__ __launch_bounds__(256) void k_cgi_rows(const unsigned long long *bins, const int32_t *genome_bin, int total_bins, int G, int NQ,
-                                                  int32_t *row_count, float *row_ident) {
+// by one in bin order (readlane + add), which reproduces the reference's sequential float32 sum bit for bit.  The bins
+// of eight 64-bin chunks are fetched together so that the sequential chain waits for HBM once per 512 bins, and
+// chunks without any mapping are skipped (x + 0.0f == x).  When `emit` is set (small passes) the last workgroup to
+// finish also forms the rows -- flag the non-empty pairs, scan, write in (query, genome) order -- which saves a launch.
+struct RowsArgs {
+  const unsigned long long *bins;
+  const int32_t *genome_bin;
+  int32_t total_bins, G, NQ;
+  int32_t *row_count;
+  float *row_ident;
+  int32_t emit;                    // fused row emission (npairs small)
+  uint32_t *done;                  // workgroups finished (zeroed by k_clear)
+  const int32_t *query_total_frag;
+  int32_t query_id_base;
+  fa_cgi_row *rows;
+  int64_t cap;
+  int32_t *total_rows;
+};
+
+__global__ __launch_bounds__(256) void k_cgi_rows(RowsArgs a) {
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (i >= (int64_t)NQ * G) return;
-  const int q = (int)(i / G), g = (int)(i % G);
-  const unsigned long long *b = bins + (size_t)q * total_bins;
-  const int x0 = genome_bin[g], x1 = genome_bin[g + 1];
-  int cnt = 0;
-  float sum = 0.0f;
-  for (int x = x0; x < x1; x += 64) {
-    unsigned long long v = (x + lane < x1) ? b[x + lane] : 0ULL;
-    float val = __uint_as_float((uint32_t)(v >> 32));
-    cnt += __popcll(__ballot(v != 0ULL));
-    // empty bins hold +0.0f and x + 0.0f == x exactly, so adding all 64 lanes in lane order IS the reference's
-    // sequential sum over the non-empty bins; constant lane indices keep the chain at one v_readlane + v_add each
-    const int bits = (int)__float_as_uint(val);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t npairs = (int64_t)a.NQ * a.G;
+  if (i < npairs) {
+    const int q = (int)(i / a.G), g = (int)(i % a.G);
+    const unsigned long long *b = a.bins + (size_t)q * a.total_bins;
+    const int x0 = a.genome_bin[g], x1 = a.genome_bin[g + 1];
+    int cnt = 0;
+    float sum = 0.0f;
+    for (int x = x0; x < x1; x += 512) {
+      unsigned long long v[8];
 #pragma unroll
-    for (int src = 0; src < 64; src++) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane(bits, src));
+      for (int u = 0; u < 8; u++) v[u] = (x + 64 * u + lane < x1) ? b[x + 64 * u + lane] : 0ULL;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint64_t any = __ballot(v[u] != 0ULL);
+        if (any == 0) continue;                                    // wave-uniform
+        cnt += __popcll(any);
+        // empty bins hold +0.0f and x + 0.0f == x exactly, so adding all 64 lanes in lane order IS the reference's
+        // sequential sum over the non-empty bins; constant lane indices keep the chain at one v_readlane + v_add each
+        const int bits = (int)(uint32_t)(v[u] >> 32);
+#pragma unroll
+        for (int src = 0; src < 64; src++) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane(bits, src));
+      }
+    }
+    if (lane == 0) {
+      a.row_count[i] = cnt;
+      a.row_ident[i] = cnt ? sum / (float)cnt : 0.0f;
+    }
   }
-  if (lane == 0) {
-    row_count[i] = cnt;
-    row_ident[i] = cnt ? sum / (float)cnt : 0.0f;
+  if (!a.emit) return;
+  // ---- last workgroup done: rows of the whole pass ----
+  __shared__ int sh_last, sh_run, sh_wave[4];
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) sh_last = atomicAdd(a.done, 1u) == gridDim.x - 1;
+  __syncthreads();
+  if (!sh_last) return;
+  __threadfence();
+  if (threadIdx.x == 0) sh_run = 0;
+  __syncthreads();
+  const volatile int32_t *rc = a.row_count;
+  const volatile float *ri = a.row_ident;
+  const int n = (int)npairs;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int p = i0 + threadIdx.x;
+    const int c = p < n ? rc[p] : 0;
+    const bool keep = c != 0;
+    const uint64_t bal = __ballot(keep);
+    if (lane == 0) sh_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = sh_run + __popcll(bal & ((1ULL << lane) - 1ULL));
+    for (int w = 0; w < wv; w++) off += sh_wave[w];
+    if (keep && off < a.cap) {
+      fa_cgi_row r;
+      r.query_id = a.query_id_base + p / a.G;
+      r.ref_genome_id = p % a.G;
+      r.count_seq = c;
+      r.total_query_fragments = a.query_total_frag[p / a.G];
+      r.identity = ri[p];
+      a.rows[off] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh_run += sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *a.total_rows = sh_run;
 }
 
 // ordered compaction of the non-empty (query, genome) pairs into fa_cgi_row records
@@ -1087,39 +1149,6 @@ __global__ __launch_bounds__(256) void k_clear(ClearArgs a) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (int r = 0; r < a.count; r++)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n16[r]; i += stride) a.ptr[r][i] = make_uint4(0, 0, 0, 0);
-}
-
-// Rows of a small pass (one workgroup): flag the non-empty (query, genome) pairs, scan, emit -- in (query, genome) order.
-__global__ __launch_bounds__(1024) void k_emit_rows_small(const int32_t *row_count, const float *row_ident, int G, int n,
-                                                          const int32_t *query_total_frag, int32_t query_id_base, fa_cgi_row *rows,
-                                                          int64_t cap, int32_t *total_rows) {
-  __shared__ int sh_wave[16];
-  __shared__ int sh_run;
-  if (threadIdx.x == 0) sh_run = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  for (int i0 = 0; i0 < n; i0 += 1024) {
-    const int i = i0 + threadIdx.x;
-    const bool keep = i < n && row_count[i] != 0;
-    const uint64_t bal = __ballot(keep);
-    if (lane == 0) sh_wave[wv] = __popcll(bal);
-    __syncthreads();
-    int off = sh_run + __popcll(bal & ((1ULL << lane) - 1ULL));
-    for (int q = 0; q < wv; q++) off += sh_wave[q];
-    if (keep && off < cap) {
-      fa_cgi_row r;
-      r.query_id = query_id_base + i / G;
-      r.ref_genome_id = i % G;
-      r.count_seq = row_count[i];
-      r.total_query_fragments = query_total_frag[i / G];
-      r.identity = row_ident[i];
-      rows[off] = r;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) { int tot = 0; for (int q = 0; q < 16; q++) tot += sh_wave[q]; sh_run += tot; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total_rows = sh_run;
 }
 
 }  // namespace fa
