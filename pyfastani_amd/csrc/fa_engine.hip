@@ -262,6 +262,7 @@ struct fa_mapper {
   DevBuf<uint8_t> rec_flags;
   DevBuf<uint32_t> rec_geo;       // packed window geometry + flags for k_l2_events (empty when cmw >= 8191)
   DevBuf<uint16_t> rec_prev16;
+  DevBuf<int2> rec_sw;            // (rec_seq, rec_wpos) interleaved for k_l1
   bool packed_geo = false;
   int64_t N = 0, U = 0;
   int32_t C = 0, G = 0, table_bits = 4, freq_threshold = INT_MAX, total_bins = 0;
@@ -306,7 +307,7 @@ struct fa_mapper {
   IndexView view() const {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
-    v.rec_geo = packed_geo ? rec_geo.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr;
+    v.rec_geo = packed_geo ? rec_geo.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_sw = rec_sw.p;
     v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.table = table.p;
     v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
     v.N = N; v.U = U; v.C = C; v.G = G; v.table_bits = table_bits; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
@@ -435,6 +436,8 @@ static void build_index(fa_mapper &m) {
                        m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
     hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, m.contig_rec.p, N, m.cmw,
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
+    m.rec_sw.ensure((size_t)N + 4);
+    hipLaunchKernelGGL(k_interleave_seq_wpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, N, m.rec_sw.p);
     m.packed_geo = m.cmw + 1 < (1 << GEO_BITS);
     if (m.packed_geo) {
       m.rec_geo.ensure((size_t)N + 4); m.rec_prev16.ensure((size_t)N + 4);
@@ -470,7 +473,7 @@ static void ensure_luts(fa_mapper &m, int smax) {
 
 // seed hits of one fragment sorted in LDS by k_l1 (12 bytes each: two buffers + list ids); more go through HBM scratch
 static uint32_t lds_seed_cap_max(int smax) {
-  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 5 * 4 - ((int64_t)smax + 2) * 4 - 16;
+  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 5 * 4 - ((int64_t)smax + 2) * 8 - 32;
   return (uint32_t)std::max<int64_t>(256, room / 12 / 256 * 256);
 }
 

@@ -226,6 +226,11 @@ __global__ void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, 
   }
 }
 
+__global__ void k_interleave_seq_wpos(const int32_t *rec_seq, const int32_t *rec_wpos, int64_t N, int2 *rec_sw) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) rec_sw[i] = make_int2(rec_seq[i], rec_wpos[i]);
+}
+
 // The same geometry packed for the hot loop of k_l2_events (fewer bytes per record, fewer loads): one 32-bit word
 //   geo[i] = (rec_fwd[i+1] - (i+1)) | (i - rec_bwd[i]) << 13 | flags << 26,   both distances are <= cmw < 8192,
 // and prev16[i] = min(i - rec_prev[i], 65535) (65535 also for "no earlier record with this hash in the contig": only
@@ -254,6 +259,7 @@ struct IndexView {
   const uint8_t *rec_flags;
   const uint32_t *rec_geo;      // packed geometry (k_pack_geometry), null when cmw is too large for it
   const uint16_t *rec_prev16;
+  const int2 *rec_sw;           // (rec_seq, rec_wpos) interleaved: one 8-byte gather per seed hit in k_l1
   const uint32_t *uniq_hash;
   const uint32_t *uniq_off;
   const uint32_t *pos_ridx;
@@ -388,13 +394,13 @@ struct L1Args {
   uint32_t lds_seed_cap;
 };
 
-// dynamic LDS of k_l1: seeds [cap] + their list ids [cap, 16-bit], the list offsets [lut_smax + 2], the staged loci (5 arrays
+// dynamic LDS of k_l1: seeds [cap] + their list ids [cap, 16-bit], the list offsets and sources [lut_smax + 2 each], the staged loci (5 arrays
 // of L1_STAGE), and -- only when a fragment can exceed what the in-place merge holds in registers -- a second pair of
 // seed / list-id buffers
 constexpr int L1_INPLACE = 16;    // elements per thread the in-place merge keeps in registers
 __host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 6 + 15) / 16 * 16; }
 __host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax) {
-  return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 4 + 15) / 16 * 16;
+  return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 8 + 15) / 16 * 16;   // list offsets + list sources
 }
 __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int threads) {
   const size_t base = l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 5 * 4;
@@ -429,6 +435,7 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
     uint32_t *A = (uint32_t *)lds;
     uint16_t *R = (uint16_t *)(A + cap);                                 // list every element came from
     uint32_t *off = (uint32_t *)(lds + l1_off_offset(cap));             // [s + 1] first seed of every list
+    uint32_t *qo = off + a.lut_smax + 2;                                 // [s] where every list starts in the index
     if (tid == 0) sh_run = 0;
     __syncthreads();
     for (int j0 = 0; j0 < s; j0 += NT) {
@@ -440,19 +447,26 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       __syncthreads();
       uint32_t o = sh_run + incl - cnt;
       for (int q = 0; q < wv; q++) o += sh_scan[q];
-      if (j < s) off[j] = o;
+      if (j < s) { off[j] = o; qo[j] = cnt ? a.q_off[(size_t)f * a.qcap + j] : 0u; }
       __syncthreads();
       if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
       __syncthreads();
     }
     if (tid == 0) off[s] = n;
     __syncthreads();
-    const uint32_t *qoff = a.q_off + (size_t)f * a.qcap;
-    for (uint32_t i = tid; i < n; i += NT) {
-      int lo = 0, hi = s - 1;                                            // the list j with off[j] <= i < off[j + 1]
+    // flat gather, two elements per thread and trip so that two index reads are in flight
+    auto locate = [&](uint32_t i) __attribute__((always_inline)) {
+      int lo = 0, hi = s - 1;                                              // the list j with off[j] <= i < off[j + 1]
       while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid + 1] <= i) lo = mid + 1; else hi = mid; }
-      A[i] = a.ix.pos_ridx[qoff[lo] + (i - off[lo])];
-      R[i] = (uint16_t)lo;
+      return lo;
+    };
+    for (uint32_t i0 = tid; i0 < n; i0 += 2 * NT) {
+      const uint32_t i1 = i0 + NT;
+      const int j0 = locate(i0), j1 = i1 < n ? locate(i1) : 0;
+      const uint32_t v0 = a.ix.pos_ridx[qo[j0] + (i0 - off[j0])];
+      const uint32_t v1 = i1 < n ? a.ix.pos_ridx[qo[j1] + (i1 - off[j1])] : 0u;
+      A[i0] = v0; R[i0] = (uint16_t)j0;
+      if (i1 < n) { A[i1] = v1; R[i1] = (uint16_t)j1; }
     }
     __syncthreads();
     // one merge step for the element at position i: where it lands in the run merged from its own and the sibling run
@@ -547,15 +561,23 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   for (int pass = 0; pass < 2; pass++) {
     if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
     __syncthreads();
+    // (contig, window) of the seed this thread owns in the first trip; later trips are fetched one trip ahead
+    uint32_t ra_n = tid < n ? seeds[tid] : 0u;
+    int2 sw_n = tid < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
     for (uint32_t i0 = 0; i0 < ncand; i0 += NT) {
       uint32_t i = i0 + tid;
       bool flag = false;
-      int seq = -1, wa = 0, start = 0;
-      uint32_t ra = 0;
+      int start = 0;
       // every lane fetches (contig, window) of its own seed once; the partner seed i+m-1 comes from a neighbour lane
-      if (i < n) { ra = seeds[i]; seq = a.ix.rec_seq[ra]; wa = a.ix.rec_wpos[ra]; }
+      const uint32_t ra = ra_n;
+      const int seq = sw_n.x, wa = sw_n.y;
+      if (i0 + NT < ncand) {
+        const uint32_t in = i + NT;
+        ra_n = in < n ? seeds[in] : 0u;
+        sw_n = in < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
+      }
       int seqb = __shfl(seq, (lane + m - 1) & 63), wb = __shfl(wa, (lane + m - 1) & 63);
-      if (lane + m - 1 >= 64 && i < ncand) { const uint32_t rb = seeds[i + m - 1]; seqb = a.ix.rec_seq[rb]; wb = a.ix.rec_wpos[rb]; }
+      if (lane + m - 1 >= 64 && i < ncand) { const int2 swb = a.ix.rec_sw[seeds[i + m - 1]]; seqb = swb.x; wb = swb.y; }
       if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
