@@ -275,11 +275,20 @@ struct fa_mapper {
   DevBuf<float> d_ident;
   // workspace
   SketchWork sk;
-  DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf, counters;
-  DevBuf<int32_t> q_size, stats_dev, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
+  DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf;
+  // every small counter / statistic of a pass in ONE device block, mirrored into pinned host memory by one copy
+  struct Status {
+    int32_t stats[4];                 // [0] largest query sketch
+    int32_t total_rows, pad0[3];
+    uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
+    uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
+    unsigned long long pinfo[4];      // slide events reserved, speculation flags
+  };
+  DevBuf<Status> status;
+  Status *h_status = nullptr;         // pinned
+  DevBuf<int32_t> q_size, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
   DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
   DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
-  DevBuf<unsigned long long> pinfo;
   // data-dependent sizes speculated from earlier passes (see run_query_pass)
   struct Spec {
     bool init = false;
@@ -293,7 +302,6 @@ struct fa_mapper {
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo;
   uint64_t last_items = 0;
-  DevBuf<uint64_t> totals;
   DevBuf<unsigned long long> group_best, bins;
   DevBuf<float> row_ident;
   DevBuf<fa_cgi_row> rows_dev;
@@ -579,7 +587,13 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
     m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
     m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
-    m.stats_dev.ensure(8); m.totals.ensure(8); m.counters.ensure(8); m.pinfo.ensure(8);
+    m.status.ensure(1);
+    if (!m.h_status) FA_HIP(hipHostMalloc((void **)&m.h_status, sizeof(fa_mapper::Status), hipHostMallocDefault));
+    int32_t *const d_stats = m.status.p->stats;
+    uint64_t *const d_totals = m.status.p->totals;
+    uint32_t *const d_counters = m.status.p->counters;
+    unsigned long long *const d_pinfo = m.status.p->pinfo;
+    int32_t *const d_total_rows = &m.status.p->total_rows;
     // ---- buffers and tables sized by the speculated bounds ----
     const int smax = sp.smax;
     FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
@@ -599,8 +613,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     FA_HIP(hipEventRecord(m.ev[0], st));
     {
       ClearList cl;
-      cl.add(m.stats_dev.p, 4 * sizeof(int32_t)); cl.add(m.totals.p, 4 * sizeof(uint64_t));
-      cl.add(m.counters.p, 8 * sizeof(uint32_t)); cl.add(m.pinfo.p, 4 * sizeof(unsigned long long));
+      cl.add(m.status.p, sizeof(fa_mapper::Status));
       cl.add(m.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(m.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(m.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
       if (npairs > 0 && first_part) cl.add(m.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
@@ -613,7 +626,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
       a.tile_count = m.sk.tile_count.p; a.stage_hash = m.sk.stage_hash.p; a.stage_wpos = m.sk.stage_wpos.p;
       a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
-      a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = m.stats_dev.p; a.qcap = qcap;
+      a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = d_stats; a.qcap = qcap;
       a.sort_cap = (int32_t)(qs_lds / 4);
       if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
       hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
@@ -624,10 +637,10 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     {
       LookupArgs a;
       a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
-      a.n_seeds = m.n_seeds.p; a.totals = m.totals.p; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
+      a.n_seeds = m.n_seeds.p; a.totals = d_totals; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
       hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
-      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, seed_slots, m.totals.p, m.ovf_off.p,
-                         m.stats_dev.p, smax, sp.scratch_words, m.pinfo.p);
+      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, seed_slots, d_totals, m.ovf_off.p,
+                         d_stats, smax, sp.scratch_words, d_pinfo);
     }
     debug_sync(st, "lookup");
     // ---- L1 ----
@@ -637,8 +650,8 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.ovf_off = m.ovf_off.p; a.ovf_buf = m.ovf_buf.p; a.min_hits_lut = m.d_min_hits.p;
       a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
       a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p;
-      a.counters = m.counters.p; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
-      a.lds_seed_cap = seed_slots; a.pinfo = m.pinfo.p; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
+      a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
+      a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
       constexpr int L1_THREADS = 256;
       const size_t lds = l1_lds_bytes(seed_slots, smax, L1_THREADS);   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
@@ -654,13 +667,13 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
       a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p; a.frag_len = m.P.fragment_length;
       a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_nev = m.l_nev.p; a.l_ioff = m.l_ioff.p; a.l_ndrop = m.l_ndrop.p;
-      a.items = m.items.p; a.items_cap = sp.items_cap; a.pinfo = m.pinfo.p; a.l_cap = (int32_t)l_cap;
+      a.items = m.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
       a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
-      a.counters = m.counters.p; a.qcap = qcap; a.cmw = m.cmw;
+      a.counters = d_counters; a.qcap = qcap; a.cmw = m.cmw;
       a.cnt_slots = smax + 1;
-      a.rec_total = (unsigned long long *)(m.totals.p + 3);
+      a.rec_total = (unsigned long long *)(d_totals + 3);
       a.l_redo = m.l_redo.p;
-      a.redo_count = m.counters.p + 3;
+      a.redo_count = d_counters + 3;
       a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
       a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
       const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
@@ -714,7 +727,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     int32_t total_rows = 0;
     if (npairs > 0) {
       CgiArgs a;
-      a.ix = ix; a.group_best = m.group_best.p; a.counters = m.counters.p; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
+      a.ix = ix; a.group_best = m.group_best.p; a.counters = d_counters; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
       a.l_pos = m.l_pos.p; a.q_size = m.q_size.p; a.ident_lut = m.d_ident.p;
       a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = m.bins.p;
       a.bin_len = m.P.fragment_length - 20;
@@ -726,16 +739,15 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       ra.bins = m.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
       ra.row_count = m.row_count.p; ra.row_ident = m.row_ident.p;
       ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
-      ra.done = m.counters.p + 4; ra.query_total_frag = g.d_total_frag.p + g0; ra.query_id_base = g0;
-      ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = m.row_off.p;
+      ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag.p + g0; ra.query_id_base = g0;
+      ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = d_total_rows;
       hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
       if (ra.emit) {
-        FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       } else {
         hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
         FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
         exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
-        FA_HIP(hipMemcpyAsync(&total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        FA_HIP(hipMemcpyAsync(d_total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
                            npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
       }
@@ -744,16 +756,14 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     debug_sync(st, "cgi");
     FA_HIP(hipEventRecord(m.ev[4], st));
     // ---- the one synchronisation of the pass: results, statistics and the speculation verdict ----
-    int32_t h_stats[4];
-    uint64_t h_totals[4];
-    uint32_t h_counters[4];
-    unsigned long long h_pinfo[4];
-    m.stats_dev.download(h_stats, 4, st);
-    m.totals.download(h_totals, 4, st);
-    m.counters.download(h_counters, 4, st);
-    m.pinfo.download(h_pinfo, 4, st);
+    FA_HIP(hipMemcpyAsync(m.h_status, m.status.p, sizeof(fa_mapper::Status), hipMemcpyDeviceToHost, st));
     FA_HIP(hipEventRecord(m.ev[5], st));
     FA_HIP(hipStreamSynchronize(st));
+    const int32_t *h_stats = m.h_status->stats;
+    const uint64_t *h_totals = m.h_status->totals;
+    const uint32_t *h_counters = m.h_status->counters;
+    const unsigned long long *h_pinfo = m.h_status->pinfo;
+    total_rows = m.h_status->total_rows;
     const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
     const unsigned long long flags = h_pinfo[1];
     // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
@@ -1151,6 +1161,7 @@ void fa_mapper_free(fa_mapper *m) {
   if (!m) return;
   for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
   if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->h_status) (void)hipHostFree(m->h_status);
   delete m;
 }
 int fa_mapper_freq_threshold(fa_mapper *m, int *thr) { *thr = m->freq_threshold; return FA_OK; }
