@@ -861,7 +861,9 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
     const int64_t nfrag = len / frag;
     if (nfrag > 0) { use_ptr.push_back(contigs[c]); use_len.push_back(nfrag * frag); use_contig.push_back(c); }   // the tail past the last whole fragment is never read
   }
+  StageTrace tr("upload_genomes");
   hs.append_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width);
+  tr.mark("pack", st);
   // pass 2: fragments, tiles and per-genome bookkeeping, in contig order
   int32_t cur = 0;
   size_t used = 0;
@@ -889,6 +891,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   g->F = (int64_t)frag_query.size();
   g->frag_tile_lo.push_back((int32_t)tiles.size());
   g->ntiles = (int64_t)tiles.size();
+  tr.mark("fragments_tiles", st);
   g->store.upload(hs, st);
   g->tiles.upload(tiles, st);
   g->d_frag_tile_lo.upload(g->frag_tile_lo, st);
@@ -900,6 +903,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   for (int i = 0; i < n_genomes; i++) tf[i] = (int32_t)g->total_fragments[i];
   g->d_total_frag.upload(tf, st);
   FA_HIP(hipStreamSynchronize(st));
+  tr.mark("uploads", st);
   return g;
 }
 
