@@ -655,8 +655,14 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
       constexpr int L1_THREADS = 256;
       const size_t lds = l1_lds_bytes(seed_slots, smax, L1_THREADS);   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
-      if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(k_l1<L1_THREADS>, dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
+      // fragments of up to E x 256 seed hits are merged in place; E = 16 costs fewer registers (more fragments per CU)
+      if (seed_slots <= 16 * L1_THREADS) {
+        if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_l1<L1_THREADS, 16>), dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
+      } else {
+        if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_l1<L1_THREADS, 32>), dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
+      }
     }
     debug_sync(st, "l1");
     FA_HIP(hipEventRecord(m.ev[2], st));
@@ -767,6 +773,7 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
     const unsigned long long flags = h_pinfo[1];
     // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
+    if (flags || (h_counters[3] > 0 && !sp.redo)) m.last_ms[9] += 1.0f;   // repeated attempts of this call (speculation misses)
     auto shrink_part = [&](double have, double limit, const char *what) {
       FA_REQUIRE(F > 1, FA_ERR_UNSUPPORTED, std::string("a single query fragment produces too many ") + what);
       sp.part_frags = std::max<int64_t>(1, std::min<int64_t>(F / 2, (int64_t)((double)F * limit / have * 0.8)));

@@ -397,18 +397,19 @@ struct L1Args {
 // dynamic LDS of k_l1: seeds [cap] + their list ids [cap, 16-bit], the list offsets and sources [lut_smax + 2 each], the staged loci (5 arrays
 // of L1_STAGE), and -- only when a fragment can exceed what the in-place merge holds in registers -- a second pair of
 // seed / list-id buffers
-constexpr int L1_INPLACE = 16;    // elements per thread the in-place merge keeps in registers
+constexpr int L1_INPLACE_MAX = 32;  // most elements per thread the in-place merge keeps in registers (template parameter E: 16 or 32)
 __host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 6 + 15) / 16 * 16; }
 __host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax) {
   return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 8 + 15) / 16 * 16;   // list offsets + list sources
 }
 __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int threads) {
   const size_t base = l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 5 * 4;
-  return seed_cap > (uint32_t)(L1_INPLACE * threads) ? base + (size_t)seed_cap * 6 : base;
+  return seed_cap > (uint32_t)(L1_INPLACE_MAX * threads) ? base + (size_t)seed_cap * 6 : base;
 }
 
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
-template <int NT>
+// E = elements per thread the in-place merge can hold (16 for small fragments: fewer registers, more workgroups per CU).
+template <int NT, int E>
 __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sh_scan[NT / 64];
@@ -480,23 +481,22 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (src[mid] < x) lo = mid + 1; else hi = mid; }
       return a0 + (i - own) + (lo - sib);
     };
-    if (n <= (uint32_t)(L1_INPLACE * NT)) {
-      // in place: every thread keeps its (at most L1_INPLACE) elements in registers across the barrier that separates
-      // the reads of a level from its writes -- 6 bytes of LDS per seed, which keeps 6-7 workgroups on a CU
+    if (n <= (uint32_t)(E * NT)) {
+      // in place: every thread keeps its (at most E) elements in registers across the barrier that separates the reads
+      // of a level from its writes -- 6 bytes of LDS per seed, which keeps several workgroups on a CU
       for (int k = 0; (1 << k) < s; k++) {
-        uint32_t xs[L1_INPLACE], ds[L1_INPLACE];
-        int js[L1_INPLACE];
+        uint32_t xs[E], pk[E];                                           // element, destination | list id << 16
 #pragma unroll
-        for (int e = 0; e < L1_INPLACE; e++) {
+        for (int e = 0; e < E; e++) {
           const uint32_t i = tid + e * NT;
-          xs[e] = 0; ds[e] = 0; js[e] = 0;
-          if (i < n) { xs[e] = A[i]; js[e] = R[i]; ds[e] = place(A, i, k, xs[e], js[e]); }
+          xs[e] = 0; pk[e] = 0;
+          if (i < n) { xs[e] = A[i]; const int j = R[i]; pk[e] = place(A, i, k, xs[e], j) | ((uint32_t)j << 16); }
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < L1_INPLACE; e++) {
+        for (int e = 0; e < E; e++) {
           const uint32_t i = tid + e * NT;
-          if (i < n) { A[ds[e]] = xs[e]; R[ds[e]] = (uint16_t)js[e]; }
+          if (i < n) { A[pk[e] & 0xFFFFu] = xs[e]; R[pk[e] & 0xFFFFu] = (uint16_t)(pk[e] >> 16); }
         }
         __syncthreads();
       }

@@ -36,7 +36,13 @@ t0 = time.time()
 batch = mapper.upload_genomes([[s] for s in genomes])
 t_upload = time.time() - t0
 t0 = time.time()
-rows = [batch.query_rows(i, min(chunk, n - i)) for i in range(0, n, chunk)]
+import ctypes as C
+from pyfastani_amd._lib import lib
+rows, retries, phase = [], 0, np.zeros(5)
+for i in range(0, n, chunk):
+    rows.append(batch.query_rows(i, min(chunk, n - i)))
+    ms = (C.c_float * 16)(); lib.fa_mapper_last_timings(mapper._h, ms, 16)
+    retries += int(ms[9]); phase += np.array(list(ms)[:5])
 t_map = time.time() - t0
 rows = np.concatenate(rows)
 fam = np.array(fam)
@@ -56,5 +62,5 @@ print(json.dumps({
     "pairs": n * n, "rows": int(len(rows)), "hits_after_min_fraction": int(len(hits)), "index_minimizers": n_min, "threshold": mapper.occurences_threshold,
     "generate_s": t_gen, "host_pack_s": t_pack, "sketch_index_s": t_index, "upload_queries_s": t_upload, "map_s": t_map,
     "pairs_per_s_map_only": n * n / t_map, "pairs_per_s_with_index": n * n / (t_map + t_index + t_upload + t_pack),
-    "self_hits_exact": ok_self, "hits_within_family": ok_family, "membership_symmetric": ok_sym,
+    "repeated_attempts": retries, "device_phase_ms": dict(zip(["sketch", "lookup_l1", "l2", "cgi", "total"], [float(x) for x in phase])), "self_hits_exact": ok_self, "hits_within_family": ok_family, "membership_symmetric": ok_sym,
 }))
