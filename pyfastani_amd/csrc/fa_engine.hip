@@ -1020,17 +1020,17 @@ void fa_fasta_close(fa_fasta *f) { delete f; }
 int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int64_t *n_short) {
   return guarded([&] {
     FA_REQUIRE(path, FA_ERR_INVALID, "null path");
-    std::vector<std::vector<uint8_t>> seqs;
-    read_fasta_records(path, seqs, host_threads());
+    std::vector<FastaSeq> seqs;
+    read_fasta_records(path, seqs);
     std::lock_guard<std::mutex> lock(s->mtx);
     std::vector<const void *> ptrs;
     std::vector<int64_t> lens;
     int64_t shorts = 0;
     for (auto &q : seqs) {
-      const int64_t length = (int64_t)q.size();
+      const int64_t length = (int64_t)q.size;
       FA_REQUIRE(length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
       if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
-        ptrs.push_back(q.data()); lens.push_back(length);
+        ptrs.push_back(q.data.get()); lens.push_back(length);
         s->pending_contig.push_back((int32_t)s->counter);
       } else {
         shorts++;
@@ -1248,13 +1248,13 @@ int fa_genomes_upload(fa_mapper *m, const void *const *contigs, const int64_t *l
 int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_paths, fa_genomes **out) {
   return guarded([&] {
     FA_REQUIRE(n_paths >= 0, FA_ERR_INVALID, "negative count");
-    std::vector<std::vector<std::vector<uint8_t>>> files((size_t)n_paths);
+    std::vector<std::vector<FastaSeq>> files((size_t)n_paths);
     std::vector<const void *> ptrs;
     std::vector<int64_t> lens;
     std::vector<int32_t> genome;
     for (int32_t i = 0; i < n_paths; i++) {
-      read_fasta_records(paths[i], files[i], host_threads());
-      for (auto &q : files[i]) { ptrs.push_back(q.data()); lens.push_back((int64_t)q.size()); genome.push_back(i); }
+      read_fasta_records(paths[i], files[i]);
+      for (auto &q : files[i]) { ptrs.push_back(q.data.get()); lens.push_back((int64_t)q.size); genome.push_back(i); }
     }
     std::lock_guard<std::mutex> lock(m->mtx);
     *out = upload_genomes(m->P, m->stream, ptrs.data(), lens.data(), genome.data(), (int64_t)ptrs.size(), n_paths, 1).release();

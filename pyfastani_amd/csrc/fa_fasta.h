@@ -15,11 +15,13 @@
 #include <cerrno>
 #include <cstdint>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
 
 #include "fa_common.h"
+#include "fa_sketch.hip.h"   // HostPool
 
 namespace fa {
 
@@ -71,10 +73,14 @@ struct FastaFile {
     // fgets(line, 2048): at most 2047 characters, and the reference insists that the last one is the newline
     if (!nl || line_len > 2047) throw Error(FA_ERR_BUFFER, "FASTA identifier too large for the line buffer");
     sp.header = pos; sp.header_end = pos + line_len; sp.body = sp.header_end;
+    // the next header is a '>' at a line start; sequence lines hold no '>', so this is normally one memchr per record
     size_t p = sp.body;
-    while (p < size && data[p] != '>') {
-      const char *e = (const char *)memchr(data + p, '\n', size - p);
-      p = e ? (size_t)(e - data) + 1 : size;
+    while (p < size) {
+      const char *e = (const char *)memchr(data + p, '>', size - p);
+      if (!e) { p = size; break; }
+      p = (size_t)(e - data);
+      if (p == sp.body || data[p - 1] == '\n') break;
+      p++;
     }
     sp.body_end = p;
     pos = p;
@@ -108,23 +114,61 @@ struct FastaFile {
   }
 };
 
-// every record of a file: boundaries found serially (memchr speed), bodies joined and upper-cased by a pool of threads
-inline void read_fasta_records(const char *path, std::vector<std::vector<uint8_t>> &seqs, int threads) {
+// Every record of a file.  Boundaries are found serially (memchr speed); the bodies are then cut into pieces of about
+// 256 KiB that start at line starts, every piece counts the bytes it will produce, and after a prefix sum all pieces
+// are joined + upper-cased in parallel straight into place -- a genome that is ONE long record still uses every thread.
+struct FastaSeq {
+  std::unique_ptr<uint8_t[]> data;   // not value-initialised: the pieces below write every byte
+  size_t size = 0;
+};
+
+inline void read_fasta_records(const char *path, std::vector<FastaSeq> &seqs) {
   FastaFile f;
   f.open(path);
   std::vector<FastaFile::Span> spans;
   FastaFile::Span sp;
   while (f.next_span(sp)) spans.push_back(sp);
-  seqs.assign(spans.size(), {});
-  const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), spans.size()));
-  if (nt <= 1) {
-    for (size_t i = 0; i < spans.size(); i++) FastaFile::fill_seq(f.data, spans[i], seqs[i]);
-  } else {
-    std::vector<std::thread> pool;
-    for (int t = 0; t < nt; t++)
-      pool.emplace_back([&, t] { for (size_t i = (size_t)t; i < spans.size(); i += (size_t)nt) FastaFile::fill_seq(f.data, spans[i], seqs[i]); });
-    for (auto &th : pool) th.join();
+  seqs.clear();
+  seqs.resize(spans.size());
+  struct Piece { size_t rec, lo, hi, out, count; };
+  std::vector<Piece> pieces;
+  const size_t PIECE = 256 * 1024;
+  for (size_t r = 0; r < spans.size(); r++) {
+    size_t p = spans[r].body;
+    while (p < spans[r].body_end) {
+      size_t q = std::min(spans[r].body_end, p + PIECE);
+      if (q < spans[r].body_end) {                       // extend to the end of the line
+        const char *e = (const char *)memchr(f.data + q, '\n', spans[r].body_end - q);
+        q = e ? (size_t)(e - f.data) + 1 : spans[r].body_end;
+      }
+      pieces.push_back({r, p, q, 0, 0});
+      p = q;
+    }
   }
+  const char *data = f.data;
+  HostPool::get().parallel_for(pieces.size(), [&](size_t i) {
+    Piece &pc = pieces[i];
+    size_t nl = 0;
+    for (const char *c = data + pc.lo, *end = data + pc.hi; (c = (const char *)memchr(c, '\n', (size_t)(end - c))) != nullptr; c++) nl++;
+    pc.count = (pc.hi - pc.lo) - nl;
+  });
+  std::vector<size_t> total(spans.size(), 0);
+  for (auto &pc : pieces) { pc.out = total[pc.rec]; total[pc.rec] += pc.count; }
+  for (size_t r = 0; r < spans.size(); r++) { seqs[r].size = total[r]; seqs[r].data.reset(new uint8_t[std::max<size_t>(total[r], 1)]); }
+  HostPool::get().parallel_for(pieces.size(), [&](size_t i) {
+    const Piece &pc = pieces[i];
+    uint8_t *dst = seqs[pc.rec].data.get() + pc.out;
+    size_t p = pc.lo;
+    while (p < pc.hi) {
+      const char *e = (const char *)memchr(data + p, '\n', pc.hi - p);
+      const size_t end = e ? (size_t)(e - data) : pc.hi;
+      for (size_t k = p; k < end; k++) {
+        const uint8_t c = (uint8_t)data[k];
+        *dst++ = (c >= 'a' && c <= 'z') ? (uint8_t)(c - 32) : c;
+      }
+      p = e ? end + 1 : end;
+    }
+  });
 }
 
 }  // namespace fa

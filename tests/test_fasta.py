@@ -20,6 +20,25 @@ def test_records_ids_and_upper_casing(tmp_path):
     assert all(isinstance(r, Record) and isinstance(r.seq, bytes) and isinstance(r.id, str) for r in recs)
 
 
+def test_greater_than_inside_a_line_is_sequence(tmp_path):
+    recs = list(Parser(write(tmp_path, "gt.fa", b">a\nAC>GT\nTT\n>b\nGG\n")))
+    assert [(r.id, r.seq) for r in recs] == [("a", b"AC>GTTT"), ("b", b"GG")]
+
+
+def test_add_fasta_counts_records_and_short_contigs(tmp_path):
+    # host-side part of Sketch.add_fasta (no device needed until the sketch is flushed): one genome per file, a record
+    # shorter than the window is reported like add_draft reports it
+    import warnings
+    import pyfastani_amd as pf
+    body = (b"ACGTTGCA" * 10 + b"\n") * 400
+    path = write(tmp_path, "g.fna", b">c1\n" + body + b">c2 short\nACGT\n>c3\n" + body)
+    sk = pf.Sketch()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sk.add_fasta("genome", path)
+    assert sk.names == ["genome"] and len(w) == 1 and "short" in str(w[0].message)
+
+
 def test_crlf_is_kept_like_the_reference(tmp_path):
     # only the '\n' is stripped (_fasta.pyx:95-96): a carriage return stays in the id and in the sequence
     recs = list(Parser(write(tmp_path, "crlf.fa", b">id\r\nAC\r\nGT\r\n")))
