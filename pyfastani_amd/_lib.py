@@ -118,6 +118,9 @@ def _share_hip_runtime_with_torch():
     also works but is pathologically slow (torch then registers its thousands of kernels with a live runtime: 10 s to
     minutes, measured), hence the eager import.  ``FA_SYSTEM_HIP=1`` skips it and keeps the system runtime (no torch
     interoperability in that process)."""
+    # concurrent query calls each use their own stream; the runtime's default of 4 hardware queues would put several of
+    # them on one queue (measured: two part streams serialised), so ask for more before HIP starts
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if os.environ.get("FA_SYSTEM_HIP"):
         return
     try:

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -248,6 +249,48 @@ struct fa_genomes {
   DevBuf<int32_t> d_frag_tile_lo, d_frag_query, d_frag_qseq, d_total_frag;
 };
 
+// Every small counter / statistic of a pass in ONE device block, mirrored into pinned host memory by one copy.
+struct PassStatus {
+  int32_t stats[4];                 // [0] largest query sketch
+  int32_t total_rows, pad0[3];
+  uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
+  uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
+  unsigned long long pinfo[4];      // slide events reserved, speculation flags
+};
+
+// Everything one query call owns: its stream, every intermediate of the pipeline, its status block and timing events.
+struct Workspace {
+  bool in_use = false;
+  hipStream_t stream = nullptr;
+  SketchWork sk;
+  DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf;
+  DevBuf<PassStatus> status;
+  PassStatus *h_status = nullptr;     // pinned
+  DevBuf<int32_t> q_size, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
+  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
+  DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
+  DevBuf<unsigned char> items;
+  DevBuf<uint8_t> l_redo;
+  DevBuf<unsigned long long> group_best, bins;
+  DevBuf<float> row_ident;
+  DevBuf<fa_cgi_row> rows_dev;
+  // LUT pointers captured for the call (the mapper may publish larger tables while this call is in flight)
+  const int32_t *lut_min_hits = nullptr, *lut_pass = nullptr;
+  const float *lut_ident = nullptr;
+  // last-pass bookkeeping for the debug getters
+  int64_t last_F = 0, last_f0 = 0;
+  uint32_t last_loci = 0;
+  uint64_t last_items = 0;
+  const fa_genomes *last_genomes = nullptr;
+  float last_ms[16] = {0};
+  hipEvent_t ev[6] = {nullptr};
+  ~Workspace() {
+    for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (h_status) (void)hipHostFree(h_status);
+  }
+};
+
 // ------------------------------------------------------------------------------------------------------------
 // fa_mapper: the indexed reference + the workspace of the query pipeline
 // ------------------------------------------------------------------------------------------------------------
@@ -273,23 +316,7 @@ struct fa_mapper {
   StatTables stats;
   DevBuf<int32_t> d_min_hits, d_pass;
   DevBuf<float> d_ident;
-  // workspace
-  SketchWork sk;
-  DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf;
-  // every small counter / statistic of a pass in ONE device block, mirrored into pinned host memory by one copy
-  struct Status {
-    int32_t stats[4];                 // [0] largest query sketch
-    int32_t total_rows, pad0[3];
-    uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
-    uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
-    unsigned long long pinfo[4];      // slide events reserved, speculation flags
-  };
-  DevBuf<Status> status;
-  Status *h_status = nullptr;         // pinned
-  DevBuf<int32_t> q_size, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
-  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
-  DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
-  // data-dependent sizes speculated from earlier passes (see run_query_pass)
+  // data-dependent sizes speculated from earlier passes (see run_query_pass); shared by all workspaces, guarded by mtx
   struct Spec {
     bool init = false;
     int smax = 0;
@@ -299,18 +326,16 @@ struct fa_mapper {
     int64_t part_frags = 0;   // fragments per part of a pass (shrinks when a part overflows the 32-bit workspace)
     bool redo = false;        // launch the wide-state scan as well (set once a locus overflowed the one-byte state)
   } spec;
-  DevBuf<unsigned char> items;
-  DevBuf<uint8_t> l_redo;
-  uint64_t last_items = 0;
-  DevBuf<unsigned long long> group_best, bins;
-  DevBuf<float> row_ident;
-  DevBuf<fa_cgi_row> rows_dev;
-  // last-pass bookkeeping for the debug getters
-  int64_t last_F = 0, last_f0 = 0;
-  uint32_t last_loci = 0;
-  const fa_genomes *last_genomes = nullptr;
-  float last_ms[16] = {0};
-  hipEvent_t ev[6] = {nullptr};
+  // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
+  // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
+  // which is worth ~27 % of throughput over strictly serial calls).  `mtx` guards the pool, the speculation record and
+  // the LUTs; the index itself is read-only.
+  static constexpr int NWS = 4;
+  Workspace ws[NWS];
+  std::condition_variable ws_free;
+  int last_ws = 0;                    // workspace of the most recent call (stage getters, timings)
+  std::vector<DevBuf<int32_t>> retired_i32;   // LUT generations still referenced by calls in flight
+  std::vector<DevBuf<float>> retired_f32;
 
   IndexView view() const {
     IndexView v;
@@ -471,11 +496,15 @@ static void build_index(fa_mapper &m) {
 // ------------------------------------------------------------------------------------------------------------
 // query pipeline over the fragment range [f0, f1) of a resident batch
 // ------------------------------------------------------------------------------------------------------------
+// (Re)builds the LUTs for sketches up to smax.  Called with m.mtx held; calls in flight keep the tables they captured
+// (older generations are retired, not freed), so the tables can grow while other workspaces are busy.
 static void ensure_luts(fa_mapper &m, int smax) {
   if (m.stats.extend(std::max(smax, 1))) {
+    if (m.d_min_hits.p) { m.retired_i32.push_back(std::move(m.d_min_hits)); m.retired_i32.push_back(std::move(m.d_pass)); m.retired_f32.push_back(std::move(m.d_ident)); }
     m.d_min_hits.upload(m.stats.min_hits, m.stream);
     m.d_pass.upload(m.stats.pass_shared, m.stream);
     m.d_ident.upload(m.stats.ident, m.stream);
+    FA_HIP(hipStreamSynchronize(m.stream));
   }
 }
 
@@ -538,33 +567,55 @@ static int64_t pass_fragments() {
 // alone holds more fragments than pass_fragments(), or when the loci / seeds / slide events of the range exceed what
 // the 32-bit offsets of the workspace can address: the parts share the CGI bin table (step 2 of computeCGI is an
 // atomicMax, so it simply accumulates) and the rows are formed after the last part.
-static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
+static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
                               int64_t row_base) {
-  hipStream_t st = m.stream;
+  hipStream_t st = w.stream;
   const int64_t range_f0 = g.genome_frag_lo[g0], range_f1 = g.genome_frag_lo[g1];
   const int NQ = g1 - g0;
-  m.last_F = 0; m.last_f0 = range_f0; m.last_loci = 0; m.last_genomes = &g;
-  for (int i = 0; i < 6; i++) if (!m.ev[i]) FA_HIP(hipEventCreate(&m.ev[i]));
+  w.last_F = 0; w.last_f0 = range_f0; w.last_loci = 0; w.last_genomes = &g;
+  for (int i = 0; i < 6; i++) if (!w.ev[i]) FA_HIP(hipEventCreate(&w.ev[i]));
   if (range_f1 == range_f0) return 0;
   FA_REQUIRE(m.P.fragment_length > 20, FA_ERR_UNSUPPORTED, "fragment_length must exceed 20 (the reference bins by fragment_length - 20)");
   const int qcap = m.qcap;
   const IndexView ix = m.view();
   const int64_t npairs = (int64_t)NQ * m.G;
-  fa_mapper::Spec &sp = m.spec;
-  if (!sp.init) {
-    sp.init = true;
-    sp.smax = 256;
-    sp.seed_slots = 4096;
-    sp.scratch_words = 0;
-    sp.l_cap = (int64_t)env_u64("FA_LOCI_CAP_MIN", 1u << 18);   // the tests force the retry path with a tiny value
-    sp.items_cap = env_u64("FA_EVENTS_CAP_MIN", 1u << 26);
-    sp.part_frags = pass_fragments();
-  }
+  // the speculated bounds are shared by all workspaces: every attempt works on a copy taken under the lock and
+  // publishes what it learnt (bounds only ever grow, except the LDS seed slots, which follow the latest pass)
+  fa_mapper::Spec sp;
+  auto fetch_spec = [&] {
+    std::lock_guard<std::mutex> lock(m.mtx);
+    fa_mapper::Spec &ms = m.spec;
+    if (!ms.init) {
+      ms.init = true;
+      ms.smax = 256;
+      ms.seed_slots = 4096;
+      ms.scratch_words = 0;
+      ms.l_cap = (int64_t)env_u64("FA_LOCI_CAP_MIN", 1u << 18);   // the tests force the retry path with a tiny value
+      ms.items_cap = env_u64("FA_EVENTS_CAP_MIN", 1u << 26);
+      ms.part_frags = pass_fragments();
+    }
+    sp = ms;
+    FA_REQUIRE(sp.smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
+    ensure_luts(m, sp.smax);
+    w.lut_min_hits = m.d_min_hits.p; w.lut_pass = m.d_pass.p; w.lut_ident = m.d_ident.p;
+  };
+  auto publish_spec = [&] {
+    std::lock_guard<std::mutex> lock(m.mtx);
+    fa_mapper::Spec &ms = m.spec;
+    ms.smax = std::max(ms.smax, sp.smax);
+    ms.seed_slots = sp.seed_slots;
+    ms.scratch_words = std::max(ms.scratch_words, sp.scratch_words);
+    ms.items_cap = std::max(ms.items_cap, sp.items_cap);
+    ms.l_cap = std::max(ms.l_cap, sp.l_cap);
+    ms.part_frags = std::min(ms.part_frags, sp.part_frags);
+    ms.redo = ms.redo || sp.redo;
+  };
+  fetch_spec();
   // event offsets are 32-bit: at most this many slide events per part (FA_EVENTS_CAP_MAX: the tests force the split)
   const uint64_t items_max = env_u64("FA_EVENTS_CAP_MAX", (1ULL << 32) - 64);
-  m.bins.ensure((size_t)NQ * std::max(m.total_bins, 1) + 2);
-  m.row_count.ensure((size_t)npairs + 1); m.row_ident.ensure((size_t)npairs + 1);
-  m.row_flag.ensure((size_t)npairs + 1); m.row_off.ensure((size_t)npairs + 1);
+  w.bins.ensure((size_t)NQ * std::max(m.total_bins, 1) + 2);
+  w.row_count.ensure((size_t)npairs + 1); w.row_ident.ensure((size_t)npairs + 1);
+  w.row_flag.ensure((size_t)npairs + 1); w.row_off.ensure((size_t)npairs + 1);
   const size_t qs_lds = (size_t)next_pow2((uint32_t)std::max(qcap, 2)) * 4;
   FA_REQUIRE(qs_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
 
@@ -574,85 +625,84 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   while (f0 < range_f1) {
     FA_REQUIRE(attempt < 40, FA_ERR_INTERNAL, "query pass did not converge on its buffer sizes");
     attempt++;
+    if (attempt > 1 || f0 != range_f0) fetch_spec();
     const int64_t f1 = std::min(range_f1, f0 + std::max<int64_t>(1, sp.part_frags));
     const int64_t F = f1 - f0;
     const bool first_part = f0 == range_f0, last_part = f1 == range_f1;
-    m.last_F = F; m.last_f0 = f0;
+    w.last_F = F; w.last_f0 = f0;
     const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
     const int ntiles = t1 - t0;
     // buffers whose size depends only on the geometry of the part
-    m.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
-    m.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
-    m.sk.tile_count.ensure((size_t)ntiles + 1);
-    m.q_hash.ensure((size_t)F * qcap); m.q_off.ensure((size_t)F * qcap); m.q_cnt.ensure((size_t)F * qcap);
-    m.q_size.ensure((size_t)F); m.n_seeds.ensure((size_t)F); m.ovf_off.ensure((size_t)F);
-    m.f_loci_lo.ensure((size_t)F); m.f_loci_n.ensure((size_t)F);
-    m.status.ensure(1);
-    if (!m.h_status) FA_HIP(hipHostMalloc((void **)&m.h_status, sizeof(fa_mapper::Status), hipHostMallocDefault));
-    int32_t *const d_stats = m.status.p->stats;
-    uint64_t *const d_totals = m.status.p->totals;
-    uint32_t *const d_counters = m.status.p->counters;
-    unsigned long long *const d_pinfo = m.status.p->pinfo;
-    int32_t *const d_total_rows = &m.status.p->total_rows;
+    w.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
+    w.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
+    w.sk.tile_count.ensure((size_t)ntiles + 1);
+    w.q_hash.ensure((size_t)F * qcap); w.q_off.ensure((size_t)F * qcap); w.q_cnt.ensure((size_t)F * qcap);
+    w.q_size.ensure((size_t)F); w.n_seeds.ensure((size_t)F); w.ovf_off.ensure((size_t)F);
+    w.f_loci_lo.ensure((size_t)F); w.f_loci_n.ensure((size_t)F);
+    w.status.ensure(1);
+    if (!w.h_status) FA_HIP(hipHostMalloc((void **)&w.h_status, sizeof(PassStatus), hipHostMallocDefault));
+    int32_t *const d_stats = w.status.p->stats;
+    uint64_t *const d_totals = w.status.p->totals;
+    uint32_t *const d_counters = w.status.p->counters;
+    unsigned long long *const d_pinfo = w.status.p->pinfo;
+    int32_t *const d_total_rows = &w.status.p->total_rows;
     // ---- buffers and tables sized by the speculated bounds ----
     const int smax = sp.smax;
-    FA_REQUIRE(smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
-    ensure_luts(m, smax);
     const int64_t l_cap = sp.l_cap;
     const uint32_t seed_slots = std::min(sp.seed_slots, lds_seed_cap_max(smax));   // LDS also holds smax list offsets
-    m.l_frag.ensure((size_t)l_cap); m.l_seq.ensure((size_t)l_cap); m.l_start.ensure((size_t)l_cap); m.l_end.ensure((size_t)l_cap + 4);
-    m.l_rfirst.ensure((size_t)l_cap); m.l_rlast.ensure((size_t)l_cap + 4);
-    m.l_group.ensure((size_t)l_cap); m.l_shared.ensure((size_t)l_cap); m.l_pos.ensure((size_t)l_cap);
-    m.group_best.ensure((size_t)l_cap + 2);
-    m.l_beg.ensure((size_t)l_cap); m.l_end0.ensure((size_t)l_cap); m.l_last.ensure((size_t)l_cap); m.l_ndrop.ensure((size_t)l_cap);
-    m.l_nev.ensure((size_t)l_cap); m.l_ioff.ensure((size_t)l_cap); m.l_redo.ensure((size_t)l_cap + 4);
-    m.ovf_buf.ensure((size_t)sp.scratch_words + 4);
+    w.l_frag.ensure((size_t)l_cap); w.l_seq.ensure((size_t)l_cap); w.l_start.ensure((size_t)l_cap); w.l_end.ensure((size_t)l_cap + 4);
+    w.l_rfirst.ensure((size_t)l_cap); w.l_rlast.ensure((size_t)l_cap + 4);
+    w.l_group.ensure((size_t)l_cap); w.l_shared.ensure((size_t)l_cap); w.l_pos.ensure((size_t)l_cap);
+    w.group_best.ensure((size_t)l_cap + 2);
+    w.l_beg.ensure((size_t)l_cap); w.l_end0.ensure((size_t)l_cap); w.l_last.ensure((size_t)l_cap); w.l_ndrop.ensure((size_t)l_cap);
+    w.l_nev.ensure((size_t)l_cap); w.l_ioff.ensure((size_t)l_cap); w.l_redo.ensure((size_t)l_cap + 4);
+    w.ovf_buf.ensure((size_t)sp.scratch_words + 4);
     const bool wide = smax > 1022;                                      // slot = rank + 1 must fit the 10-bit field
-    m.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
+    w.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
 
-    FA_HIP(hipEventRecord(m.ev[0], st));
+    FA_HIP(hipEventRecord(w.ev[0], st));
     {
       ClearList cl;
-      cl.add(m.status.p, sizeof(fa_mapper::Status));
-      cl.add(m.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(m.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
-      cl.add(m.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
-      if (npairs > 0 && first_part) cl.add(m.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
+      cl.add(w.status.p, sizeof(PassStatus));
+      cl.add(w.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(w.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
+      cl.add(w.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
+      if (npairs > 0 && first_part) cl.add(w.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
       cl.launch(st);
     }
     // ---- K1 + per-fragment sort/unique ----
-    launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, m.sk.stage_hash.p, m.sk.stage_wpos.p, m.sk.tile_count.p, st);
+    launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, st);
     {
       QuerySketchArgs a;
       a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
-      a.tile_count = m.sk.tile_count.p; a.stage_hash = m.sk.stage_hash.p; a.stage_wpos = m.sk.stage_wpos.p;
+      a.tile_count = w.sk.tile_count.p; a.stage_hash = w.sk.stage_hash.p; a.stage_wpos = w.sk.stage_wpos.p;
       a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
-      a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.stats = d_stats; a.qcap = qcap;
+      a.q_hash = w.q_hash.p; a.q_size = w.q_size.p; a.stats = d_stats; a.qcap = qcap;
       a.sort_cap = (int32_t)(qs_lds / 4);
       if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
       hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
     }
     debug_sync(st, "sketch");
-    FA_HIP(hipEventRecord(m.ev[1], st));
+    FA_HIP(hipEventRecord(w.ev[1], st));
     // ---- lookup, seed totals and speculation checks ----
     {
       LookupArgs a;
-      a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p;
-      a.n_seeds = m.n_seeds.p; a.totals = d_totals; a.ovf_off = m.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
+      a.ix = ix; a.q_hash = w.q_hash.p; a.q_size = w.q_size.p; a.q_off = w.q_off.p; a.q_cnt = w.q_cnt.p;
+      a.n_seeds = w.n_seeds.p; a.totals = d_totals; a.ovf_off = w.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
       hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
-      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, m.n_seeds.p, F, seed_slots, d_totals, m.ovf_off.p,
+      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, w.n_seeds.p, F, seed_slots, d_totals, w.ovf_off.p,
                          d_stats, smax, sp.scratch_words, d_pinfo);
     }
     debug_sync(st, "lookup");
     // ---- L1 ----
     {
       L1Args a;
-      a.ix = ix; a.q_size = m.q_size.p; a.q_off = m.q_off.p; a.q_cnt = m.q_cnt.p; a.n_seeds = m.n_seeds.p;
-      a.ovf_off = m.ovf_off.p; a.ovf_buf = m.ovf_buf.p; a.min_hits_lut = m.d_min_hits.p;
-      a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
-      a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p;
+      a.ix = ix; a.q_size = w.q_size.p; a.q_off = w.q_off.p; a.q_cnt = w.q_cnt.p; a.n_seeds = w.n_seeds.p;
+      a.ovf_off = w.ovf_off.p; a.ovf_buf = w.ovf_buf.p; a.min_hits_lut = w.lut_min_hits;
+      a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p; a.l_start = w.l_start.p; a.l_end = w.l_end.p; a.l_group = w.l_group.p;
+      a.l_rfirst = w.l_rfirst.p; a.l_rlast = w.l_rlast.p;
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
-      a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
+      a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
       constexpr int L1_THREADS = 256;
       const size_t lds = l1_lds_bytes(seed_slots, smax, L1_THREADS);   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
       // fragments of up to E x 256 seed hits are merged in place; E = 16 costs fewer registers (more fragments per CU)
@@ -665,22 +715,22 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       }
     }
     debug_sync(st, "l1");
-    FA_HIP(hipEventRecord(m.ev[2], st));
+    FA_HIP(hipEventRecord(w.ev[2], st));
     // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
     {
       L2Args a;
-      a.ix = ix; a.q_hash = m.q_hash.p; a.q_size = m.q_size.p;
-      a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p; a.l_start = m.l_start.p; a.l_end = m.l_end.p; a.l_group = m.l_group.p;
-      a.l_rfirst = m.l_rfirst.p; a.l_rlast = m.l_rlast.p; a.frag_len = m.P.fragment_length;
-      a.l_beg = m.l_beg.p; a.l_end0 = m.l_end0.p; a.l_last = m.l_last.p; a.l_nev = m.l_nev.p; a.l_ioff = m.l_ioff.p; a.l_ndrop = m.l_ndrop.p;
-      a.items = m.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
-      a.l_shared = m.l_shared.p; a.l_pos = m.l_pos.p; a.pass_lut = m.d_pass.p; a.group_best = m.group_best.p;
+      a.ix = ix; a.q_hash = w.q_hash.p; a.q_size = w.q_size.p;
+      a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p; a.l_start = w.l_start.p; a.l_end = w.l_end.p; a.l_group = w.l_group.p;
+      a.l_rfirst = w.l_rfirst.p; a.l_rlast = w.l_rlast.p; a.frag_len = m.P.fragment_length;
+      a.l_beg = w.l_beg.p; a.l_end0 = w.l_end0.p; a.l_last = w.l_last.p; a.l_nev = w.l_nev.p; a.l_ioff = w.l_ioff.p; a.l_ndrop = w.l_ndrop.p;
+      a.items = w.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
+      a.l_shared = w.l_shared.p; a.l_pos = w.l_pos.p; a.pass_lut = w.lut_pass; a.group_best = w.group_best.p;
       a.counters = d_counters; a.qcap = qcap; a.cmw = m.cmw;
       a.cnt_slots = smax + 1;
       a.rec_total = (unsigned long long *)(d_totals + 3);
-      a.l_redo = m.l_redo.p;
+      a.l_redo = w.l_redo.p;
       a.redo_count = d_counters + 3;
-      a.f_loci_lo = m.f_loci_lo.p; a.f_loci_n = m.f_loci_n.p;
+      a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
       a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
       const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
       FA_REQUIRE(ev_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
@@ -728,57 +778,57 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
       }
     }
     debug_sync(st, "l2 scan");
-    FA_HIP(hipEventRecord(m.ev[3], st));
+    FA_HIP(hipEventRecord(w.ev[3], st));
     // ---- core-genome identity ----
     int32_t total_rows = 0;
     if (npairs > 0) {
       CgiArgs a;
-      a.ix = ix; a.group_best = m.group_best.p; a.counters = d_counters; a.l_frag = m.l_frag.p; a.l_seq = m.l_seq.p;
-      a.l_pos = m.l_pos.p; a.q_size = m.q_size.p; a.ident_lut = m.d_ident.p;
-      a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = m.bins.p;
+      a.ix = ix; a.group_best = w.group_best.p; a.counters = d_counters; a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p;
+      a.l_pos = w.l_pos.p; a.q_size = w.q_size.p; a.ident_lut = w.lut_ident;
+      a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = w.bins.p;
       a.bin_len = m.P.fragment_length - 20;
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
     }
     if (npairs > 0 && last_part) {
       RowsArgs ra;
-      ra.bins = m.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
-      ra.row_count = m.row_count.p; ra.row_ident = m.row_ident.p;
+      ra.bins = w.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
+      ra.row_count = w.row_count.p; ra.row_ident = w.row_ident.p;
       ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
       ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag.p + g0; ra.query_id_base = g0;
       ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = d_total_rows;
       hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
       if (ra.emit) {
       } else {
-        hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, npairs, m.row_flag.p);
-        FA_HIP(hipMemsetAsync(m.row_flag.p + npairs, 0, sizeof(int32_t), st));
-        exclusive_sum_i32(m.sk.cub_temp, m.row_flag.p, m.row_off.p, (int)npairs + 1, st);
-        FA_HIP(hipMemcpyAsync(d_total_rows, m.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, m.row_count.p, m.row_ident.p, m.row_off.p, m.G,
+        hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, npairs, w.row_flag.p);
+        FA_HIP(hipMemsetAsync(w.row_flag.p + npairs, 0, sizeof(int32_t), st));
+        exclusive_sum_i32(w.sk.cub_temp, w.row_flag.p, w.row_off.p, (int)npairs + 1, st);
+        FA_HIP(hipMemcpyAsync(d_total_rows, w.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, w.row_ident.p, w.row_off.p, m.G,
                            npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
       }
     }
     FA_HIP(hipGetLastError());
     debug_sync(st, "cgi");
-    FA_HIP(hipEventRecord(m.ev[4], st));
+    FA_HIP(hipEventRecord(w.ev[4], st));
     // ---- the one synchronisation of the pass: results, statistics and the speculation verdict ----
-    FA_HIP(hipMemcpyAsync(m.h_status, m.status.p, sizeof(fa_mapper::Status), hipMemcpyDeviceToHost, st));
-    FA_HIP(hipEventRecord(m.ev[5], st));
+    FA_HIP(hipMemcpyAsync(w.h_status, w.status.p, sizeof(PassStatus), hipMemcpyDeviceToHost, st));
+    FA_HIP(hipEventRecord(w.ev[5], st));
     FA_HIP(hipStreamSynchronize(st));
-    const int32_t *h_stats = m.h_status->stats;
-    const uint64_t *h_totals = m.h_status->totals;
-    const uint32_t *h_counters = m.h_status->counters;
-    const unsigned long long *h_pinfo = m.h_status->pinfo;
-    total_rows = m.h_status->total_rows;
+    const int32_t *h_stats = w.h_status->stats;
+    const uint64_t *h_totals = w.h_status->totals;
+    const uint32_t *h_counters = w.h_status->counters;
+    const unsigned long long *h_pinfo = w.h_status->pinfo;
+    total_rows = w.h_status->total_rows;
     const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
     const unsigned long long flags = h_pinfo[1];
     // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
-    if (flags || (h_counters[3] > 0 && !sp.redo)) m.last_ms[9] += 1.0f;   // repeated attempts of this call (speculation misses)
+    if (flags || (h_counters[3] > 0 && !sp.redo)) w.last_ms[9] += 1.0f;   // repeated attempts of this call (speculation misses)
     auto shrink_part = [&](double have, double limit, const char *what) {
       FA_REQUIRE(F > 1, FA_ERR_UNSUPPORTED, std::string("a single query fragment produces too many ") + what);
       sp.part_frags = std::max<int64_t>(1, std::min<int64_t>(F / 2, (int64_t)((double)F * limit / have * 0.8)));
     };
-    if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); continue; }
+    if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); publish_spec(); continue; }
     // bounds for the next pass (or the repeat of this one)
     if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 16 + 31) / 32 * 32;
     // LDS slots for the seed sort: a quarter of headroom over the largest fragment seen, (LDS per workgroup sets how many fragments a CU works on at once)
@@ -788,30 +838,31 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
     if (flags & SPEC_LOCI) {
       const int64_t want = std::max<int64_t>(sp.l_cap * 2, (int64_t)h_counters[0] + h_counters[0] / 4);
       const int64_t l_max = (1LL << 31) - 64;
-      if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); continue; }
+      if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); publish_spec(); continue; }
       sp.l_cap = std::min(want, l_max);
     }
     if (flags & SPEC_EVENTS) {
-      if (h_pinfo[0] > items_max) { shrink_part((double)h_pinfo[0], (double)items_max, "slide events"); continue; }
+      if (h_pinfo[0] > items_max) { shrink_part((double)h_pinfo[0], (double)items_max, "slide events"); publish_spec(); continue; }
       sp.items_cap = std::min<uint64_t>(items_max, std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4));
     }
-    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; continue; }   // void part: run it again
-    if (h_counters[3] > 0 && !sp.redo) { sp.redo = true; continue; }   // loci overflowed the byte state and the wide pass was not launched
+    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; publish_spec(); continue; }   // void part: run it again
+    if (h_counters[3] > 0 && !sp.redo) { sp.redo = true; publish_spec(); continue; }   // loci overflowed the byte state and the wide pass was not launched
     if (slots_changed) {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;
     }
+    publish_spec();
     // ---- accepted ----
     float ms;
-    for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, m.ev[i], m.ev[i + 1])); m.last_ms[i] += ms; }
-    FA_HIP(hipEventElapsedTime(&ms, m.ev[0], m.ev[5]));
-    m.last_ms[4] += ms;
-    m.last_loci = h_counters[0];
-    m.last_items = h_pinfo[0];
-    m.last_ms[5] += (float)h_totals[3];   // reference records inside the locus ranges of this call (roofline line)
-    m.last_ms[6] += (float)h_counters[0];
-    m.last_ms[7] += (float)h_pinfo[0];    // slide events
-    m.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
+    for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, w.ev[i], w.ev[i + 1])); w.last_ms[i] += ms; }
+    FA_HIP(hipEventElapsedTime(&ms, w.ev[0], w.ev[5]));
+    w.last_ms[4] += ms;
+    w.last_loci = h_counters[0];
+    w.last_items = h_pinfo[0];
+    w.last_ms[5] += (float)h_totals[3];   // reference records inside the locus ranges of this call (roofline line)
+    w.last_ms[6] += (float)h_counters[0];
+    w.last_ms[7] += (float)h_pinfo[0];    // slide events
+    w.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
     if (last_part) nrows = total_rows;
     f0 = f1;
     attempt = 0;
@@ -820,27 +871,50 @@ static int64_t run_query_pass(fa_mapper &m, const fa_genomes &g, int32_t g0, int
   return nrows;
 }
 
-static int64_t run_query(fa_mapper &m, const fa_genomes &g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap, bool rows_device) {
+static int64_t run_query(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap, bool rows_device) {
   require_device();
   FA_REQUIRE(first >= 0 && count >= 0 && first + count <= g.n_genomes, FA_ERR_INVALID, "genome range out of bounds");
-  for (float &x : m.last_ms) x = 0;
+  for (float &x : w.last_ms) x = 0;
   fa_cgi_row *dst = rows;
-  if (!rows_device) { m.rows_dev.ensure((size_t)std::max<int64_t>(cap, 1)); dst = m.rows_dev.p; }
+  if (!rows_device) { w.rows_dev.ensure((size_t)std::max<int64_t>(cap, 1)); dst = w.rows_dev.p; }
   int64_t nrows = 0;
   int32_t g0 = first;
   while (g0 < first + count) {
     int32_t g1 = g0 + 1;
     while (g1 < first + count && g.genome_frag_lo[g1 + 1] - g.genome_frag_lo[g0] <= pass_fragments()) g1++;
     // frag_query is batch-wide: the bins of a pass are indexed by (genome - g0), handled through the pointer offset below
-    nrows += run_query_pass(m, g, g0, g1, dst, cap, nrows);
+    nrows += run_query_pass(m, w, g, g0, g1, dst, cap, nrows);
     g0 = g1;
   }
   if (!rows_device && nrows) {
-    FA_HIP(hipMemcpyAsync(rows, m.rows_dev.p, (size_t)nrows * sizeof(fa_cgi_row), hipMemcpyDeviceToHost, m.stream));
-    FA_HIP(hipStreamSynchronize(m.stream));
+    FA_HIP(hipMemcpyAsync(rows, w.rows_dev.p, (size_t)nrows * sizeof(fa_cgi_row), hipMemcpyDeviceToHost, w.stream));
+    FA_HIP(hipStreamSynchronize(w.stream));
   }
   return nrows;
 }
+
+// A query call borrows one workspace of the mapper for its duration (blocks while all are busy).
+struct WorkspaceLease {
+  fa_mapper &m;
+  Workspace *w = nullptr;
+  int index = -1;
+  explicit WorkspaceLease(fa_mapper &mm) : m(mm) {
+    std::unique_lock<std::mutex> lock(m.mtx);
+    for (;;) {
+      for (int i = 0; i < fa_mapper::NWS; i++) if (!m.ws[i].in_use) { index = i; break; }
+      if (index >= 0) break;
+      m.ws_free.wait(lock);
+    }
+    w = &m.ws[index];
+    w->in_use = true;
+    lock.unlock();
+    if (!w->stream) FA_HIP(hipStreamCreate(&w->stream));
+  }
+  ~WorkspaceLease() {
+    { std::lock_guard<std::mutex> lock(m.mtx); w->in_use = false; m.last_ws = index; }
+    m.ws_free.notify_one();
+  }
+};
 
 // pack + cut into fragments + tiles + upload
 static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
@@ -1170,10 +1244,8 @@ int fa_sketch_index(fa_sketch *s, fa_mapper **out) {
 
 void fa_mapper_free(fa_mapper *m) {
   if (!m) return;
-  for (auto &e : m->ev) if (e) (void)hipEventDestroy(e);
   if (m->stream) (void)hipStreamDestroy(m->stream);
-  if (m->h_status) (void)hipHostFree(m->h_status);
-  delete m;
+  delete m;   // the workspaces release their own streams, events and pinned blocks
 }
 int fa_mapper_freq_threshold(fa_mapper *m, int *thr) { *thr = m->freq_threshold; return FA_OK; }
 int fa_mapper_lookup_size(fa_mapper *m, int64_t *n) { *n = m->U; return FA_OK; }
@@ -1273,36 +1345,37 @@ int fa_genomes_info(fa_genomes *g, int32_t *n_genomes, uint64_t *tf, uint64_t *t
 int fa_mapper_query_genomes(fa_mapper *m, fa_genomes *g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap,
                             int64_t *n_rows, int rows_device) {
   return guarded([&] {
-    std::lock_guard<std::mutex> lock(m->mtx);
-    *n_rows = run_query(*m, *g, first, count, rows, cap, rows_device != 0);
+    WorkspaceLease lease(*m);
+    *n_rows = run_query(*m, *lease.w, *g, first, count, rows, cap, rows_device != 0);
   });
 }
 int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *lengths, int n_contigs, int char_width,
                     fa_cgi_row *rows, int64_t cap, int64_t *n_rows, int *n_short, uint64_t *total_fragments,
                     uint64_t *total_length) {
   return guarded([&] {
-    std::lock_guard<std::mutex> lock(m->mtx);
+    WorkspaceLease lease(*m);
     std::vector<int32_t> cg((size_t)std::max(n_contigs, 1), 0);
-    auto g = upload_genomes(m->P, m->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width);
+    auto g = upload_genomes(m->P, lease.w->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width);
     if (n_short) *n_short = g->n_short[0];
     if (total_fragments) *total_fragments = g->total_fragments[0];
     if (total_length) *total_length = g->total_length[0];
-    *n_rows = run_query(*m, *g, 0, 1, rows, cap, false);
-    m->last_genomes = nullptr;
+    *n_rows = run_query(*m, *lease.w, *g, 0, 1, rows, cap, false);
+    lease.w->last_genomes = nullptr;
   });
 }
 
 int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t *n) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
-    const uint32_t L = m->last_loci;
-    std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)m->last_F);
+    Workspace &w = m->ws[m->last_ws];
+    const uint32_t L = w.last_loci;
+    std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)w.last_F);
     if (L) {
-      m->l_frag.download(lf.data(), L, m->stream); m->l_seq.download(ls.data(), L, m->stream);
-      m->l_pos.download(lp.data(), L, m->stream); m->l_shared.download(lsh.data(), L, m->stream);
+      w.l_frag.download(lf.data(), L, w.stream); w.l_seq.download(ls.data(), L, w.stream);
+      w.l_pos.download(lp.data(), L, w.stream); w.l_shared.download(lsh.data(), L, w.stream);
     }
-    if (m->last_F) m->q_size.download(qs.data(), (size_t)m->last_F, m->stream);
-    FA_HIP(hipStreamSynchronize(m->stream));
+    if (w.last_F) w.q_size.download(qs.data(), (size_t)w.last_F, w.stream);
+    FA_HIP(hipStreamSynchronize(w.stream));
     ensure_luts(*m, 1);
     int64_t k = 0;
     for (uint32_t i = 0; i < L; i++) {
@@ -1321,25 +1394,27 @@ int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t
 int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *rs, int32_t *re, int64_t cap, int64_t *n) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
-    const uint32_t L = m->last_loci;
+    Workspace &w = m->ws[m->last_ws];
+    const uint32_t L = w.last_loci;
     *n = L;
     size_t c = (size_t)std::min<int64_t>(L, cap);
     if (c) {
-      m->l_frag.download(frag, c, m->stream); m->l_seq.download(seq_id, c, m->stream);
-      m->l_start.download(rs, c, m->stream); m->l_end.download(re, c, m->stream);
-      FA_HIP(hipStreamSynchronize(m->stream));
+      w.l_frag.download(frag, c, w.stream); w.l_seq.download(seq_id, c, w.stream);
+      w.l_start.download(rs, c, w.stream); w.l_end.download(re, c, w.stream);
+      FA_HIP(hipStreamSynchronize(w.stream));
     }
   });
 }
 int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashes, int32_t cap, int32_t *sketch_size) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
-    FA_REQUIRE(fragment >= 0 && fragment < m->last_F, FA_ERR_INVALID, "fragment out of range");
+    Workspace &w = m->ws[m->last_ws];
+    FA_REQUIRE(fragment >= 0 && fragment < w.last_F, FA_ERR_INVALID, "fragment out of range");
     int32_t s = 0;
-    FA_HIP(hipMemcpy(&s, m->q_size.p + fragment, 4, hipMemcpyDeviceToHost));
+    FA_HIP(hipMemcpy(&s, w.q_size.p + fragment, 4, hipMemcpyDeviceToHost));
     *sketch_size = s;
     int c = std::min(s, cap);
-    if (c > 0) FA_HIP(hipMemcpy(hashes, m->q_hash.p + (size_t)fragment * m->qcap, (size_t)c * 4, hipMemcpyDeviceToHost));
+    if (c > 0) FA_HIP(hipMemcpy(hashes, w.q_hash.p + (size_t)fragment * m->qcap, (size_t)c * 4, hipMemcpyDeviceToHost));
   });
 }
 int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t length, int char_width, uint32_t *hash,
@@ -1366,34 +1441,36 @@ int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t 
 }
 
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {
-  for (int i = 0; i < n && i < 16; i++) ms[i] = m->last_ms[i];
+  std::lock_guard<std::mutex> lock(m->mtx);
+  for (int i = 0; i < n && i < 16; i++) ms[i] = m->ws[m->last_ws].last_ms[i];
   return FA_OK;
 }
 int fa_mapper_stream(fa_mapper *m, void **stream) { *stream = (void *)m->stream; return FA_OK; }
 
 int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_per_launch, uint64_t *bases, uint64_t *minimizers) {
   return guarded([&] {
-    std::lock_guard<std::mutex> lock(m->mtx);
+    WorkspaceLease lease(*m);
+    Workspace &w = *lease.w;
     require_device();
     const int ntiles = (int)g->ntiles;
     FA_REQUIRE(ntiles > 0 && repeat > 0, FA_ERR_INVALID, "nothing to sketch");
-    m->sk.stage_hash.ensure((size_t)ntiles * TILE);
-    m->sk.stage_wpos.ensure((size_t)ntiles * TILE);
-    m->sk.tile_count.ensure((size_t)ntiles + 1);
+    w.sk.stage_hash.ensure((size_t)ntiles * TILE);
+    w.sk.stage_wpos.ensure((size_t)ntiles * TILE);
+    w.sk.tile_count.ensure((size_t)ntiles + 1);
     hipEvent_t e0, e1;
     FA_HIP(hipEventCreate(&e0)); FA_HIP(hipEventCreate(&e1));
-    launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, m->sk.stage_hash.p, m->sk.stage_wpos.p, m->sk.tile_count.p, m->stream);
-    FA_HIP(hipEventRecord(e0, m->stream));
+    launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
+    FA_HIP(hipEventRecord(e0, w.stream));
     for (int i = 0; i < repeat; i++)
-      launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, m->sk.stage_hash.p, m->sk.stage_wpos.p, m->sk.tile_count.p, m->stream);
-    FA_HIP(hipEventRecord(e1, m->stream));
+      launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
+    FA_HIP(hipEventRecord(e1, w.stream));
     FA_HIP(hipEventSynchronize(e1));
     float ms = 0;
     FA_HIP(hipEventElapsedTime(&ms, e0, e1));
     *ms_per_launch = ms / repeat;
     std::vector<int32_t> counts((size_t)ntiles);
-    m->sk.tile_count.download(counts.data(), (size_t)ntiles, m->stream);
-    FA_HIP(hipStreamSynchronize(m->stream));
+    w.sk.tile_count.download(counts.data(), (size_t)ntiles, w.stream);
+    FA_HIP(hipStreamSynchronize(w.stream));
     uint64_t tot = 0;
     for (int c : counts) tot += (uint64_t)c;
     *minimizers = tot;

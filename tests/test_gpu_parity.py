@@ -796,3 +796,49 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         pf.Sketch().add_fasta("x", files[0])                 # the 6-base contig is reported like add_draft does
     with pytest.raises(OSError):
         pf.Sketch().add_fasta("x", str(tmp_path / "missing.fna"))
+
+
+def test_concurrent_queries_on_one_mapper():
+    """Mapper.query_draft is re-entrant (_fastani.pyx:1158-1161): calls from several host threads run on separate
+    workspaces / streams of the same mapper and must return what serial calls return."""
+    import threading
+    g = syn.rng(777)
+    anc = syn.random_codes(g, 400_000)
+    refs = [syn.to_ascii(syn.mutate_codes(g, anc, d)) for d in (0.0, 0.02, 0.06, 0.11)] + [syn.to_ascii(syn.random_codes(g, 200_000))]
+    sk = pf.Sketch()
+    for i, r in enumerate(refs):
+        sk.add_genome(i, r)
+    mapper = sk.index()
+    queries = [syn.to_ascii(syn.mutate_codes(g, anc, d)) for d in (0.01, 0.03, 0.05, 0.08, 0.12, 0.16)]
+    want = [hit_tuples(mapper.query_genome(q)) for q in queries]
+    got = [[None] * 4 for _ in queries]
+    errors = []
+
+    def worker(qi):
+        try:
+            for rep in range(4):
+                got[qi][rep] = hit_tuples(mapper.query_genome(queries[qi]))
+        except Exception as e:            # noqa: BLE001
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(queries))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for qi in range(len(queries)):
+        assert all(r == want[qi] for r in got[qi]), qi
+    # a resident batch queried from two threads at once
+    batch = mapper.upload_genomes([[q] for q in queries])
+    out = [None, None]
+
+    def half(i):
+        out[i] = [hit_tuples(h) for h in batch.query(3 * i, 3)]
+
+    ts = [threading.Thread(target=half, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert out[0] + out[1] == want
