@@ -140,7 +140,10 @@ int fa_mapper_get_state(fa_mapper *m, uint64_t *lengths, int32_t *sequences_by_f
 /* Mapper._query_draft up to and including computeCGI, _fastani.pyx:1006-1118, for ONE query genome given as
  * host buffers.  rows receive one cgi::CGI_Results per reference genome with at least one mapping, in
  * refGenomeId order; the minimum_fraction filter and the sort (_fastani.pyx:1121-1136) stay with the caller,
- * which owns the names.  *n_short = contigs skipped with the short-sequence warning (:1061-1070). */
+ * which owns the names.  *n_short = contigs skipped with the short-sequence warning (:1061-1070).
+ * Re-entrant like the reference's query (:1158-1161): every call borrows one of the mapper's workspaces (a HIP stream
+ * and every intermediate buffer), so calls from several host threads on ONE mapper overlap on the device; the stage
+ * getters and fa_mapper_last_timings below report the most recently finished call. */
 int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *lengths, int n_contigs, int char_width,
                     fa_cgi_row *rows, int64_t cap, int64_t *n_rows, int *n_short, uint64_t *total_fragments,
                     uint64_t *total_length);

@@ -908,7 +908,13 @@ struct WorkspaceLease {
     w = &m.ws[index];
     w->in_use = true;
     lock.unlock();
-    if (!w->stream) FA_HIP(hipStreamCreate(&w->stream));
+    if (!w->stream && hipStreamCreate(&w->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      w->stream = nullptr;
+      { std::lock_guard<std::mutex> relock(m.mtx); w->in_use = false; }
+      m.ws_free.notify_one();
+      throw Error(FA_ERR_NO_DEVICE, "hipStreamCreate failed");
+    }
   }
   ~WorkspaceLease() {
     { std::lock_guard<std::mutex> lock(m.mtx); w->in_use = false; m.last_ws = index; }
