@@ -45,6 +45,14 @@ static int guarded(F &&fn) {
   }
 }
 
+// The device chosen with fa_set_device (-1: whatever the calling thread has current).  HIP's current device is a
+// per-thread setting, and sketches / mappers are used from any host thread: each object remembers its device and every
+// entry point binds it again.
+static std::atomic<int> g_device{-1};
+static void bind_device(int device) {
+  if (device >= 0) FA_HIP(hipSetDevice(device));
+}
+
 static void require_device() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -141,6 +149,7 @@ static void exclusive_sum_i32(DevBuf<unsigned char> &temp, const int32_t *in, in
 // ------------------------------------------------------------------------------------------------------------
 struct fa_sketch {
   fa_params P;
+  int device = -1;
   hipStream_t stream = nullptr;
   HostStore pending;                      // packed contigs not yet sketched
   std::vector<int32_t> pending_contig;    // contig id of each pending sequence
@@ -164,6 +173,7 @@ struct fa_sketch {
   void flush() {
     if (pending.seq_off.empty()) return;
     require_device();
+    bind_device(device);
     if (!stream) FA_HIP(hipStreamCreate(&stream));
     StageTrace tr("sketch flush");
     DevStore store;
@@ -296,6 +306,7 @@ struct Workspace {
 // ------------------------------------------------------------------------------------------------------------
 struct fa_mapper {
   fa_params P;
+  int device = -1;
   hipStream_t stream = nullptr;
   std::mutex mtx;
   // reference records and index (see fa_map.hip.h for the layout)
@@ -899,6 +910,7 @@ struct WorkspaceLease {
   Workspace *w = nullptr;
   int index = -1;
   explicit WorkspaceLease(fa_mapper &mm) : m(mm) {
+    bind_device(m.device);
     std::unique_lock<std::mutex> lock(m.mtx);
     for (;;) {
       for (int i = 0; i < fa_mapper::NWS; i++) if (!m.ws[i].in_use) { index = i; break; }
@@ -1009,7 +1021,7 @@ int fa_device_count(int *count) {
   return FA_OK;
 }
 int fa_set_device(int device) {
-  return guarded([&] { require_device(); FA_HIP(hipSetDevice(device)); });
+  return guarded([&] { require_device(); FA_HIP(hipSetDevice(device)); g_device.store(device); });
 }
 
 int fa_recommended_window_size(double p_value, int k, int alphabet_size, float identity, int fragment_length,
@@ -1052,6 +1064,7 @@ int fa_sketch_new(const fa_params *params, fa_sketch **out) {
     validate_params(*params);
     std::unique_ptr<fa_sketch> s(new fa_sketch());
     s->P = *params;
+    s->device = g_device.load();
     s->reset_data();
     *out = s.release();
   });
@@ -1066,6 +1079,7 @@ int fa_sketch_add_contig(fa_sketch *s, const void *data, int64_t length, int cha
     FA_REQUIRE(char_width == 1 || char_width == 2 || char_width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
     FA_REQUIRE(length >= 0 && length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     int ok = 0;
     if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
       s->pending.append(data, char_width, length);
@@ -1103,6 +1117,7 @@ int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int6
     std::vector<FastaSeq> seqs;
     read_fasta_records(path, seqs);
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     std::vector<const void *> ptrs;
     std::vector<int64_t> lens;
     int64_t shorts = 0;
@@ -1129,6 +1144,7 @@ int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int6
 int fa_sketch_end_genome(fa_sketch *s) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     s->lengths.push_back(s->cur_total);                  // :687
     s->cur_total = 0;
     s->seqs_by_file.push_back((int32_t)s->counter);      // :690
@@ -1143,6 +1159,7 @@ int fa_sketch_num_minimizers(fa_sketch *s, int64_t *n) {
 int fa_sketch_get_minimizers(fa_sketch *s, uint32_t *hash, int32_t *seq_id, int32_t *wpos) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     s->flush();
     if (s->nrec == 0) return;
     s->rec_hash.download(hash, (size_t)s->nrec, s->stream);
@@ -1157,6 +1174,7 @@ int fa_sketch_num_genomes(fa_sketch *s, int64_t *n) {
 int fa_sketch_get_state(fa_sketch *s, uint64_t *lengths, int32_t *sbf, int64_t *counter) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     for (size_t i = 0; i < s->lengths.size(); i++) { lengths[i] = s->lengths[i]; sbf[i] = s->seqs_by_file[i]; }
     *counter = s->counter;
   });
@@ -1165,12 +1183,14 @@ int fa_sketch_set_state(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths
                         int64_t n_min, const uint32_t *hash, const int32_t *seq_id, const int32_t *wpos) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     s->reset_data();
     s->lengths.assign(lengths, lengths + n_genomes);
     s->seqs_by_file.assign(sbf, sbf + n_genomes);
     s->counter = counter;
     if (n_min > 0) {
       require_device();
+      bind_device(s->device);
       if (!s->stream) FA_HIP(hipStreamCreate(&s->stream));
       s->rec_hash.upload(hash, (size_t)n_min, s->stream);
       s->rec_seq.upload(seq_id, (size_t)n_min, s->stream);
@@ -1188,6 +1208,7 @@ int fa_sketch_set_state(fa_sketch *s, int64_t n_genomes, const uint64_t *lengths
 int fa_sketch_get_minimizers_device(fa_sketch *s, int64_t cap, uint32_t *d_hash, int32_t *d_seq_id, int32_t *d_wpos) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     s->flush();
     FA_REQUIRE(cap >= s->nrec, FA_ERR_INVALID, "destination holds fewer records than the sketch");
     if (s->nrec == 0) return;
@@ -1202,6 +1223,7 @@ int fa_sketch_set_state_device(fa_sketch *s, int64_t n_genomes, const uint64_t *
                                int64_t n_min, const uint32_t *d_hash, const int32_t *d_seq_id, const int32_t *d_wpos) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     FA_REQUIRE(n_min >= 0 && n_genomes >= 0, FA_ERR_INVALID, "negative count");
     s->reset_data();
     s->lengths.assign(lengths, lengths + n_genomes);
@@ -1209,6 +1231,7 @@ int fa_sketch_set_state_device(fa_sketch *s, int64_t n_genomes, const uint64_t *
     s->counter = counter;
     if (n_min > 0) {
       require_device();
+      bind_device(s->device);
       if (!s->stream) FA_HIP(hipStreamCreate(&s->stream));
       const size_t n = (size_t)n_min;
       s->rec_hash.ensure(n); s->rec_seq.ensure(n); s->rec_wpos.ensure(n);
@@ -1224,10 +1247,14 @@ int fa_sketch_set_state_device(fa_sketch *s, int64_t n_genomes, const uint64_t *
 int fa_sketch_index(fa_sketch *s, fa_mapper **out) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
     require_device();
     s->flush();
+    bind_device(s->device);
     std::unique_ptr<fa_mapper> m(new fa_mapper());
     m->P = s->P;
+    m->device = s->device;
+    if (m->device < 0) FA_HIP(hipGetDevice(&m->device));
     FA_HIP(hipStreamCreate(&m->stream));
     m->rec_hash = std::move(s->rec_hash);
     m->rec_seq = std::move(s->rec_seq);
@@ -1258,6 +1285,7 @@ int fa_mapper_lookup_size(fa_mapper *m, int64_t *n) { *n = m->U; return FA_OK; }
 int fa_mapper_lookup_keys(fa_mapper *m, uint32_t *keys) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     m->uniq_hash.download(keys, (size_t)m->U, m->stream);
     FA_HIP(hipStreamSynchronize(m->stream));
   });
@@ -1282,6 +1310,7 @@ static int64_t host_find(fa_mapper *m, uint32_t hash, uint32_t *off, uint32_t *c
 int fa_mapper_lookup_count(fa_mapper *m, uint32_t hash, int64_t *count) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     uint32_t off, cnt;
     *count = host_find(m, hash, &off, &cnt) < 0 ? -1 : (int64_t)cnt;
   });
@@ -1289,6 +1318,7 @@ int fa_mapper_lookup_count(fa_mapper *m, uint32_t hash, int64_t *count) {
 int fa_mapper_lookup_get(fa_mapper *m, uint32_t hash, int32_t *seq_id, int32_t *wpos, int64_t cap) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     uint32_t off, cnt;
     FA_REQUIRE(host_find(m, hash, &off, &cnt) >= 0, FA_ERR_INVALID, "hash not in the lookup index");
     std::vector<uint32_t> ridx(cnt);
@@ -1303,6 +1333,7 @@ int fa_mapper_num_minimizers(fa_mapper *m, int64_t *n) { *n = m->N; return FA_OK
 int fa_mapper_get_minimizers(fa_mapper *m, uint32_t *hash, int32_t *seq_id, int32_t *wpos) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     if (m->N == 0) return;
     m->rec_hash.download(hash, (size_t)m->N, m->stream);
     m->rec_seq.download(seq_id, (size_t)m->N, m->stream);
@@ -1320,6 +1351,7 @@ int fa_genomes_upload(fa_mapper *m, const void *const *contigs, const int64_t *l
                       int64_t n_contigs, int32_t n_genomes, int char_width, fa_genomes **out) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     *out = upload_genomes(m->P, m->stream, contigs, lengths, contig_genome, n_contigs, n_genomes, char_width).release();
   });
 }
@@ -1335,6 +1367,7 @@ int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_pa
       for (auto &q : files[i]) { ptrs.push_back(q.data.get()); lens.push_back((int64_t)q.size); genome.push_back(i); }
     }
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     *out = upload_genomes(m->P, m->stream, ptrs.data(), lens.data(), genome.data(), (int64_t)ptrs.size(), n_paths, 1).release();
   });
 }
@@ -1373,6 +1406,7 @@ int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *len
 int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t *n) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
     const uint32_t L = w.last_loci;
     std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)w.last_F);
@@ -1400,6 +1434,7 @@ int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t
 int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *rs, int32_t *re, int64_t cap, int64_t *n) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
     const uint32_t L = w.last_loci;
     *n = L;
@@ -1414,6 +1449,7 @@ int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *rs
 int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashes, int32_t cap, int32_t *sketch_size) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
     FA_REQUIRE(fragment >= 0 && fragment < w.last_F, FA_ERR_INVALID, "fragment out of range");
     int32_t s = 0;
