@@ -122,36 +122,53 @@ def main():
     batch = mapper.upload_genomes(queries)
     n_pairs_step = args.refs * args.batch
 
-    rows = torch.zeros((max(n_pairs_step, 1), 5), dtype=torch.int32, device="cuda")
+    # Every step maps this rank's query and leaves its hit rows in HBM; the hit tables of all ranks are exchanged ONCE, by a
+    # single all-gather at the end of the timed region -- the only collective of the path (queries are independent).
+    cap_rows = max(n_pairs_step, 1)
+    table = torch.zeros((max(args.steps, args.warmup, 1), cap_rows + 1, 5), dtype=torch.int32, device="cuda")
+    counts = np.zeros(table.shape[0], dtype=np.int32)
+    row_ptr = [table[i, 1:].data_ptr() for i in range(table.shape[0])]
 
-    def step():
-        n = batch.query_rows_device(0, args.batch, rows.data_ptr(), rows.shape[0])
-        if world > 1:
-            return sharding.all_gather_rows(rows[:n].cpu() if share_gpu else rows[:n], max_rows=n_pairs_step)
-        return rows[:n]
+    def step(i):
+        counts[i] = batch.query_rows_device(0, args.batch, row_ptr[i], cap_rows)
+        return counts[i]
+
+    def exchange(k):
+        if world == 1:
+            return table[:k]
+        table[:k, 0, 0] = torch.from_numpy(counts[:k]).to(table.device)   # the row counts travel with the rows
+        local = table[:k].contiguous()
+        if share_gpu:
+            local = local.cpu()
+        out = torch.empty((world * local.numel(),), dtype=torch.int32, device=local.device)
+        dist.all_gather_into_tensor(out, local.view(-1))
+        return out.view(world, k, cap_rows + 1, 5)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
+    for i in range(args.warmup):
+        step(i)
+    exchange(max(args.warmup, 1))
     phase_ms = np.zeros(5)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    for i in range(args.steps):
+        n_last = step(i)
         ms = (C.c_float * 8)()
         lib.fa_mapper_last_timings(mapper._h, ms, 8)     # HIP-event timings of this step, on the library's stream
         phase_ms += np.array(list(ms)[:5])
+    gathered = exchange(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    n_hits = int(out.shape[0])
+    # hits of one step over all ranks (every rank holds the whole table now)
+    n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if world > 1 else int(n_last)
     phase_ms /= max(args.steps, 1)
 
     result = None
