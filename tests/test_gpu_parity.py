@@ -842,3 +842,12 @@ def test_concurrent_queries_on_one_mapper():
     for t in ts:
         t.join()
     assert out[0] + out[1] == want
+
+
+def test_device_memory_is_stable():
+    """Repeated queries, resident batches and mapper life cycles must not grow the device allocation (scripts/check_leaks.py)."""
+    import subprocess
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_leaks.py")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["after_600_queries_mb"] <= 1.0 and out["after_50_batches_mb"] <= 1.0 and out["after_20_mappers_mb"] <= 64.0, out
