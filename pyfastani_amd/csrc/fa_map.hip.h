@@ -848,23 +848,25 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
       while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
       const bool found = x < s && Q[x] == h;
       constexpr int RB = EvBits<T>::RANK;
-      if (i < end0) {
-        // first super-window: inserted in record order, compared once after the last one
-        const int on = prev_in ? 0 : 1;                    // the hash is already in the first window
-        out[i - beg] = (T)ev_word(RB, x + 1, found ? on : 0, found ? 0 : on, false, i == end0 - 1);
-      } else {
-        // admitted after the drops of all records before the one active at its window position (rec_bwd)
-        const uint32_t pos = (uint32_t)(n_init + (i - end0) + (bwd - beg));
-        const int on = (rf & FLAG_INS_LINKED) ? 0 : 1;
-        out[pos] = (T)ev_word(RB, x + 1, found ? on : 0, found ? 0 : on, false, true);
-      }
+      // both events carry slot = rank + 1 and ONE signed delta: of the matched bit (field at RB) when the hash is in the
+      // query sketch, of the window-only count (field at RB + 2) otherwise; branch-free apart from the store predicates
+      const uint32_t base = (uint32_t)(x + 1);
+      const int dsh = found ? RB : RB + 2;
+      const bool first = i < end0;
+      // admit.  First super-window: inserted in record order, compared once after the last one, a no-op when the hash
+      // is already in the window (prev_in).  Later: after the drops of all records before the one active at its window
+      // position (rec_bwd), a no-op when linked to the previous record of the same hash.
+      const uint32_t on = first ? (prev_in ? 0u : 1u) : ((rf & FLAG_INS_LINKED) ? 0u : 1u);
+      const uint32_t evl1 = first ? (i == end0 - 1 ? 1u : 0u) : 1u;
+      const uint32_t pos1 = first ? (uint32_t)(i - beg) : (uint32_t)(n_init + (i - end0) + (bwd - beg));
+      out[pos1] = (T)(base | (on << dsh) | (evl1 << (RB + 5)));
       if (i - beg < ndrop) {
         // dropped at window position wpos[i+1], after the admits of earlier positions and before the admit of
         // that same position (FLAG_SAME_STEP), which then carries the comparison
-        const bool same = (rf & FLAG_SAME_STEP) != 0;
-        const uint32_t pos = (uint32_t)(n_init + (i - beg) + (fwd1 - (same ? 1 : 0) - end0));
-        const int off = (rf & FLAG_DEL_LINKED) ? 0 : -1;
-        out[pos] = (T)ev_word(RB, x + 1, found ? off : 0, found ? 0 : off, true, !same);
+        const uint32_t same = (rf & FLAG_SAME_STEP) ? 1u : 0u;
+        const uint32_t pos2 = (uint32_t)(n_init + (i - beg) + (fwd1 - (int)same - end0));
+        const uint32_t off = (rf & FLAG_DEL_LINKED) ? 0u : 3u;          // -1 in the two-bit field
+        out[pos2] = (T)(base | (off << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5)));
       }
     };
     // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
