@@ -68,7 +68,7 @@ struct QuerySketchArgs {
 __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   uint32_t *buf = (uint32_t *)lds;                 // [sort_cap]
-  __shared__ int sh_n, sh_drop, sh_total;
+  __shared__ int sh_drop, sh_total;
   __shared__ uint32_t sh_h0;
   __shared__ int sh_wpos0;
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   // a real hash may equal SEED_PAD (protein mode): harmless, the first n sorted entries are then the same multiset
   block_bitonic_sort(buf, n32);
   // unique: keep buf[i] if i == 0 or differs from predecessor, among the first n sorted entries
-  if (tid == 0) { sh_n = 0; sh_total = 0; }
+  if (tid == 0) sh_total = 0;
   __syncthreads();
   uint32_t *out = a.q_hash + (size_t)f * a.qcap;
   for (int base = 0; base < n; base += blockDim.x) {
@@ -562,8 +562,8 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
     if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
     __syncthreads();
     // (contig, window) of the seed this thread owns in the first trip; later trips are fetched one trip ahead
-    uint32_t ra_n = tid < n ? seeds[tid] : 0u;
-    int2 sw_n = tid < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
+    uint32_t ra_n = (uint32_t)tid < n ? seeds[tid] : 0u;
+    int2 sw_n = (uint32_t)tid < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
     for (uint32_t i0 = 0; i0 < ncand; i0 += NT) {
       uint32_t i = i0 + tid;
       bool flag = false;
@@ -741,10 +741,6 @@ constexpr int EV_THREADS = 256;
 template <typename T> struct EvBits;
 template <> struct EvBits<uint16_t> { static constexpr int RANK = 10; };   // sketches up to 1022 minimizers
 template <> struct EvBits<uint32_t> { static constexpr int RANK = 24; };
-__device__ __forceinline__ uint32_t ev_word(int rank_bits, int slot, int dM, int dW, bool drop, bool eval) {
-  return (uint32_t)slot | (((uint32_t)dM & 3u) << rank_bits) | (((uint32_t)dW & 3u) << (rank_bits + 2)) |
-         ((drop ? 1u : 0u) << (rank_bits + 4)) | ((eval ? 1u : 0u) << (rank_bits + 5));
-}
 
 template <typename T, bool PACKED>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
@@ -945,7 +941,6 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   constexpr int PER = 16 / sizeof(T);                               // events per 16-byte load
   const uint4 *ev = (const uint4 *)((const T *)a.items + a.l_ioff[l]);
   constexpr int RB = EvBits<T>::RANK;
-  constexpr uint32_t RANK_MASK = (1u << RB) - 1u;
   for (int i = 0; i <= s + 1; i++) st[i * LN + lane] = 0;
   // LDS byte addresses as plain integers: `extern __shared__` has a link-time base the compiler would add on every access
   typedef __attribute__((address_space(3))) ST *lds_ptr;
