@@ -81,12 +81,12 @@ static const uint8_t kCodeOf[256] = {
 #undef X4
 };
 
-// host threads used for packing (FA_HOST_THREADS overrides; default = hardware concurrency, at most 64)
+// host threads used for packing (FA_HOST_THREADS overrides; default = hardware concurrency, at most 128)
 inline int host_threads() {
   static const int v = [] {
     const char *e = getenv("FA_HOST_THREADS");
     int x = e ? atoi(e) : 0;
-    if (x <= 0) x = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64u);
+    if (x <= 0) x = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
     return x;
   }();
   return v;
@@ -99,7 +99,10 @@ class HostPool {
  public:
   static HostPool &get() { static HostPool *p = new HostPool(host_threads()); return *p; }
   void parallel_for(size_t total, const std::function<void(size_t)> &f) {
-    const int helpers = (int)std::min<size_t>((size_t)nworkers_, total > 0 ? total - 1 : 0);
+    // waking a thread costs about as much as a 64 Kbase chunk of packing: two chunks per helper at least
+    // (measured on a 5 Mb query = 77 chunks: 16-32 helpers are fastest, 128 cost 15 % more); big jobs use every worker
+    const size_t cap = total >= 4096 ? (size_t)nworkers_ : std::min<size_t>((size_t)nworkers_, 24);
+    const int helpers = (int)std::min<size_t>(cap, total / 2);
     if (helpers == 0) { for (size_t i = 0; i < total; i++) f(i); return; }
     std::lock_guard<std::mutex> serial(call_mu_);
     {
@@ -174,6 +177,13 @@ struct HostStore {
     struct Chunk { const void *data; int64_t src0, count, store_off; size_t word0; std::vector<int64_t> epos; std::vector<uint8_t> eval; };
     std::vector<Chunk> chunks;
     const int64_t CH = 1 << 16;   // bases per chunk (multiple of 16): fine enough to spread one 5 Mb genome over every thread
+    {
+      // one allocation for the whole call (a thousand genomes would otherwise regrow -- and copy -- the store many times)
+      size_t add = 0;
+      for (int64_t q = 0; q < n; q++) add += (size_t)((lens[q] + 63) / 64 * 64);
+      if (protein) bytes.reserve(bytes.size() + add); else packed.reserve(packed.size() + add / 16);
+      seq_off.reserve(seq_off.size() + (size_t)n); seq_len.reserve(seq_len.size() + (size_t)n);
+    }
     for (int64_t q = 0; q < n; q++) {
       const int64_t len = lens[q], off = total, padded = (len + 63) / 64 * 64;
       seq_off.push_back(off);
