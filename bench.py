@@ -216,7 +216,7 @@ def main():
                                 "algorithmic_bytes": k1_bytes},
             "phases_ms": phase,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
             result["cpu_baseline"] = cpu_baseline(args, anc)
     if world > 1:
         dist.barrier()
