@@ -65,6 +65,7 @@ struct QuerySketchArgs {
   int32_t tile_base;            // first tile of this pass (staging is indexed pass-locally)
 };
 
+constexpr int QS_TILES = 16;      // tiles of a fragment whose counts k_query_sketch fetches in one go
 __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   uint32_t *buf = (uint32_t *)lds;                 // [sort_cap]
@@ -73,13 +74,29 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   __shared__ int sh_wpos0;
   const int f = blockIdx.x, tid = threadIdx.x;
   const int t0 = a.frag_tile_lo[f] - a.tile_base, t1 = a.frag_tile_lo[f + 1] - a.tile_base;
-  // gather in order
+  // gather in order.  The counts of the (few) tiles of a fragment are fetched together, then all staged records: two
+  // dependent round trips to HBM per fragment instead of two per tile
+  __shared__ int sh_cnt[QS_TILES + 1];
+  const int ntile = t1 - t0;
   int n = 0;
-  for (int t = t0; t < t1; t++) {
-    int c = a.tile_count[t];
-    for (int i = tid; i < c; i += blockDim.x) buf[n + i] = a.stage_hash[(size_t)t * TILE + i];
-    if (n == 0 && c > 0 && tid == 0) { sh_h0 = a.stage_hash[(size_t)t * TILE]; sh_wpos0 = a.stage_wpos[(size_t)t * TILE]; }
-    n += c;
+  if (ntile <= QS_TILES) {
+    if (tid < ntile) sh_cnt[tid] = a.tile_count[t0 + tid];
+    __syncthreads();
+    int first = -1;
+    for (int q = 0; q < ntile; q++) { if (first < 0 && sh_cnt[q] > 0) first = q; n += sh_cnt[q]; }
+    for (int i = tid; i < n; i += blockDim.x) {
+      int q = 0, o = i;
+      while (o >= sh_cnt[q]) { o -= sh_cnt[q]; q++; }
+      buf[i] = a.stage_hash[(size_t)(t0 + q) * TILE + o];
+    }
+    if (tid == 0 && first >= 0) { sh_h0 = a.stage_hash[(size_t)(t0 + first) * TILE]; sh_wpos0 = a.stage_wpos[(size_t)(t0 + first) * TILE]; }
+  } else {
+    for (int t = t0; t < t1; t++) {
+      int c = a.tile_count[t];
+      for (int i = tid; i < c; i += blockDim.x) buf[n + i] = a.stage_hash[(size_t)t * TILE + i];
+      if (n == 0 && c > 0 && tid == 0) { sh_h0 = a.stage_hash[(size_t)t * TILE]; sh_wpos0 = a.stage_wpos[(size_t)t * TILE]; }
+      n += c;
+    }
   }
   if (tid == 0) { sh_drop = n; }
   __syncthreads();
@@ -98,13 +115,34 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
     }
   }
   __syncthreads();
-  uint32_t n32 = 1;
-  while (n32 < (uint32_t)n) n32 <<= 1;
-  if (n32 < 2) n32 = 2;
-  for (uint32_t i = n + tid; i < n32; i += blockDim.x) buf[i] = SEED_PAD;
-  __syncthreads();
-  // a real hash may equal SEED_PAD (protein mode): harmless, the first n sorted entries are then the same multiset
-  block_bitonic_sort(buf, n32);
+  if (n <= (int)blockDim.x) {
+    // the usual case (a 3 kb fragment holds ~240 minimizers): one record per thread, ranked by counting -- every thread
+    // reads the same LDS words (broadcast, four at a time), two barriers instead of the 36 of a bitonic network
+    const int n4 = (n + 3) & ~3;
+    for (int i = n + tid; i < n4; i += blockDim.x) buf[i] = SEED_PAD;
+    __syncthreads();
+    const uint32_t x = tid < n ? buf[tid] : 0u;
+    int rank = 0;
+    const uint4 *b4 = (const uint4 *)buf;
+    for (int j = 0; j < n4; j += 4) {
+      const uint4 v = b4[j >> 2];
+      rank += (v.x < x || (v.x == x && j < tid)) ? 1 : 0;
+      rank += (v.y < x || (v.y == x && j + 1 < tid)) ? 1 : 0;
+      rank += (v.z < x || (v.z == x && j + 2 < tid)) ? 1 : 0;
+      rank += (v.w < x || (v.w == x && j + 3 < tid)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < n) buf[rank] = x;
+    __syncthreads();
+  } else {
+    uint32_t n32 = 1;
+    while (n32 < (uint32_t)n) n32 <<= 1;
+    if (n32 < 2) n32 = 2;
+    for (uint32_t i = n + tid; i < n32; i += blockDim.x) buf[i] = SEED_PAD;
+    __syncthreads();
+    // a real hash may equal SEED_PAD (protein mode): harmless, the first n sorted entries are then the same multiset
+    block_bitonic_sort(buf, n32);
+  }
   // unique: keep buf[i] if i == 0 or differs from predecessor, among the first n sorted entries
   if (tid == 0) sh_total = 0;
   __syncthreads();
@@ -126,7 +164,9 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   }
   if (tid == 0) {
     a.q_size[f] = sh_total;
-    atomicMax(&a.stats[0], sh_total);
+    // ~1700 workgroups updating one address serialise in L2 (that alone was most of this kernel's time): the maximum
+    // only ever grows, so a plain read filters out nearly all of them
+    if (sh_total > *(volatile int32_t *)&a.stats[0]) atomicMax(&a.stats[0], sh_total);
   }
 }
 
