@@ -181,8 +181,10 @@ struct HostStore {
       // one allocation for the whole call (a thousand genomes would otherwise regrow -- and copy -- the store many times)
       size_t add = 0;
       for (int64_t q = 0; q < n; q++) add += (size_t)((lens[q] + 63) / 64 * 64);
-      if (protein) bytes.reserve(bytes.size() + add); else packed.reserve(packed.size() + add / 16);
-      seq_off.reserve(seq_off.size() + (size_t)n); seq_len.reserve(seq_len.size() + (size_t)n);
+      // (geometric: an exact reserve on every call would copy the whole store once per added contig)
+      auto grow = [](auto &v, size_t need) { if (need > v.capacity()) v.reserve(std::max(need, v.capacity() * 2)); };
+      if (protein) grow(bytes, bytes.size() + add); else grow(packed, packed.size() + add / 16);
+      grow(seq_off, seq_off.size() + (size_t)n); grow(seq_len, seq_len.size() + (size_t)n);
     }
     for (int64_t q = 0; q < n; q++) {
       const int64_t len = lens[q], off = total, padded = (len + 63) / 64 * 64;
