@@ -31,6 +31,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <cstdlib>
 #include <thread>
@@ -93,8 +94,10 @@ inline int host_threads() {
 }
 
 // Persistent host threads for the packer: a 5 Mb query is packed in ~0.1 ms when the work is cut finely, which a
-// thread spawn per call (tens of microseconds each) would eat.  One parallel_for runs at a time; the calling thread
-// takes part; workers are detached and live as long as the process.
+// thread spawn per call (tens of microseconds each) would eat.  A call publishes a job and wakes only as many workers
+// as it can use (waking all 127 for every contig of a draft assembly cost seconds); the calling thread works too, so a
+// job completes even if no worker shows up, and callers on different threads simply publish their own jobs.  Workers
+// are detached and live as long as the process.
 class HostPool {
  public:
   static HostPool &get() { static HostPool *p = new HostPool(host_threads()); return *p; }
@@ -103,46 +106,52 @@ class HostPool {
     // (measured on a 5 Mb query = 77 chunks: 16-32 helpers are fastest, 128 cost 15 % more); big jobs use every worker
     const size_t cap = total >= 4096 ? (size_t)nworkers_ : std::min<size_t>((size_t)nworkers_, 24);
     const int helpers = (int)std::min<size_t>(cap, total / 2);
-    if (helpers == 0) { for (size_t i = 0; i < total; i++) f(i); return; }
-    std::lock_guard<std::mutex> serial(call_mu_);
+    if (helpers == 0 || total < 4) { for (size_t i = 0; i < total; i++) f(i); return; }
+    auto job = std::make_shared<Job>();
+    job->fn = &f; job->total = total;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      fn_ = &f; total_ = total; next_.store(0); helpers_ = helpers; pending_ = helpers; epoch_++;
+      job_ = job; epoch_++;
     }
-    cv_work_.notify_all();
-    run(f, total);
+    for (int i = 0; i < helpers; i++) cv_work_.notify_one();
+    work(*job);
     std::unique_lock<std::mutex> lk(mu_);
-    cv_done_.wait(lk, [&] { return pending_ == 0; });
-    fn_ = nullptr;
+    cv_done_.wait(lk, [&] { return job->done.load() == total; });
   }
 
  private:
+  struct Job {
+    const std::function<void(size_t)> *fn = nullptr;
+    size_t total = 0;
+    std::atomic<size_t> next{0}, done{0};
+  };
   explicit HostPool(int threads) : nworkers_(std::max(0, threads - 1)) {
-    for (int id = 0; id < nworkers_; id++) std::thread([this, id] { worker(id); }).detach();
+    for (int id = 0; id < nworkers_; id++) std::thread([this] { worker(); }).detach();
   }
-  void run(const std::function<void(size_t)> &f, size_t total) { for (size_t i; (i = next_.fetch_add(1)) < total;) f(i); }
-  void worker(int id) {
+  // a worker that arrives late finds the items of its job taken and never touches the (by then dead) function object
+  void work(Job &j) {
+    for (size_t i; (i = j.next.fetch_add(1)) < j.total;) {
+      (*j.fn)(i);
+      if (j.done.fetch_add(1) + 1 == j.total) { std::lock_guard<std::mutex> lk(mu_); cv_done_.notify_all(); }
+    }
+  }
+  void worker() {
     uint64_t seen = 0;
     for (;;) {
-      std::unique_lock<std::mutex> lk(mu_);
-      cv_work_.wait(lk, [&] { return epoch_ != seen; });
-      seen = epoch_;
-      if (id >= helpers_) continue;
-      const std::function<void(size_t)> *f = fn_;
-      const size_t total = total_;
-      lk.unlock();
-      run(*f, total);
-      lk.lock();
-      if (--pending_ == 0) cv_done_.notify_one();
+      std::shared_ptr<Job> j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_work_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        j = job_;
+      }
+      if (j) work(*j);
     }
   }
   const int nworkers_;
-  std::mutex mu_, call_mu_;
+  std::mutex mu_;
   std::condition_variable cv_work_, cv_done_;
-  const std::function<void(size_t)> *fn_ = nullptr;
-  size_t total_ = 0;
-  std::atomic<size_t> next_{0};
-  int helpers_ = 0, pending_ = 0;
+  std::shared_ptr<Job> job_;
   uint64_t epoch_ = 0;
 };
 
