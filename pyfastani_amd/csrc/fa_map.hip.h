@@ -819,7 +819,8 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
       // the ones before the record active at that position
       const int ndrop = last > end0 ? a.ix.rec_bwd[last - 1] - beg : 0;
       a.l_beg[l] = beg; a.l_end0[l] = end0; a.l_last[l] = last; a.l_ndrop[l] = ndrop;
-      nev = (uint32_t)((last - beg + ndrop + 7) & ~7);
+      // the first super-window is padded to whole 8-event groups: k_l2_scan applies it in bulk, without the pivot logic
+      nev = (uint32_t)((((end0 - beg + 7) & ~7) + (last - end0) + ndrop + 7) & ~7);
       records = (uint32_t)(last - beg);
       a.l_nev[l] = nev;
     }
@@ -866,8 +867,8 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   // the waves of the workgroup take the loci of the fragment round-robin
   for (uint32_t l = l_lo + wv; l < l_lo + l_n; l += EV_THREADS / 64) {
     const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
-    const int n_init = end0 - beg;
-    const uint32_t total = (uint32_t)(last - beg + ndrop);
+    const int n_init = end0 - beg, n_init_pad = (n_init + 7) & ~7;
+    const uint32_t total = (uint32_t)(n_init_pad + (last - end0) + ndrop);
     const uint32_t padded = (total + 7u) & ~7u;
     const uint32_t ioff = sh_base + a.l_ioff[l];
     __builtin_amdgcn_wave_barrier();
@@ -878,6 +879,7 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     const bool staged = padded <= (uint32_t)a.ev_stage;
     T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
     for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)0;
+    if (lane < n_init_pad - n_init) out[n_init + lane] = (T)0;
     auto emit = [&](int i, uint32_t h, uint32_t rf, bool prev_in, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
       const uint32_t qb = min(h >> qshift, (uint32_t)(1 << QT_BITS));     // the last bucket is [2^bits, inf): rank s
       int x = QT[qb], y = QT[qb + 1];
@@ -894,13 +896,13 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
       // position (rec_bwd), a no-op when linked to the previous record of the same hash.
       const uint32_t on = first ? (prev_in ? 0u : 1u) : ((rf & FLAG_INS_LINKED) ? 0u : 1u);
       const uint32_t evl1 = first ? (i == end0 - 1 ? 1u : 0u) : 1u;
-      const uint32_t pos1 = first ? (uint32_t)(i - beg) : (uint32_t)(n_init + (i - end0) + (bwd - beg));
+      const uint32_t pos1 = first ? (uint32_t)(i - beg) : (uint32_t)(n_init_pad + (i - end0) + (bwd - beg));
       out[pos1] = (T)(base | (on << dsh) | (evl1 << (RB + 5)));
       if (i - beg < ndrop) {
         // dropped at window position wpos[i+1], after the admits of earlier positions and before the admit of
         // that same position (FLAG_SAME_STEP), which then carries the comparison
         const uint32_t same = (rf & FLAG_SAME_STEP) ? 1u : 0u;
-        const uint32_t pos2 = (uint32_t)(n_init + (i - beg) + (fwd1 - (int)same - end0));
+        const uint32_t pos2 = (uint32_t)(n_init_pad + (i - beg) + (fwd1 - (int)same - end0));
         const uint32_t off = (rf & FLAG_DEL_LINKED) ? 0u : 3u;          // -1 in the two-bit field
         out[pos2] = (T)(base | (off << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5)));
       }
@@ -988,18 +990,59 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   const int lbase = (int)(uint32_t)(uintptr_t)(lds_ptr)st + lane * STB;
   const int LNB = LN * STB;                                         // bytes between consecutive slots of one lane
 
-  int rl = s * LNB + lbase;                                         // address of slot r* (= state of rank r*-1)
-  int F = s, shared = 0, beg = beg0;                                // F = r* + sum of cnt[c] for c < r*  (= f(r*-1) + 1)
-  int best = -1, opt_s = beg0, opt_e = beg0;
+  // ---- the first super-window: its admits only change the per-rank state, so they are applied without the pivot logic
+  //      (the pivot, F and the shared count are functions of the state and are read off it afterwards) ----
   uint32_t overflow = 0;
   const uint32_t ngroups = nev / PER;
+  const uint32_t fill_groups = min(ngroups, (uint32_t)((((a.l_end0[l] - beg0) + 7) & ~7) / PER));
+  auto word_of = [](const uint4 &g, int q) __attribute__((always_inline)) {
+    constexpr int WPE = (int)sizeof(T);
+    return (q * WPE / 4 == 0) ? g.x : (q * WPE / 4 == 1) ? g.y : (q * WPE / 4 == 2) ? g.z : g.w;
+  };
   uint4 cur = ngroups ? ev[0] : make_uint4(0, 0, 0, 0);
-  for (uint32_t g = 0; g < ngroups; g++) {
+  for (uint32_t g = 0; g < fill_groups; g++) {
+    const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t word = word_of(cur, q);
+      const int SH = (sizeof(T) == 2 && (q & 1)) ? 16 : 0;
+      const int slot = (int)__builtin_amdgcn_ubfe(word, SH, RB);
+      const int dM = __builtin_amdgcn_sbfe(word, SH + RB, 2), dW = __builtin_amdgcn_sbfe(word, SH + RB + 2, 2);
+      const int addr = slot * LNB + lbase;
+      const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
+      const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+      overflow |= nv;
+      *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
+    }
+    cur = nxt;
+  }
+  // pivot of the filled window: r* = min{r : r + sum_{c <= r} cnt[c] >= s} (s if there is none)
+  int rstar = s, F = s, shared = 0;
+  {
+    int acc = 0, m_acc = 0;
+    bool hit = false;
+    for (int r = 0; r < s; r++) {
+      const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)((r + 1) * LNB + lbase);
+      const int c = (int)(v >> 1), mt = (int)(v & 1u);
+      const bool now = !hit && r + acc + c >= s;
+      rstar = now ? r : rstar;
+      F = now ? r + acc : F;
+      shared = now ? m_acc : shared;
+      hit = hit || now;
+      acc += c; m_acc += mt;
+    }
+    F = hit ? F : s + acc;
+    shared = hit ? shared : m_acc;
+  }
+  int rl = rstar * LNB + lbase;                                     // address of slot r* (= state of rank r*-1)
+  int beg = beg0;
+  // the comparison after the last admit of the first window (best was -1: it always wins)
+  int best = fill_groups ? shared : -1, opt_s = beg0, opt_e = beg0;
+  for (uint32_t g = fill_groups; g < ngroups; g++) {
     const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);   // prefetch: the load is off the chain
 #pragma unroll
     for (int q = 0; q < PER; q++) {
-      constexpr int WPE = (int)sizeof(T);
-      const uint32_t word = (q * WPE / 4 == 0) ? cur.x : (q * WPE / 4 == 1) ? cur.y : (q * WPE / 4 == 2) ? cur.z : cur.w;
+      const uint32_t word = word_of(cur, q);
       const int SH = (sizeof(T) == 2 && (q & 1)) ? 16 : 0;         // position of the event inside its 32-bit word (a constant after unrolling)
       // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
       const int slot = (int)__builtin_amdgcn_ubfe(word, SH, RB);   // query rank + 1 (0 = padding)
