@@ -714,16 +714,25 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
-      constexpr int L1_THREADS = 256;
-      const size_t lds = l1_lds_bytes(seed_slots, smax, L1_THREADS);   // 512 and 1024 measured slower (cross-wave scans and barriers grow with the wave count)
-      // fragments of up to E x 256 seed hits are merged in place; E = 16 costs fewer registers (more fragments per CU)
-      if (seed_slots <= 16 * L1_THREADS) {
-        if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_l1<L1_THREADS, 16>), dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
-      } else {
-        if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<L1_THREADS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_l1<L1_THREADS, 32>), dim3((unsigned)F), dim3(L1_THREADS), lds, st, a);
-      }
+      // threads per fragment (FA_L1_THREADS = 256 / 512 / 1024).  512 measured best with the merge sort: twice the threads
+      // halve every thread's chain of LDS round trips per level, and fragments of up to 8192 seed hits stay in the
+      // 16-per-thread variant with its lower register count (bench 0.185 -> 0.170 ms, config 3 212 -> 144 ms; 1024
+      // threads pay more for barriers than they gain)
+      static const int l1_threads = (int)env_u64("FA_L1_THREADS", 512);
+      auto go = [&](auto nt_tag) {
+        constexpr int NTT = decltype(nt_tag)::value;
+        const size_t lds = l1_lds_bytes(seed_slots, smax, NTT);
+        if (seed_slots <= 16 * (uint32_t)NTT) {
+          if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3((unsigned)F), dim3(NTT), lds, st, a);
+        } else {
+          if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3((unsigned)F), dim3(NTT), lds, st, a);
+        }
+      };
+      if (l1_threads >= 1024) go(std::integral_constant<int, 1024>());
+      else if (l1_threads >= 512) go(std::integral_constant<int, 512>());
+      else go(std::integral_constant<int, 256>());
     }
     debug_sync(st, "l1");
     FA_HIP(hipEventRecord(w.ev[2], st));
