@@ -457,6 +457,20 @@ def test_seed_overflow_to_hbm_scratch():
     assert hit_tuples(hits) == ohits
 
 
+@pytest.mark.parametrize("copies", [12, 25, 45])
+def test_seed_counts_across_the_merge_tiers(copies):
+    # `copies` identical references: every query minimizer hits `copies` positions, a fragment gathers ~240 x copies seed
+    # hits -- about 2 900 / 6 000 / 10 800: the 16-per-thread in-place merge, its upper range, and the 32-per-thread one
+    g = syn.rng(950 + copies)
+    base = syn.random_codes(g, 24_000)
+    refs = [[syn.to_ascii(base)] for _ in range(copies)] + [[syn.to_ascii(syn.mutate_codes(g, base, 0.05))]]
+    query = [syn.to_ascii(syn.mutate_codes(g, base, 0.02))]
+    mapper, hits, ohits, det = run_both({}, refs, query, threads=8)
+    assert len(ohits) == copies + 1
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+
+
 def test_speculated_capacities_retry():
     # forces the speculated loci / event capacities below the real numbers: the device raises a flag, the pass is void
     # and is run again with larger buffers (sketch-size and scratch speculation are exercised by the other tests)
