@@ -519,10 +519,10 @@ static void ensure_luts(fa_mapper &m, int smax) {
   }
 }
 
-// seed hits of one fragment sorted in LDS by k_l1 (12 bytes each: two buffers + list ids); more go through HBM scratch
+// seed hits of one fragment sorted in LDS by k_l1 (4 bytes each); more go through HBM scratch
 static uint32_t lds_seed_cap_max(int smax) {
   const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 5 * 4 - ((int64_t)smax + 2) * 8 - 32;
-  return (uint32_t)std::max<int64_t>(256, room / 12 / 256 * 256);
+  return (uint32_t)std::max<int64_t>(256, room / 4 / 256 * 256);
 }
 
 static uint64_t env_u64(const char *name, uint64_t dflt) {
@@ -660,7 +660,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     // ---- buffers and tables sized by the speculated bounds ----
     const int smax = sp.smax;
     const int64_t l_cap = sp.l_cap;
-    const uint32_t seed_slots = std::min(sp.seed_slots, lds_seed_cap_max(smax));   // LDS also holds smax list offsets
+    // LDS also holds smax list offsets; the in-place merge keeps at most 32 seeds per thread in registers
+    static const int l1_threads = (int)env_u64("FA_L1_THREADS", 512);
+    const int l1_nt = l1_threads >= 1024 ? 1024 : (l1_threads >= 512 ? 512 : 256);
+    const uint32_t seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * l1_nt));
     w.l_frag.ensure((size_t)l_cap); w.l_seq.ensure((size_t)l_cap); w.l_start.ensure((size_t)l_cap); w.l_end.ensure((size_t)l_cap + 4);
     w.l_rfirst.ensure((size_t)l_cap); w.l_rlast.ensure((size_t)l_cap + 4);
     w.l_group.ensure((size_t)l_cap); w.l_shared.ensure((size_t)l_cap); w.l_pos.ensure((size_t)l_cap);
@@ -714,14 +717,11 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
-      // threads per fragment (FA_L1_THREADS = 256 / 512 / 1024).  512 measured best with the merge sort: twice the threads
-      // halve every thread's chain of LDS round trips per level, and fragments of up to 8192 seed hits stay in the
-      // 16-per-thread variant with its lower register count (bench 0.185 -> 0.170 ms, config 3 212 -> 144 ms; 1024
-      // threads pay more for barriers than they gain)
-      static const int l1_threads = (int)env_u64("FA_L1_THREADS", 512);
+      // threads per fragment (FA_L1_THREADS = 256 / 512 / 1024; 512 measured best: fewer seeds per thread shorten every
+      // thread's chain of dependent LDS round trips, 1024 threads pay more for barriers than they gain)
       auto go = [&](auto nt_tag) {
         constexpr int NTT = decltype(nt_tag)::value;
-        const size_t lds = l1_lds_bytes(seed_slots, smax, NTT);
+        const size_t lds = l1_lds_bytes(seed_slots, smax);
         if (seed_slots <= 16 * (uint32_t)NTT) {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hipLaunchKernelGGL((k_l1<NTT, 16>), dim3((unsigned)F), dim3(NTT), lds, st, a);

@@ -434,17 +434,15 @@ struct L1Args {
   uint32_t lds_seed_cap;
 };
 
-// dynamic LDS of k_l1: seeds [cap] + their list ids [cap, 16-bit], the list offsets and sources [lut_smax + 2 each], the staged loci (5 arrays
-// of L1_STAGE), and -- only when a fragment can exceed what the in-place merge holds in registers -- a second pair of
-// seed / list-id buffers
-constexpr int L1_INPLACE_MAX = 32;  // most elements per thread the in-place merge keeps in registers (template parameter E: 16 or 32)
-__host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 6 + 15) / 16 * 16; }
+// dynamic LDS of k_l1: the seed hits [cap], the list offsets and sources [lut_smax + 2 each], the staged loci (5 arrays
+// of L1_STAGE)
+constexpr int L1_INPLACE_MAX = 32;  // most seeds per thread the in-place merge keeps in registers (template parameter E: 16 or 32)
+__host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 4 + 15) / 16 * 16; }
 __host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax) {
   return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 8 + 15) / 16 * 16;   // list offsets + list sources
 }
-__host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int threads) {
-  const size_t base = l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 5 * 4;
-  return seed_cap > (uint32_t)(L1_INPLACE_MAX * threads) ? base + (size_t)seed_cap * 6 : base;
+__host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax) {
+  return l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 5 * 4;
 }
 
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
@@ -464,17 +462,15 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   if (s > a.lut_smax) return;                    // SPEC_SMAX was raised by k_seed_totals: the pass will be repeated
   uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
   if (n32 < 2) n32 = 2;
-  const bool in_lds = n <= a.lds_seed_cap;
+  const bool in_lds = n <= a.lds_seed_cap;                               // (the host keeps lds_seed_cap <= E x NT)
   if (!in_lds && (uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;   // SPEC_SCRATCH, same
   uint32_t *seeds;
   if (in_lds) {
     // ---- the position lists of the query minimizers are each sorted already (CSR order = record order): gather them
-    //      back to back and merge them pairwise, bottom-up.  Every element finds its place in the merged run by its rank
-    //      in its own run plus a binary search in the sibling run (record indices are unique: no ties); a run is a group
-    //      of 2^k consecutive lists, so its bounds come from the prefix sums of the list lengths. ----
+    //      back to back and merge them pairwise, bottom-up (record indices are unique: no ties).  A run is a group of
+    //      2^k consecutive lists, so its bounds come from the prefix sums of the list lengths. ----
     const uint32_t cap = a.lds_seed_cap;
     uint32_t *A = (uint32_t *)lds;
-    uint16_t *R = (uint16_t *)(A + cap);                                 // list every element came from
     uint32_t *off = (uint32_t *)(lds + l1_off_offset(cap));             // [s + 1] first seed of every list
     uint32_t *qo = off + a.lut_smax + 2;                                 // [s] where every list starts in the index
     if (tid == 0) sh_run = 0;
@@ -506,56 +502,64 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       const int j0 = locate(i0), j1 = i1 < n ? locate(i1) : 0;
       const uint32_t v0 = a.ix.pos_ridx[qo[j0] + (i0 - off[j0])];
       const uint32_t v1 = i1 < n ? a.ix.pos_ridx[qo[j1] + (i1 - off[j1])] : 0u;
-      A[i0] = v0; R[i0] = (uint16_t)j0;
-      if (i1 < n) { A[i1] = v1; R[i1] = (uint16_t)j1; }
+      A[i0] = v0;
+      if (i1 < n) A[i1] = v1;
     }
     __syncthreads();
-    // one merge step for the element at position i: where it lands in the run merged from its own and the sibling run
-    auto place = [&](const uint32_t *src, uint32_t i, int k, uint32_t x, int j) __attribute__((always_inline)) {
-      const int r = j >> k, r0 = r & ~1;
-      const uint32_t a0 = off[min(r0 << k, s)], a1 = off[min((r0 + 1) << k, s)], a2 = off[min((r0 + 2) << k, s)];
-      const bool left = (r & 1) == 0;
-      uint32_t lo = left ? a1 : a0;
-      uint32_t hi = left ? a2 : a1;
-      const uint32_t sib = lo, own = left ? a0 : a1;
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (src[mid] < x) lo = mid + 1; else hi = mid; }
-      return a0 + (i - own) + (lo - sib);
-    };
-    if (n <= (uint32_t)(E * NT)) {
-      // in place: every thread keeps its (at most E) elements in registers across the barrier that separates the reads
-      // of a level from its writes -- 6 bytes of LDS per seed, which keeps several workgroups on a CU
-      for (int k = 0; (1 << k) < s; k++) {
-        uint32_t xs[E], pk[E];                                           // element, destination | list id << 16
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          const uint32_t i = tid + e * NT;
-          xs[e] = 0; pk[e] = 0;
-          if (i < n) { xs[e] = A[i]; const int j = R[i]; pk[e] = place(A, i, k, xs[e], j) | ((uint32_t)j << 16); }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-          const uint32_t i = tid + e * NT;
-          if (i < n) { A[pk[e] & 0xFFFFu] = xs[e]; R[pk[e] & 0xFFFFu] = (uint16_t)(pk[e] >> 16); }
-        }
-        __syncthreads();
+    // Merge path, in place.  Thread t produces the outputs [t x per, (t + 1) x per) of every level: it finds where that
+    // range starts on the merge path of its pair of runs (ONE binary search along the diagonal), then merges `per`
+    // elements sequentially -- one LDS read and a compare per output, the same number of steps in every lane -- keeps
+    // them in registers across the barrier that separates the reads of a level from its writes, and writes them back.
+    // 4 bytes of LDS per seed; the chain of dependent LDS round trips per level is (two searches) + per.
+    const uint32_t per = (n + NT - 1) / NT;                              // outputs per thread (<= E)
+    const uint32_t o_lo = (uint32_t)tid * per;
+    for (int k = 0; (1 << k) < s; k++) {
+      uint32_t out[E];
+      const int w2 = 2 << k;                                             // lists per pair of runs
+      const int npairs = (s + w2 - 1) / w2;
+      uint32_t A0 = 0, A1 = 0, A2 = 0, ia = 0, ib = 0;
+      int p = 0;
+      if (o_lo < n) {
+        // the pair that holds output o_lo: the last one starting at or before it
+        int lo = 0, hi = npairs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[min(mid * w2, s)] <= o_lo) lo = mid; else hi = mid - 1; }
+        p = lo;
+        A0 = off[min(p * w2, s)]; A1 = off[min(p * w2 + (w2 >> 1), s)]; A2 = off[min((p + 1) * w2, s)];
+        // merge path: how many of the first (o_lo - A0) outputs of the pair come from its left run
+        const uint32_t diag = o_lo - A0, lenA = A1 - A0, lenB = A2 - A1;
+        uint32_t l = diag > lenB ? diag - lenB : 0u, h = min(diag, lenA);
+        while (l < h) { const uint32_t mid = (l + h) >> 1; if (A[A0 + mid] < A[A1 + diag - 1 - mid]) l = mid + 1; else h = mid; }
+        ia = l; ib = diag - l;
       }
-    } else {
-      // larger fragments: ping-pong between two buffers (12 bytes of LDS per seed)
-      uint32_t *B = (uint32_t *)(lds + l1_stage_offset(cap, a.lut_smax) + (size_t)L1_STAGE * 5 * 4);
-      uint16_t *R2 = (uint16_t *)(B + cap);
-      for (int k = 0; (1 << k) < s; k++) {
-        for (uint32_t i = tid; i < n; i += NT) {
-          const uint32_t x = A[i];
-          const int j = R[i];
-          const uint32_t dst = place(A, i, k, x, j);
-          B[dst] = x;
-          R2[dst] = (uint16_t)j;
+      uint32_t ka = (o_lo < n && A0 + ia < A1) ? A[A0 + ia] : 0xFFFFFFFFu;
+      uint32_t kb = (o_lo < n && A1 + ib < A2) ? A[A1 + ib] : 0xFFFFFFFFu;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const uint32_t o = o_lo + e;
+        out[e] = 0;
+        if ((uint32_t)e < per && o < n) {
+          while (o >= A2) {                                              // next pair (empty ones are skipped)
+            p++;
+            A0 = off[min(p * w2, s)]; A1 = off[min(p * w2 + (w2 >> 1), s)]; A2 = off[min((p + 1) * w2, s)];
+            ia = 0; ib = 0;
+            ka = A0 < A1 ? A[A0] : 0xFFFFFFFFu;
+            kb = A1 < A2 ? A[A1] : 0xFFFFFFFFu;
+          }
+          const bool take_a = ka < kb;                                   // an exhausted run reads as +inf
+          out[e] = take_a ? ka : kb;
+          ia += take_a ? 1u : 0u; ib += take_a ? 0u : 1u;
+          const uint32_t nxt = take_a ? A0 + ia : A1 + ib, end = take_a ? A1 : A2;
+          const uint32_t v = nxt < end ? A[nxt] : 0xFFFFFFFFu;
+          ka = take_a ? v : ka; kb = take_a ? kb : v;
         }
-        __syncthreads();
-        uint32_t *t = A; A = B; B = t;
-        uint16_t *u = R; R = R2; R2 = u;
       }
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const uint32_t o = o_lo + e;
+        if ((uint32_t)e < per && o < n) A[o] = out[e];
+      }
+      __syncthreads();
     }
     seeds = A;
   } else {
