@@ -767,6 +767,11 @@ class Mapper(_Parameterized):
         from ._batch import GenomeBatch
         return GenomeBatch(self, genomes)
 
+    def query_fasta(self, path):
+        """`query_draft` for a genome stored as a FASTA file (its records are the contigs): read, packed and mapped
+        without creating a Python object per contig.  Returns the same `Hit` list as `query_draft`."""
+        return self.upload_fasta([path]).query()[0]
+
     def upload_fasta(self, paths):
         """One query genome per FASTA file (its records are the contigs), read, packed and uploaded natively."""
         from ._batch import GenomeBatch

@@ -806,6 +806,9 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         got = [hit_tuples(h) for h in m1.upload_fasta(files).query()]
         want = [hit_tuples(m2.query_draft([r.seq for r in Parser(path)])) for path in files]
     assert got == want and all(len(w) == 3 for w in want)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert hit_tuples(m1.query_fasta(files[1])) == want[1]
     with pytest.warns(UserWarning):
         pf.Sketch().add_fasta("x", files[0])                 # the 6-base contig is reported like add_draft does
     with pytest.raises(OSError):
