@@ -280,7 +280,7 @@ struct Workspace {
   DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
   DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
   DevBuf<unsigned char> items;
-  DevBuf<uint8_t> l_redo;
+  DevBuf<uint8_t> l_redo, big_state;
   DevBuf<unsigned long long> group_best, bins;
   DevBuf<float> row_ident;
   DevBuf<fa_cgi_row> rows_dev;
@@ -717,6 +717,19 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
+      // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
+      // into LDS-sized chunks at contig boundaries by k_l1_big first; what it cannot cut stays with k_l1's HBM path
+      static const bool l1_big = !(getenv("FA_L1_BIG") && atoi(getenv("FA_L1_BIG")) == 0);
+      a.big_state = nullptr; a.big_enabled = 0; a.big_cap = 0;
+      if (l1_big && sp.scratch_words > 0) {
+        w.big_state.ensure((size_t)F);
+        const size_t room = (size_t)160 * 1024 - 2048 - ((size_t)smax + 2) * 16;
+        a.big_cap = (uint32_t)std::min<size_t>((size_t)L1_BIG_E * L1_BIG_THREADS, room / 4 / 256 * 256);
+        a.big_state = w.big_state.p; a.big_enabled = 1;
+        const size_t lds = l1_big_lds_bytes(a.big_cap, smax);
+        if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_l1_big, dim3((unsigned)F), dim3(L1_BIG_THREADS), lds, st, a);
+      }
       // threads per fragment (FA_L1_THREADS = 256 / 512 / 1024; 512 measured best: fewer seeds per thread shorten every
       // thread's chain of dependent LDS round trips, 1024 threads pay more for barriers than they gain)
       auto go = [&](auto nt_tag) {

@@ -432,6 +432,9 @@ struct L1Args {
   uint64_t scratch_words;        // capacity of ovf_buf
   int32_t qcap, frag_len, l_cap;
   uint32_t lds_seed_cap;
+  uint8_t *big_state;            // [F] k_l1_big: 1 = this fragment was handled there, 0 = not (k_l1 takes it)
+  int32_t big_enabled;           // k_l1_big ran before k_l1 in this pass
+  uint32_t big_cap;              // seed hits per chunk of k_l1_big (<= L1_BIG_E x L1_BIG_THREADS)
 };
 
 // dynamic LDS of k_l1: the seed hits [cap], the list offsets and sources [lut_smax + 2 each], the staged loci (5 arrays
@@ -457,6 +460,7 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
   const uint32_t n = a.n_seeds[f];
+  if (a.big_enabled && a.big_state[f]) return;   // more hits than LDS holds: cut into chunks by k_l1_big, which ran before
   if (tid == 0) { a.f_loci_lo[f] = 0; a.f_loci_n[f] = 0; }
   if (s == 0 || n == 0) return;
   if (s > a.lut_smax) return;                    // SPEC_SMAX was raised by k_seed_totals: the pass will be repeated
@@ -700,6 +704,272 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   if (wv == 0) {
     uint32_t run = 0, gbase = 0;
     // count groups first
+    for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+      uint32_t i = i0 + lane;
+      bool gh = false;
+      if (i < nl) {
+        int g = a.ix.contig_genome[a.l_seq[base + i]];
+        gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
+      }
+      run += __popcll(__ballot(gh));
+    }
+    if (lane == 0) gbase = atomicAdd(&a.counters[1], run);
+    gbase = __shfl(gbase, 0);
+    run = 0;
+    for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
+      uint32_t i = i0 + lane;
+      bool gh = false;
+      if (i < nl) {
+        int g = a.ix.contig_genome[a.l_seq[base + i]];
+        gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
+      }
+      uint64_t gb = __ballot(gh);
+      if (i < nl) a.l_group[base + i] = (int32_t)(gbase + run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1);
+      run += __popcll(gb);
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// L1 for fragments with more seed hits than LDS holds (an index with hundreds of strains of the query's species).
+// The hits are cut at CONTIG boundaries -- no candidate spans two contigs -- into chunks that fit LDS: every list
+// proposes the record `share` entries ahead of its cursor, the smallest proposal, rounded down to the start of its
+// contig, bounds the chunk (no list then contributes more than `share` = cap / s hits).  Every chunk goes through the
+// same gather, merge-path merge and candidate pass as in k_l1; the loci are collected in the fragment's HBM scratch
+// and moved to their final place at the end.  A fragment that cannot be cut (one contig alone holds more than a fair
+// share of some list) or whose loci outgrow the scratch is left to k_l1's HBM path (big_state = 0).
+// ----------------------------------------------------------------------------------------------------------
+constexpr int L1_BIG_THREADS = 512, L1_BIG_E = 32;
+__host__ __device__ inline size_t l1_big_lds_bytes(uint32_t seed_cap, int lut_smax) {
+  return ((size_t)seed_cap * 4 + 15) / 16 * 16 + ((size_t)lut_smax + 2) * 16;   // seeds, then off / qo / cur / nxt
+}
+
+__global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
+  constexpr int NT = L1_BIG_THREADS, E = L1_BIG_E;
+  extern __shared__ __align__(16) unsigned char lds[];
+  __shared__ uint32_t sh_scan[NT / 64], sh_min[NT / 64], sh_first[NT / 64];
+  __shared__ uint32_t sh_run, sh_loci, sh_v, sh_firstrem, sh_bound, sh_base, sh_cnt;
+  __shared__ int sh_prev_seq, sh_prev_wa, sh_has_prev, sh_fail, sh_last;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int s = a.q_size[f];
+  const uint32_t n = a.n_seeds[f];
+  const uint32_t cap = a.big_cap;
+  if (tid == 0) a.big_state[f] = 0;
+  if (s == 0 || n <= a.lds_seed_cap || s > a.lut_smax) return;
+  uint32_t n32 = 1; while (n32 < n) n32 <<= 1;
+  if ((uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;           // SPEC_SCRATCH: the pass is void anyway
+  uint32_t *A = (uint32_t *)lds;
+  uint32_t *off = (uint32_t *)(lds + ((size_t)cap * 4 + 15) / 16 * 16);  // [s + 1] first hit of every list inside the chunk
+  uint32_t *qo = off + a.lut_smax + 2;                                   // [s] where the chunk's part of every list starts in the index
+  uint32_t *cur = qo + a.lut_smax + 2, *nxt = cur + a.lut_smax + 2;      // [s] cursor of every list, and its value after the chunk
+  // loci collected in the fragment's scratch: five arrays of LC entries
+  const uint32_t LC = n32 / 5;
+  int32_t *S = (int32_t *)(a.ovf_buf + a.ovf_off[f]);
+  int32_t *S_seq = S, *S_start = S + LC, *S_rfirst = S + 2 * (size_t)LC, *S_end = S + 3 * (size_t)LC, *S_rlast = S + 4 * (size_t)LC;
+  for (uint32_t i = tid; i < LC; i += NT) { S_end[i] = 0; S_rlast[i] = 0; }
+  for (int j = tid; j < s; j += NT) cur[j] = 0;
+  if (tid == 0) { sh_loci = 0; sh_fail = 0; }
+  int m = a.min_hits_lut[s];
+  if (m < 1) m = 1;
+  const int len = a.frag_len;
+  const uint32_t share = max(1u, cap / (uint32_t)s);
+  const uint32_t *qcnt = a.q_cnt + (size_t)f * a.qcap, *qoff = a.q_off + (size_t)f * a.qcap;
+  __threadfence_block();
+  __syncthreads();
+  for (;;) {
+    // ---- bound of the chunk: smallest proposal, rounded down to a contig start ----
+    uint32_t prop = 0xFFFFFFFFu, first = 0xFFFFFFFFu;
+    for (int j = tid; j < s; j += NT) {
+      const uint32_t c = qcnt[j], cj = cur[j];
+      if (cj < c) first = min(first, a.ix.pos_ridx[qoff[j] + cj]);
+      if (c - cj > share) prop = min(prop, a.ix.pos_ridx[qoff[j] + cj + share]);
+    }
+    for (int d = 32; d > 0; d >>= 1) { prop = min(prop, (uint32_t)__shfl_xor((int)prop, d)); first = min(first, (uint32_t)__shfl_xor((int)first, d)); }
+    if (lane == 0) { sh_min[wv] = prop; sh_first[wv] = first; }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t v = 0xFFFFFFFFu, fr = 0xFFFFFFFFu;
+      for (int q = 0; q < NT / 64; q++) { v = min(v, sh_min[q]); fr = min(fr, sh_first[q]); }
+      uint32_t bound = 0xFFFFFFFFu;                                     // everything that is left
+      if (v != 0xFFFFFFFFu) {
+        bound = (uint32_t)a.ix.contig_rec[a.ix.rec_sw[v].x];            // first record of the contig that holds v
+        if (bound <= fr) sh_fail = 1;                                    // that contig alone is too much: cannot cut here
+      }
+      sh_bound = bound; sh_last = v == 0xFFFFFFFFu; sh_firstrem = fr;
+    }
+    __syncthreads();
+    if (sh_fail || sh_firstrem == 0xFFFFFFFFu) break;                    // cannot cut / nothing left
+    const uint32_t bound = sh_bound;
+    // ---- the chunk's part of every list: [cur, nxt) with nxt = first entry >= bound ----
+    if (tid == 0) sh_run = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < s; j0 += NT) {
+      const int j = j0 + tid;
+      uint32_t cnt = 0;
+      if (j < s) {
+        const uint32_t c = qcnt[j], cj = cur[j];
+        uint32_t lo = cj, hi = bound == 0xFFFFFFFFu ? c : min(c, cj + share + 1);
+        if (bound != 0xFFFFFFFFu) { while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.ix.pos_ridx[qoff[j] + mid] < bound) lo = mid + 1; else hi = mid; } }
+        else lo = c;
+        nxt[j] = lo; cnt = lo - cj;
+        qo[j] = qoff[j] + cj;
+      }
+      uint32_t incl = cnt;
+      for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) sh_scan[wv] = incl;
+      __syncthreads();
+      uint32_t o = sh_run + incl - cnt;
+      for (int q = 0; q < wv; q++) o += sh_scan[q];
+      if (j < s) off[j] = o;
+      __syncthreads();
+      if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+      __syncthreads();
+    }
+    const uint32_t nc = sh_run;                                          // hits of the chunk (<= cap by construction)
+    if (tid == 0) off[s] = nc;
+    __syncthreads();
+    if (nc > cap) { if (tid == 0) sh_fail = 1; __syncthreads(); break; }
+    // ---- gather + merge-path merge in LDS (as in k_l1) ----
+    auto locate = [&](uint32_t i) __attribute__((always_inline)) {
+      int lo = 0, hi = s - 1;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+      return lo;
+    };
+    for (uint32_t i = tid; i < nc; i += NT) { const int j = locate(i); A[i] = a.ix.pos_ridx[qo[j] + (i - off[j])]; }
+    __syncthreads();
+    {
+      const uint32_t per = (nc + NT - 1) / NT;
+      const uint32_t o_lo = (uint32_t)tid * per;
+      for (int k = 0; (1 << k) < s; k++) {
+        uint32_t out[E];
+        const int w2 = 2 << k;
+        const int npairs = (s + w2 - 1) / w2;
+        uint32_t A0 = 0, A1 = 0, A2 = 0, ia = 0, ib = 0;
+        int p = 0;
+        if (o_lo < nc) {
+          int lo = 0, hi = npairs - 1;
+          while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (off[min(mid * w2, s)] <= o_lo) lo = mid; else hi = mid - 1; }
+          p = lo;
+          A0 = off[min(p * w2, s)]; A1 = off[min(p * w2 + (w2 >> 1), s)]; A2 = off[min((p + 1) * w2, s)];
+          const uint32_t diag = o_lo - A0, lenA = A1 - A0, lenB = A2 - A1;
+          uint32_t l = diag > lenB ? diag - lenB : 0u, h = min(diag, lenA);
+          while (l < h) { const uint32_t mid = (l + h) >> 1; if (A[A0 + mid] < A[A1 + diag - 1 - mid]) l = mid + 1; else h = mid; }
+          ia = l; ib = diag - l;
+        }
+        uint32_t ka = (o_lo < nc && A0 + ia < A1) ? A[A0 + ia] : 0xFFFFFFFFu;
+        uint32_t kb = (o_lo < nc && A1 + ib < A2) ? A[A1 + ib] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const uint32_t o = o_lo + e;
+          out[e] = 0;
+          if ((uint32_t)e < per && o < nc) {
+            while (o >= A2) {
+              p++;
+              A0 = off[min(p * w2, s)]; A1 = off[min(p * w2 + (w2 >> 1), s)]; A2 = off[min((p + 1) * w2, s)];
+              ia = 0; ib = 0;
+              ka = A0 < A1 ? A[A0] : 0xFFFFFFFFu;
+              kb = A1 < A2 ? A[A1] : 0xFFFFFFFFu;
+            }
+            const bool take_a = ka < kb;
+            out[e] = take_a ? ka : kb;
+            ia += take_a ? 1u : 0u; ib += take_a ? 0u : 1u;
+            const uint32_t nx = take_a ? A0 + ia : A1 + ib, end = take_a ? A1 : A2;
+            const uint32_t v = nx < end ? A[nx] : 0xFFFFFFFFu;
+            ka = take_a ? v : ka; kb = take_a ? kb : v;
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const uint32_t o = o_lo + e;
+          if ((uint32_t)e < per && o < nc) A[o] = out[e];
+        }
+        __syncthreads();
+      }
+    }
+    // ---- candidates of the chunk (computeL1CandidateRegions on its sorted hits; nothing carries over a contig start) ----
+    if ((uint32_t)m <= nc) {
+      const uint32_t ncand = nc - (uint32_t)m + 1;
+      if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
+      __syncthreads();
+      const uint32_t loci0 = sh_loci;
+      for (uint32_t i0 = 0; i0 < ncand; i0 += NT) {
+        const uint32_t i = i0 + tid;
+        bool flag = false;
+        int start = 0, seq = -1, wa = 0;
+        uint32_t ra = 0;
+        if (i < nc) { ra = A[i]; const int2 sw = a.ix.rec_sw[ra]; seq = sw.x; wa = sw.y; }
+        int seqb = __shfl(seq, (lane + m - 1) & 63), wb = __shfl(wa, (lane + m - 1) & 63);
+        if (lane + m - 1 >= 64 && i < ncand) { const int2 swb = a.ix.rec_sw[A[i + m - 1]]; seqb = swb.x; wb = swb.y; }
+        if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
+        uint64_t bal = __ballot(flag);
+        __shared__ int w_last_seq[NT / 64], w_last_wa[NT / 64], w_any[NT / 64];
+        uint64_t below = bal & ((1ULL << lane) - 1ULL);
+        int src_lane = below ? 63 - __clzll(below) : -1;
+        int p_seq = __shfl(seq, src_lane < 0 ? 0 : src_lane), p_wa = __shfl(wa, src_lane < 0 ? 0 : src_lane);
+        if (lane == 0) w_any[wv] = bal != 0;
+        if (bal && lane == 63 - __clzll(bal)) { w_last_seq[wv] = seq; w_last_wa[wv] = wa; }
+        __syncthreads();
+        bool has_prev = src_lane >= 0;
+        if (!has_prev) {
+          for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[q]) { has_prev = true; p_seq = w_last_seq[q]; p_wa = w_last_wa[q]; }
+          if (!has_prev && sh_has_prev) { has_prev = true; p_seq = sh_prev_seq; p_wa = sh_prev_wa; }
+        }
+        bool head = flag && !(has_prev && p_seq == seq && p_wa >= start);
+        uint64_t hb = __ballot(head);
+        __shared__ uint32_t w_heads[NT / 64];
+        if (lane == 0) w_heads[wv] = __popcll(hb);
+        __syncthreads();
+        uint32_t slot = sh_run + __popcll(hb & ((2ULL << lane) - 1ULL));
+        for (int q = 0; q < wv; q++) slot += w_heads[q];
+        if (flag) {
+          const uint64_t above = (lane == 63) ? 0ULL : (bal & ~((2ULL << lane) - 1ULL));
+          const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
+          const uint32_t li = loci0 + slot - 1;
+          if (li < LC) {
+            if (head) { S_seq[li] = seq; S_start[li] = start; S_rfirst[li] = (int32_t)ra; }
+            if (last_here) { atomicMax(&S_end[li], wa); atomicMax(&S_rlast[li], (int32_t)ra); }
+          } else sh_fail = 1;                                           // more loci than the scratch holds
+        }
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t tot = 0;
+          for (int q = 0; q < NT / 64; q++) tot += w_heads[q];
+          sh_run += tot;
+          for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_seq = w_last_seq[q]; sh_prev_wa = w_last_wa[q]; break; }
+        }
+        __syncthreads();
+      }
+      if (tid == 0) sh_loci = loci0 + sh_run;
+    }
+    // ---- next chunk ----
+    for (int j = tid; j < s; j += NT) cur[j] = nxt[j];
+    __syncthreads();
+    if (sh_fail || sh_last) break;
+  }
+  __syncthreads();
+  if (sh_fail) return;                                                   // big_state stays 0: k_l1 takes the fragment
+  // ---- the loci to their final place, then the groups (as in k_l1) ----
+  if (tid == 0) {
+    uint32_t cnt = sh_loci;
+    uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
+    if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+    sh_base = base; sh_cnt = cnt;
+    a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
+    a.big_state[f] = 1;
+  }
+  __threadfence_block();
+  __syncthreads();
+  const uint32_t nl = sh_cnt, base = sh_base;
+  for (uint32_t q = tid; q < nl; q += NT) {
+    const uint32_t li = base + q;
+    a.l_frag[li] = f; a.l_seq[li] = S_seq[q]; a.l_start[li] = S_start[q]; a.l_rfirst[li] = S_rfirst[q];
+    a.l_end[li] = S_end[q]; a.l_rlast[li] = S_rlast[q];
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (wv == 0) {
+    uint32_t run = 0, gbase = 0;
     for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
       uint32_t i = i0 + lane;
       bool gh = false;

@@ -457,6 +457,57 @@ def test_seed_overflow_to_hbm_scratch():
     assert hit_tuples(hits) == ohits
 
 
+@pytest.mark.parametrize("layout", ["drafts", "tandem", "mixed", "uneven"])
+def test_chunked_l1_and_its_fallback(layout):
+    # fragments with more seed hits than LDS holds are cut at contig boundaries by k_l1_big; what cannot be cut (one
+    # contig alone holds more than a fair share of a position list) falls back to the HBM sort of k_l1
+    g = syn.rng(970)
+    base = syn.random_codes(g, 18_000)
+    if layout == "drafts":        # 150 strains in 3 contigs each: 450 contigs, every chunk holds many of them
+        refs = [syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, base, 0.01)), 3) for _ in range(150)]
+    elif layout == "tandem":      # one contig of 120 tandem copies: cannot be cut at all
+        refs = [[syn.to_ascii(np.concatenate([syn.mutate_codes(g, base, 0.01) for _ in range(120)]))]]
+    elif layout == "mixed":       # 60 single copies, then the uncuttable contig: chunks first, then the fallback
+        refs = [[syn.to_ascii(syn.mutate_codes(g, base, 0.01))] for _ in range(60)]
+        refs.append([syn.to_ascii(np.concatenate([syn.mutate_codes(g, base, 0.01) for _ in range(110)]))])
+    else:                         # contigs of very different weight: 1 to 12 copies per contig
+        refs = [[syn.to_ascii(np.concatenate([syn.mutate_codes(g, base, 0.01) for _ in range(1 + (i * 7) % 12)]))] for i in range(40)]
+    query = [syn.to_ascii(syn.mutate_codes(g, base, 0.01))]
+    mapper, hits, ohits, det = run_both({}, refs, query, threads=8)
+    assert mapper.occurences_threshold == 2**31 - 1 and len(ohits) == len(refs)
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+
+
+def test_chunked_l1_switched_off_matches():
+    # FA_L1_BIG=0 keeps every oversized fragment on the HBM sort: same rows as the chunked path
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, os
+        sys.path.insert(0, %r)
+        import numpy as np
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        g = syn.rng(971)
+        base = syn.random_codes(g, 15_000)
+        sk = pf.Sketch()
+        for i in range(200):
+            sk.add_draft(i, syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, base, 0.02)), 2))
+        m = sk.index()
+        batch = m.upload_genomes([[syn.to_ascii(syn.mutate_codes(g, base, 0.02))]])
+        rows = batch.query_rows(0, 1); rows = batch.query_rows(0, 1)
+        assert len(rows) == 200
+        sys.stdout.buffer.write(b"OK" + rows.tobytes().hex().encode())
+    """ % ROOT)
+    import subprocess
+    outs = []
+    for flag in ("1", "0"):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, FA_L1_BIG=flag), capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0 and res.stdout.startswith("OK"), res.stdout[-2000:] + res.stderr[-2000:]
+        outs.append(res.stdout)
+    assert outs[0] == outs[1]
+
+
 @pytest.mark.parametrize("copies", [12, 25, 45])
 def test_seed_counts_across_the_merge_tiers(copies):
     # `copies` identical references: every query minimizer hits `copies` positions, a fragment gathers ~240 x copies seed
