@@ -392,15 +392,32 @@ __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, i
   for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d); mx = max(mx, (unsigned int)__shfl_down((int)mx, d)); any |= (unsigned int)__shfl_down((int)any, d); }
   if ((threadIdx.x & 63) == 0) { atomicAdd(&sh_sum, sum); atomicMax(&sh_max, mx); atomicOr(&sh_any, any); }
   __syncthreads();
+  // scratch of the oversized fragments, in fragment order: exclusive prefix sum of their padded sizes
+  __shared__ unsigned long long sh_words, sh_wave[16];
+  if (threadIdx.x == 0) sh_words = 0;
+  __syncthreads();
+  if (sh_any) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int64_t f0 = 0; f0 < F; f0 += blockDim.x) {
+      const int64_t f = f0 + threadIdx.x;
+      const uint32_t n = f < F ? n_seeds[f] : 0u;
+      unsigned long long n32 = 0;
+      if (n > lds_seed_cap) { n32 = 1; while (n32 < n) n32 <<= 1; }
+      unsigned long long incl = n32;
+      for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+      if (lane == 63) sh_wave[wv] = incl;
+      __syncthreads();
+      unsigned long long off = sh_words + incl - n32;
+      for (int q = 0; q < wv; q++) off += sh_wave[q];
+      if (n32) ovf_off[f] = (uint32_t)off;
+      __syncthreads();
+      if (threadIdx.x == 0) { unsigned long long t = 0; for (int q = 0; q < nw; q++) t += sh_wave[q]; sh_words += t; }
+      __syncthreads();
+    }
+  }
   if (threadIdx.x == 0) {
     totals[0] = sh_sum; totals[1] = sh_max;
-    unsigned long long words = 0;
-    if (sh_any) {
-      for (int64_t f = 0; f < F; f++) {
-        const uint32_t n = n_seeds[f];
-        if (n > lds_seed_cap) { uint32_t n32 = 1; while (n32 < n) n32 <<= 1; ovf_off[f] = (uint32_t)words; words += n32; }
-      }
-    }
+    const unsigned long long words = sh_words;
     totals[2] = words;
     unsigned long long flags = 0;
     if (stats[0] > spec_smax) flags |= SPEC_SMAX;
