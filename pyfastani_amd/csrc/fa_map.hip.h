@@ -471,8 +471,11 @@ template <int NT, int E>
 __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sh_scan[NT / 64];
-  __shared__ uint32_t sh_run;       // running offset (gather) / running head count
-  __shared__ int sh_prev_seq, sh_prev_wa, sh_has_prev;
+  __shared__ uint32_t sh_run;       // running offset (gather)
+  // candidate pass: running head count and the last flagged candidate so far, double-buffered by trip parity so that
+  // thread 0 can publish the next trip's values while slower waves still read this trip's
+  __shared__ uint32_t sh_heads[2];
+  __shared__ int sh_prev_seq[2], sh_prev_wa[2], sh_has_prev[2];
   __shared__ uint32_t sh_base, sh_gbase;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
@@ -624,8 +627,9 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
   for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
   bool staged = true;
   for (int pass = 0; pass < 2; pass++) {
-    if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
+    if (tid == 0) { sh_heads[0] = 0; sh_has_prev[0] = 0; sh_prev_seq[0] = -1; sh_prev_wa[0] = 0; }
     __syncthreads();
+    int par = 0;
     // (contig, window) of the seed this thread owns in the first trip; later trips are fetched one trip ahead
     uint32_t ra_n = (uint32_t)tid < n ? seeds[tid] : 0u;
     int2 sw_n = (uint32_t)tid < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
@@ -646,17 +650,17 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
-      __shared__ int w_last_seq[NT / 64], w_last_wa[NT / 64], w_any[NT / 64];
+      __shared__ int w_last_seq[2][NT / 64], w_last_wa[2][NT / 64], w_any[2][NT / 64];
       uint64_t below = bal & ((1ULL << lane) - 1ULL);
       int src_lane = below ? 63 - __clzll(below) : -1;
       int p_seq = __shfl(seq, src_lane < 0 ? 0 : src_lane), p_wa = __shfl(wa, src_lane < 0 ? 0 : src_lane);
-      if (lane == 0) w_any[wv] = bal != 0;
-      if (bal && lane == 63 - __clzll(bal)) { w_last_seq[wv] = seq; w_last_wa[wv] = wa; }
+      if (lane == 0) w_any[par][wv] = bal != 0;
+      if (bal && lane == 63 - __clzll(bal)) { w_last_seq[par][wv] = seq; w_last_wa[par][wv] = wa; }
       __syncthreads();
       bool has_prev = src_lane >= 0;
       if (!has_prev) {
-        for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[q]) { has_prev = true; p_seq = w_last_seq[q]; p_wa = w_last_wa[q]; }
-        if (!has_prev && sh_has_prev) { has_prev = true; p_seq = sh_prev_seq; p_wa = sh_prev_wa; }
+        for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[par][q]) { has_prev = true; p_seq = w_last_seq[par][q]; p_wa = w_last_wa[par][q]; }
+        if (!has_prev && sh_has_prev[par]) { has_prev = true; p_seq = sh_prev_seq[par]; p_wa = sh_prev_wa[par]; }
       }
       bool head = flag && !(has_prev && p_seq == seq && p_wa >= start);
       // inclusive scan of heads -> slot of the locus every flagged candidate belongs to
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
       __shared__ uint32_t w_heads[NT / 64];
       if (lane == 0) w_heads[wv] = __popcll(hb);
       __syncthreads();
-      uint32_t slot = sh_run + __popcll(hb & ((2ULL << lane) - 1ULL));
+      uint32_t slot = sh_heads[par] + __popcll(hb & ((2ULL << lane) - 1ULL));
       for (int q = 0; q < wv; q++) slot += w_heads[q];
       if (flag) {
         // the end of a locus is its last flagged seed; only the last flagged lane of a locus inside this wave
@@ -682,18 +686,21 @@ __global__ __launch_bounds__(NT) void k_l1(L1Args a) {
           if (last_here) { atomicMax(&a.l_end[li], wa); atomicMax(&a.l_rlast[li], (int32_t)ra); }
         }
       }
-      __syncthreads();
       if (tid == 0) {
-        uint32_t tot = 0;
+        // next trip's carry goes to the other parity: nobody reads it before the next trip's first barrier
+        uint32_t tot = sh_heads[par];
         for (int q = 0; q < NT / 64; q++) tot += w_heads[q];
-        sh_run += tot;
-        for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_seq = w_last_seq[q]; sh_prev_wa = w_last_wa[q]; break; }
+        sh_heads[par ^ 1] = tot;
+        int hp = sh_has_prev[par], ps = sh_prev_seq[par], pw = sh_prev_wa[par];
+        for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[par][q]) { hp = 1; ps = w_last_seq[par][q]; pw = w_last_wa[par][q]; break; }
+        sh_has_prev[par ^ 1] = hp; sh_prev_seq[par ^ 1] = ps; sh_prev_wa[par ^ 1] = pw;
       }
-      __syncthreads();
+      par ^= 1;
     }
+    __syncthreads();
     if (pass == 0) {
       if (tid == 0) {
-        uint32_t cnt = sh_run;
+        uint32_t cnt = sh_heads[par];
         uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
         if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
