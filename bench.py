@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--batch", type=int, default=1, help="query genomes mapped per step and per GPU (1 = BASELINE configs[1])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clients", type=int, default=4, help="N=1 only: host threads of the informational concurrent-clients leg (0 = skip)")
     ap.add_argument("--replicated-index", action="store_true", help="N>1: every rank sketches all references itself")
     ap.add_argument("--cpu-refs", type=int, default=10, help="references in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -216,6 +217,8 @@ def main():
                                 "algorithmic_bytes": k1_bytes},
             "phases_ms": phase,
         }
+        if world == 1 and args.clients > 1:
+            result["concurrent_clients"] = concurrent_clients(args, batch, cap_rows, n_pairs_step)
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
             result["cpu_baseline"] = cpu_baseline(args, anc)
     if world > 1:
@@ -223,6 +226,34 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
+
+
+def concurrent_clients(args, batch, cap_rows, n_pairs_step):
+    """Informational, never `value`: the same step issued by several host threads on ONE mapper (queries are re-entrant,
+    every call takes its own workspace and stream -- _fastani.pyx:1158-1161 releases the GIL for the same use), so the
+    phases of different steps overlap on the device.  Kernel durations stretch under sharing, hence no roofline here."""
+    import threading
+    import torch
+    k = args.clients
+    tables = [torch.zeros((cap_rows, 5), dtype=torch.int32, device="cuda") for _ in range(k)]
+
+    def run(i, n):
+        for _ in range(n):
+            batch.query_rows_device(0, args.batch, tables[i].data_ptr(), cap_rows)
+    for i in range(k):
+        run(i, max(args.warmup, 1))
+    torch.cuda.synchronize()
+    n = max(args.steps, 100)                                  # long enough to amortise the thread start-up
+    threads = [threading.Thread(target=run, args=(i, n)) for i in range(k)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"threads": k, "steps_per_thread": n, "value": n_pairs_step * n * k / dt, "unit": "pairs/s",
+            "ms_per_step": dt / (n * k) * 1e3}
 
 
 def profiled_traffic(kernels):
