@@ -128,6 +128,15 @@ void fa_mapper_free(fa_mapper *m);
 int fa_mapper_freq_threshold(fa_mapper *m, int *threshold);
 /* len(Mapper.lookup_index) = minimizerPosLookupIndex.size(), _fastani.pyx:1454-1456 */
 int fa_mapper_lookup_size(fa_mapper *m, int64_t *n);
+/* Reference-sharded index ("when the index does not fit"): every rank indexes its own share of
+ * the reference genomes, and the frequency threshold of Sketch_t::computeFreqHist / the `size < threshold` filter of
+ * _fastani.pyx:946 must then be taken over the position lists of ALL shards.  fa_mapper_lookup_export_device copies
+ * the distinct hashes of this shard (ascending) and their list lengths into caller-owned HBM buffers (e.g. torch
+ * tensors, `cap` >= fa_mapper_lookup_size) for the exchange; fa_mapper_set_global_frequency installs the threshold
+ * computed over all shards and the hashes (device array) whose summed list length reaches it: the lookup ignores
+ * them from then on although their local lists are short.  Call it before the first query on this mapper. */
+int fa_mapper_lookup_export_device(fa_mapper *m, int64_t cap, uint32_t *d_keys, int32_t *d_counts);
+int fa_mapper_set_global_frequency(fa_mapper *m, int threshold, int64_t n_drop, const uint32_t *d_drop_keys);
 /* MinimizerIndex.__iter__/__getitem__, _fastani.pyx:1458-1475 */
 int fa_mapper_lookup_keys(fa_mapper *m, uint32_t *keys);
 int fa_mapper_lookup_count(fa_mapper *m, uint32_t hash, int64_t *count); /* -1 when absent */

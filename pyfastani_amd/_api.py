@@ -704,6 +704,28 @@ class Mapper(_Parameterized):
         """`MinimizerIndex`: the table of minimizer positions in the reference genomes (_fastani.pyx:869-881)."""
         return MinimizerIndex(self)
 
+    def _export_lookup(self, device="cuda"):
+        """Distinct hashes of this index (ascending, ``int32`` bit patterns) and the lengths of their position lists, as
+        two torch tensors on ``device``: what a rank contributes to the global frequency threshold of a
+        reference-sharded index (`sharding.global_frequency`)."""
+        import torch
+        n = C.c_int64(0)
+        check(lib.fa_mapper_lookup_size(self._h, C.byref(n)))
+        dev = torch.device(device)
+        keys = torch.empty(max(n.value, 1), dtype=torch.int32, device="cuda")
+        counts = torch.empty(max(n.value, 1), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        check(lib.fa_mapper_lookup_export_device(self._h, keys.shape[0], keys.data_ptr(), counts.data_ptr()))
+        return keys[: n.value].to(dev), counts[: n.value].to(dev)
+
+    def _set_global_frequency(self, threshold, drop_keys):
+        """Install the frequency threshold taken over all shards of a reference-sharded index and the hashes (torch
+        ``int32`` bit patterns) whose summed list length reaches it."""
+        import torch
+        drop = drop_keys.to(device="cuda", dtype=torch.int32).contiguous()
+        torch.cuda.synchronize()
+        check(lib.fa_mapper_set_global_frequency(self._h, int(threshold), int(drop.numel()), drop.data_ptr() if drop.numel() else None))
+
     @property
     def occurences_threshold(self):
         t = C.c_int(0)

@@ -75,6 +75,8 @@ SIGNATURES = {
     "fa_sketch_index": (_i32, [_vp, _P(_vp)]),
     "fa_mapper_free": (None, [_vp]),
     "fa_mapper_freq_threshold": (_i32, [_vp, _P(_i32)]),
+    "fa_mapper_lookup_export_device": (_i32, [_vp, _i64, _vp, _vp]),
+    "fa_mapper_set_global_frequency": (_i32, [_vp, _i32, _i64, _vp]),
     "fa_mapper_lookup_size": (_i32, [_vp, _P(_i64)]),
     "fa_mapper_lookup_keys": (_i32, [_vp, _vp]),
     "fa_mapper_lookup_count": (_i32, [_vp, _u32, _P(_i64)]),

@@ -1304,6 +1304,31 @@ void fa_mapper_free(fa_mapper *m) {
 }
 int fa_mapper_freq_threshold(fa_mapper *m, int *thr) { *thr = m->freq_threshold; return FA_OK; }
 int fa_mapper_lookup_size(fa_mapper *m, int64_t *n) { *n = m->U; return FA_OK; }
+int fa_mapper_lookup_export_device(fa_mapper *m, int64_t cap, uint32_t *d_keys, int32_t *d_counts) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
+    FA_REQUIRE(cap >= m->U, FA_ERR_INVALID, "destination smaller than the lookup index");
+    if (m->U == 0) return;
+    FA_HIP(hipMemcpyAsync(d_keys, m->uniq_hash.p, (size_t)m->U * sizeof(uint32_t), hipMemcpyDeviceToDevice, m->stream));
+    hipLaunchKernelGGL(k_list_lengths, dim3(ceil_div(m->U, 256)), dim3(256), 0, m->stream, m->uniq_off.p, (int64_t)m->U, d_counts);
+    FA_HIP(hipGetLastError());
+    FA_HIP(hipStreamSynchronize(m->stream));
+  });
+}
+int fa_mapper_set_global_frequency(fa_mapper *m, int threshold, int64_t n_drop, const uint32_t *d_drop_keys) {
+  return guarded([&] {
+    FA_REQUIRE(threshold >= 0 && n_drop >= 0, FA_ERR_INVALID, "negative threshold or key count");
+    std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
+    m->freq_threshold = threshold;
+    if (n_drop > 0 && m->U > 0) {
+      hipLaunchKernelGGL(k_drop_keys, dim3(ceil_div(n_drop, 256)), dim3(256), 0, m->stream, d_drop_keys, n_drop, m->table_bits, m->table.p);
+      FA_HIP(hipGetLastError());
+    }
+    FA_HIP(hipStreamSynchronize(m->stream));
+  });
+}
 int fa_mapper_lookup_keys(fa_mapper *m, uint32_t *keys) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);

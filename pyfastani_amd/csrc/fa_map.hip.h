@@ -193,6 +193,23 @@ __global__ void k_build_table(const uint32_t *uniq_hash, const uint32_t *uniq_of
   }
 }
 
+// Reference-sharded index ("when the index does not fit"): hashes whose position lists, summed over the
+// shards of all ranks, reach the global frequency threshold are ignored by the lookup although the local list is short.
+__global__ void k_drop_keys(const uint32_t *keys, int64_t n, int bits, uint4 *table) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t h = keys[i], mask = (1u << bits) - 1u;
+  for (uint32_t slot = ht_slot(h, bits);; slot = (slot + 1) & mask) {
+    const uint4 e = table[slot];
+    if (e.z == 0u) return;                       // not in this shard
+    if (e.x == h) { table[slot].w = 1u; return; }
+  }
+}
+__global__ void k_list_lengths(const uint32_t *uniq_off, int64_t U, int32_t *counts) {
+  int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < U) counts[u] = (int32_t)(uniq_off[u + 1] - uniq_off[u]);
+}
+
 // contig_rec[c] = first record with rec_seq >= c
 __global__ void k_contig_ranges(const int32_t *rec_seq, int64_t N, int C, int32_t *contig_rec) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -321,7 +338,7 @@ __device__ __forceinline__ bool index_find(const IndexView &ix, uint32_t h, uint
   for (uint32_t slot = ht_slot(h, ix.table_bits);; slot = (slot + 1) & mask) {
     const uint4 e = ix.table[slot];
     if (e.z == 0u) return false;
-    if (e.x == h) { off = e.y; cnt = e.z - 1u; return true; }
+    if (e.x == h) { off = e.y; cnt = e.w ? 0u : e.z - 1u; return true; }   // w: too frequent over all index shards (k_drop_keys)
   }
 }
 

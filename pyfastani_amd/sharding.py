@@ -213,3 +213,115 @@ def build_index_sharded(genomes, names=None, rank=0, world_size=1, group=None, d
     merged = Sketch(**params)
     merged._import_records(names, lengths, sbf, counter, rec)
     return merged.index()
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Reference-sharded index ("alternative when the index does not fit"): rank r indexes the references
+# ``r, r + world, ...`` only and every rank maps ALL queries against its shard.  Candidates, slides and the per-genome
+# identities only ever look at one reference contig / genome, so the rows of a shard are the rows the single index
+# would produce for those genomes -- provided the frequency filter (`size < threshold`, _fastani.pyx:946) sees the
+# position lists of the whole index.  That takes one exchange: the distinct hashes of every shard with their list
+# lengths are all-gathered, summed per hash, the threshold of Sketch_t::computeFreqHist is taken over the sums, and
+# the hashes that reach it are dropped from every shard's lookup.
+# ------------------------------------------------------------------------------------------------------------
+INT_MAX = 2**31 - 1
+
+
+def frequency_threshold(top, n_unique):
+    """The walk of ``getFreqThreshold`` over ``top``, the list lengths in descending order -- only the
+    first ``min(n_unique, ignore + 1)`` are needed: a run of equal lengths that continues past them ends the walk."""
+    to_ignore = int(np.float32(n_unique) * np.float32(0.001) / np.float32(100))
+    m = min(n_unique, to_ignore + 1)
+    top = np.asarray(top[:m], dtype=np.int64)
+    thr, i = INT_MAX, 0
+    while i < m:
+        j = i
+        while j < m and top[j] == top[i]:
+            j += 1
+        if j == m and m < n_unique:
+            break
+        if j < to_ignore:
+            thr, i = int(top[i]), j
+        elif j == to_ignore:
+            thr = int(top[i])
+            break
+        else:
+            break
+    return min(thr, INT_MAX)
+
+
+def merged_frequency(keys, counts):
+    """Threshold over the position lists of several shards and the hashes that reach it.  ``keys`` / ``counts``: the
+    concatenated distinct hashes (``int64``, 0 .. 2^32-1) and list lengths of all shards (a hash may repeat)."""
+    import torch
+    uniq, inverse = torch.unique(keys, return_inverse=True)
+    total = torch.zeros(uniq.numel(), dtype=torch.int64, device=keys.device).index_add_(0, inverse, counts)
+    n_unique = int(uniq.numel())
+    to_ignore = int(np.float32(n_unique) * np.float32(0.001) / np.float32(100))
+    m = min(n_unique, to_ignore + 1)
+    top = torch.topk(total, m).values.cpu().numpy() if m > 0 else np.zeros(0, np.int64)
+    thr = frequency_threshold(top, n_unique)
+    drop = uniq[total >= thr] if thr < INT_MAX else uniq[:0]
+    drop = torch.where(drop >= 2**31, drop - 2**32, drop).to(torch.int32)        # back to int32 bit patterns
+    return thr, drop
+
+
+def global_frequency(keys, counts, world_size=1, group=None):
+    """`merged_frequency` over the shards of all ranks (one all-gather of 16 bytes per distinct hash).
+
+    ``keys`` / ``counts``: this rank's distinct hashes (``int32`` bit patterns) and list lengths (`Mapper._export_lookup`).
+    Returns ``(threshold, drop_keys)``; the same on every rank."""
+    import torch
+    k = keys.to(torch.int64) & 0xFFFFFFFF
+    c = counts.to(torch.int64)
+    if world_size > 1:
+        import torch.distributed as dist
+        n = torch.tensor([k.numel()], dtype=torch.int64, device=k.device)
+        sizes = torch.zeros(world_size, dtype=torch.int64, device=k.device)
+        dist.all_gather_into_tensor(sizes, n, group=group)
+        sizes = sizes.cpu().tolist()
+        n_max = max(max(sizes), 1)
+        local = torch.zeros(2 * n_max, dtype=torch.int64, device=k.device)
+        local[: k.numel()] = k
+        local[n_max: n_max + k.numel()] = c
+        out = torch.empty(world_size * 2 * n_max, dtype=torch.int64, device=k.device)
+        dist.all_gather_into_tensor(out, local, group=group)
+        out = out.view(world_size, 2, n_max)
+        k = torch.cat([out[r, 0, : sizes[r]] for r in range(world_size)])
+        c = torch.cat([out[r, 1, : sizes[r]] for r in range(world_size)])
+    return merged_frequency(k, c)
+
+
+def build_ref_sharded_mapper(genomes, names=None, rank=0, world_size=1, group=None, device=None, **params):
+    """A `Mapper` over the references ``rank, rank + world, ...`` whose frequency filter is the one of the whole index.
+
+    Returns ``(mapper, owned)``: ``owned[i]`` is the global number of the mapper's i-th reference genome."""
+    import torch
+    from ._api import Sketch
+    n = len(genomes)
+    names = list(range(n)) if names is None else list(names)
+    dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+    owned = shard_indices(n, rank, world_size)
+    local = Sketch(**params)
+    for i in owned:
+        local.add_draft(names[i], genomes[i])
+    mapper = local.index()
+    keys, counts = mapper._export_lookup(dev)
+    thr, drop = global_frequency(keys, counts, world_size, group)
+    mapper._set_global_frequency(thr, drop)
+    return mapper, owned
+
+
+def query_ref_sharded(mapper, owned, queries, world_size=1, group=None, device=None, chunk=64):
+    """Map ALL ``queries`` (list of contig lists, the same on every rank) against this rank's reference shard and return
+    the hit table of the whole index: rows of all ranks with global reference numbers, ordered by (query, reference)."""
+    import torch
+    batch = mapper.upload_genomes(queries)
+    parts = [batch.query_rows(first, min(chunk, len(queries) - first)) for first in range(0, len(queries), chunk)]
+    rows = np.concatenate(parts) if parts else np.zeros(0, ROW_DTYPE)
+    rows = rows.copy()
+    rows["ref_genome_id"] = np.asarray(owned, dtype=np.int64)[rows["ref_genome_id"]] if len(rows) else rows["ref_genome_id"]
+    if world_size > 1:
+        dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        rows = tensor_to_rows(all_gather_rows(rows_to_tensor(rows, dev), group=group))
+    return rows[np.lexsort((rows["ref_genome_id"], rows["query_id"]))]

@@ -821,6 +821,108 @@ def test_sharded_index_build_two_ranks_one_gpu(tmp_path):
     assert (tmp_path / "idx0.ok").exists() and (tmp_path / "idx1.ok").exists()
 
 
+def _ref_sharded_case():
+    """Six 1 Mb references; two planted 45-mers sit in genomes 0 AND 1 -- with two shards (0,2,4 / 1,3,5) their hashes
+    occur ~150 times per shard and ~300 times over the whole index, so whether they are ignored depends on the sums."""
+    g = syn.rng(53)
+    n = 1_000_000
+    genomes = [syn.random_codes(g, n) for _ in range(6)]
+    r1, r2 = syn.random_codes(g, 45), syn.random_codes(g, 45)
+    for m in genomes[:2]:
+        for p in range(1000, n - 1000, n // 150):
+            m[p: p + 45] = r1
+        for p in range(2500, n - 1000, n // 75):
+            m[p: p + 45] = r2
+    refs = [[syn.to_ascii(x)] for x in genomes]
+    queries = [[syn.to_ascii(syn.mutate_codes(g, genomes[0], 0.02))], [syn.to_ascii(syn.mutate_codes(g, genomes[3], 0.04))],
+               [syn.to_ascii(syn.mutate_codes(g, genomes[1], 0.01))]]
+    return refs, queries
+
+
+def test_reference_sharded_index_matches_single_index():
+    """SURVEY.md 8e, alternative partitioning: every shard indexes a part of the references, the frequency threshold is
+    taken over the position lists of all shards (`sharding.merged_frequency`) and installed in every shard; the rows of
+    the shards together must be the rows of the single index.  Both shards live in this one process here."""
+    import torch
+    from pyfastani_amd import sharding
+    refs, queries = _ref_sharded_case()
+    world = 2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sk = pf.Sketch()
+        for i, r in enumerate(refs):
+            sk.add_draft(i, r)
+        single = sk.index()
+        want = np.concatenate([single.upload_genomes(queries).query_rows(0, len(queries))])
+        shards = []
+        for rank in range(world):
+            owned = sharding.shard_indices(len(refs), rank, world)
+            loc = pf.Sketch()
+            for i in owned:
+                loc.add_draft(i, refs[i])
+            shards.append((loc.index(), owned))
+    exported = [m._export_lookup("cuda") for m, _ in shards]
+    local_thr = [m.occurences_threshold for m, _ in shards]
+    k = torch.cat([a.to(torch.int64) & 0xFFFFFFFF for a, _ in exported])
+    c = torch.cat([b.to(torch.int64) for _, b in exported])
+    thr, drop = sharding.merged_frequency(k, c)
+    assert thr == single.occurences_threshold and thr < 2**31 - 1 and drop.numel() > 0
+    assert any(t != thr for t in local_thr)            # the shards on their own would filter differently
+    # a single shard run through global_frequency (world 1) finds its own threshold again
+    assert sharding.global_frequency(*exported[0])[0] == local_thr[0]
+    got = []
+    for m, owned in shards:
+        m._set_global_frequency(thr, drop)
+        assert m.occurences_threshold == thr
+        got.append(sharding.query_ref_sharded(m, owned, queries))
+    got = np.concatenate(got)
+    got = got[np.lexsort((got["ref_genome_id"], got["query_id"]))]
+    want = want[np.lexsort((want["ref_genome_id"], want["query_id"]))]
+    assert len(want) >= 3 and got.tobytes() == want.tobytes()
+
+
+def test_reference_sharded_two_ranks_one_gpu(tmp_path):
+    """The same through `build_ref_sharded_mapper` / `query_ref_sharded` on two gloo ranks that share GPU 0."""
+    import socket
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import os, sys, warnings
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np, torch.distributed as dist
+        import pyfastani_amd as pf
+        from pyfastani_amd import sharding
+        from test_gpu_parity import _ref_sharded_case
+        dist.init_process_group("gloo")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        refs, queries = _ref_sharded_case()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = pf.Sketch()
+            for i, r in enumerate(refs):
+                sk.add_draft(i, r)
+            single = sk.index()
+            want = single.upload_genomes(queries).query_rows(0, len(queries))
+            m, owned = sharding.build_ref_sharded_mapper(refs, rank=rank, world_size=world, device="cpu")
+            got = sharding.query_ref_sharded(m, owned, queries, world_size=world, device="cpu")
+        want = want[np.lexsort((want["ref_genome_id"], want["query_id"]))]
+        assert m.occurences_threshold == single.occurences_threshold
+        assert got.tobytes() == want.tobytes(), (rank, len(got), len(want))
+        dist.barrier(); dist.destroy_process_group()
+        open(os.path.join(%r, f"refshard{rank}.ok"), "w").write("OK")
+    """ % (ROOT, os.path.join(ROOT, "tests"), str(tmp_path)))
+    script = tmp_path / "worker.py"
+    script.write_text(code)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "refshard0.ok").exists() and (tmp_path / "refshard1.ok").exists()
+
+
 def test_fasta_ingest_matches_python_path(tmp_path):
     """Sketch.add_fasta / Mapper.upload_fasta (native parse + pack) against the same records fed through add_draft /
     query_draft: lower case, N runs, wrapped lines, a short contig, CRLF-free files."""

@@ -165,3 +165,89 @@ def test_exchange_and_merge_record_shards_world2(tmp_path):
     assert res.returncode == 0, res.stdout + res.stderr
     total = str(sum(len(g) for g in _fake_genome_records(5, 7)[0]))
     assert (tmp_path / "shard0.ok").read_text() == total and (tmp_path / "shard1.ok").read_text() == total
+
+
+def _brute_threshold(counts):
+    """getFreqThreshold restated naively: histogram of list lengths walked from the most frequent down."""
+    from collections import Counter
+    n_unique = len(counts)
+    ignore = int(np.float32(n_unique) * np.float32(0.001) / np.float32(100))
+    thr, total = 2**31 - 1, 0
+    for freq, n in sorted(Counter(counts).items(), reverse=True):
+        total += n
+        if total < ignore:
+            thr = freq
+        elif total == ignore:
+            thr = freq
+            break
+        else:
+            break
+    return thr
+
+
+def _fake_lookup_shards(seed, world, n_keys=250_000):
+    rng = np.random.default_rng(seed)
+    shards = []
+    common = rng.integers(0, 2**32, 40, dtype=np.uint64)            # hashes every shard holds, with long lists
+    for r in range(world):
+        keys = np.unique(np.concatenate([rng.integers(0, 2**32, n_keys, dtype=np.uint64), common]))
+        counts = rng.integers(1, 4, len(keys)).astype(np.int64)
+        counts[np.isin(keys, common)] = rng.integers(20, 60, int(np.isin(keys, common).sum()))
+        shards.append((keys.astype(np.uint32), counts))
+    return shards
+
+
+def test_merged_frequency_matches_histogram_walk():
+    import torch
+    for seed, world in ((1, 1), (2, 2), (3, 3)):
+        shards = _fake_lookup_shards(seed, world)
+        total = {}
+        for keys, counts in shards:
+            for k, c in zip(keys.tolist(), counts.tolist()):
+                total[k] = total.get(k, 0) + c
+        want_thr = _brute_threshold(list(total.values()))
+        k = torch.cat([torch.from_numpy(keys.astype(np.int64)) for keys, _ in shards])
+        c = torch.cat([torch.from_numpy(counts) for _, counts in shards])
+        thr, drop = sharding.merged_frequency(k, c)
+        assert thr == want_thr and thr < 2**31 - 1
+        assert sorted(drop.numpy().view(np.uint32).tolist()) == sorted(k for k, v in total.items() if v >= thr)
+    # fewer than 100 000 distinct hashes: nothing is ignored
+    thr, drop = sharding.merged_frequency(torch.arange(1000, dtype=torch.int64), torch.full((1000,), 7, dtype=torch.int64))
+    assert thr == 2**31 - 1 and drop.numel() == 0
+
+
+FREQ_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    sys.path.insert(0, {tests!r})
+    import numpy as np, torch, torch.distributed as dist
+    from pyfastani_amd import sharding
+    from test_sharding_gloo import _fake_lookup_shards
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    shards = _fake_lookup_shards(9, world)
+    keys, counts = shards[rank]
+    thr, drop = sharding.global_frequency(torch.from_numpy(keys.view(np.int32)), torch.from_numpy(counts.astype(np.int32)), world)
+    k = torch.cat([torch.from_numpy(a.astype(np.int64)) for a, _ in shards])
+    c = torch.cat([torch.from_numpy(b) for _, b in shards])
+    want_thr, want_drop = sharding.merged_frequency(k, c)
+    assert thr == want_thr and torch.equal(drop, want_drop) and drop.numel() > 0, (rank, thr, want_thr)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join({out!r}, f"freq{{rank}}.ok"), "w").write(str(thr))
+""")
+
+
+def test_global_frequency_world2(tmp_path):
+    """The exchange of a reference-sharded index (alternative partitioning) on CPU: two gloo ranks all-gather
+    their distinct hashes + list lengths and agree on the threshold and the dropped hashes of the union."""
+    script = tmp_path / "freq_worker.py"
+    script.write_text(FREQ_WORKER.format(root=ROOT, tests=os.path.join(ROOT, "tests"), out=str(tmp_path)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "freq0.ok").read_text() == (tmp_path / "freq1.ok").read_text()
