@@ -661,7 +661,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const int smax = sp.smax;
     const int64_t l_cap = sp.l_cap;
     // LDS also holds smax list offsets; the in-place merge keeps at most 32 seeds per thread in registers
-    static const int l1_threads = (int)env_u64("FA_L1_THREADS", 512);
+    // threads per fragment in k_l1: 256 while 16 seeds per thread suffice (4-wave workgroups, eight per CU: a 5 Mb query
+    // is one round of workgroups), else 512; FA_L1_THREADS = 256 / 512 / 1024 forces one
+    static const int l1_forced = (int)env_u64("FA_L1_THREADS", 0);
+    const int l1_threads = l1_forced ? l1_forced : (std::min(sp.seed_slots, lds_seed_cap_max(sp.smax)) <= 16 * 256 ? 256 : 512);
     const int l1_nt = l1_threads >= 1024 ? 1024 : (l1_threads >= 512 ? 512 : 256);
     const uint32_t seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * l1_nt));
     w.l_frag.ensure((size_t)l_cap); w.l_seq.ensure((size_t)l_cap); w.l_start.ensure((size_t)l_cap); w.l_end.ensure((size_t)l_cap + 4);
@@ -730,11 +733,13 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_l1_big, dim3((unsigned)F), dim3(L1_BIG_THREADS), lds, st, a);
       }
-      // threads per fragment (FA_L1_THREADS = 256 / 512 / 1024; 512 measured best: fewer seeds per thread shorten every
-      // thread's chain of dependent LDS round trips, 1024 threads pay more for barriers than they gain)
+      // (above 4096 seeds 512 threads measured best: fewer seeds per thread shorten every thread's chain of dependent
+      // LDS round trips; 1024 threads pay more for barriers than they gain)
       auto go = [&](auto nt_tag) {
         constexpr int NTT = decltype(nt_tag)::value;
         const size_t lds = l1_lds_bytes(seed_slots, smax);
+        static const bool dbg = getenv("FA_DEBUG_L1") != nullptr;
+        if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);
         if (seed_slots <= 16 * (uint32_t)NTT) {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
           hipLaunchKernelGGL((k_l1<NTT, 16>), dim3((unsigned)F), dim3(NTT), lds, st, a);

@@ -485,7 +485,7 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax) 
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
 // E = elements per thread the in-place merge can hold (16 for small fragments: fewer registers, more workgroups per CU).
 template <int NT, int E>
-__global__ __launch_bounds__(NT) void k_l1(L1Args a) {
+__global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sh_scan[NT / 64];
   __shared__ uint32_t sh_run;       // running offset (gather)
