@@ -1,0 +1,3 @@
+import json, sys
+d = json.loads(sys.stdin.read())
+print(sys.argv[1] if len(sys.argv) > 1 else "", round(d["value"]), {k: round(v, 4) for k, v in d["phases_ms"].items()})
