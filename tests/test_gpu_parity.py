@@ -839,14 +839,14 @@ def _ref_sharded_case():
     return refs, queries
 
 
-def test_reference_sharded_index_matches_single_index():
+@pytest.mark.parametrize("world", [2, 8])
+def test_reference_sharded_index_matches_single_index(world):
     """SURVEY.md 8e, alternative partitioning: every shard indexes a part of the references, the frequency threshold is
     taken over the position lists of all shards (`sharding.merged_frequency`) and installed in every shard; the rows of
     the shards together must be the rows of the single index.  Both shards live in this one process here."""
     import torch
     from pyfastani_amd import sharding
-    refs, queries = _ref_sharded_case()
-    world = 2
+    refs, queries = _ref_sharded_case()            # six references: with eight shards two of them are empty
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         sk = pf.Sketch()
