@@ -15,8 +15,13 @@ _SO = os.path.join(_HERE, "_build", "libfastani_oracle.so")
 
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("oracle_capi.cpp", "fastani_oracle.hpp")]
-    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    stale = lambda: not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)  # noqa: E731
+    if force or stale():
+        import fcntl
+        with open(_SO + ".lock", "w") as lock:                 # several processes may ask at once: one runs make
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 
