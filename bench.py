@@ -93,19 +93,27 @@ def main():
     if world > 1 and not args.replicated_index:
         # every rank packs and sketches references rank, rank+world, ...; the minimizer shards are
         # all-gathered (RCCL) and every rank indexes the merged records -- the same index a single Sketch builds
+        # (build_index_sharded votes before its first collective, so a rank-local failure raises on every rank; whatever
+        # happens after the exchange, every rank still reaches the agreement check below -- no rank is left in a collective)
+        failure, sig = None, [-1, -1, -1]
+        t0 = time.time()
         try:
-            t0 = time.time()
             mapper = sharding.build_index_sharded(refs, names, rank, world, device="cpu" if share_gpu else "cuda")
-            t_index = time.time() - t0
-            index_mode = f"sharded sketching x{world} + all-gather of minimizer shards"
-            check_t = torch.tensor([len(mapper.minimizers), mapper.occurences_threshold, len(mapper.lookup_index)], dtype=torch.int64,
-                                   device="cpu" if share_gpu else "cuda")
+            sig = [len(mapper.minimizers), mapper.occurences_threshold, len(mapper.lookup_index)]
+        except Exception as e:                     # noqa: BLE001
+            failure = e
+        t_index = time.time() - t0
+        index_mode = f"sharded sketching x{world} + all-gather of minimizer shards"
+        try:
+            check_t = torch.tensor(sig, dtype=torch.int64, device="cpu" if share_gpu else "cuda")
             lo, hi = check_t.clone(), check_t.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            if not torch.equal(lo, hi):
-                raise RuntimeError("ranks disagree on the merged index")
-        except Exception as e:                     # never lose the bench line to the setup phase: fall back to replicas
-            print(f"[bench] sharded index build failed on rank {rank}: {e!r}; building replicas", file=sys.stderr)
+            if failure is None and (int(lo[0]) < 0 or not torch.equal(lo, hi)):
+                failure = RuntimeError("ranks disagree on the merged index (or another rank failed)")
+        except Exception as e:                     # noqa: BLE001
+            failure = failure or e
+        if failure is not None:                    # never lose the bench line to the setup phase: fall back to replicas
+            print(f"[bench] sharded index build failed on rank {rank}: {failure!r}; building replicas", file=sys.stderr)
             mapper, index_mode = None, "replicated (sharded build failed)"
     if mapper is None:
         t0 = time.time()

@@ -201,10 +201,23 @@ def build_index_sharded(genomes, names=None, rank=0, world_size=1, group=None, d
     n = len(genomes)
     names = list(range(n)) if names is None else list(names)
     dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
-    local = Sketch(**params)
-    for i in shard_indices(n, rank, world_size):
-        local.add_draft(i, genomes[i])
-    rec, (lengths, sbf, counter) = local._export_records(dev)
+    failure = None
+    try:
+        local = Sketch(**params)
+        for i in shard_indices(n, rank, world_size):
+            local.add_draft(i, genomes[i])
+        rec, (lengths, sbf, counter) = local._export_records(dev)
+    except Exception as e:                       # noqa: BLE001 -- reported to every rank below
+        failure = e
+    if world_size > 1:
+        # a rank that failed on its own share must not leave the others waiting in the all-gather: vote first
+        import torch.distributed as dist
+        ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0:
+            raise RuntimeError(f"sketching the reference shard failed on some rank (this rank: {failure!r})") from failure
+    elif failure is not None:
+        raise failure
     if world_size > 1:
         gathered, rec_off, ctg, lengths = exchange_record_shards(rec, lengths, sbf, n, rank, world_size, group)
         rec, sbf = merge_record_shards(gathered, rec_off, ctg)
