@@ -724,10 +724,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       // into LDS-sized chunks at contig boundaries by k_l1_big first; what it cannot cut stays with k_l1's HBM path
       static const bool l1_big = !(getenv("FA_L1_BIG") && atoi(getenv("FA_L1_BIG")) == 0);
       a.big_state = nullptr; a.big_enabled = 0; a.big_cap = 0;
-      if (l1_big && sp.scratch_words > 0) {
+      const int64_t big_room = (int64_t)160 * 1024 - 2048 - ((int64_t)smax + 2) * 16;   // LDS left for a chunk's seeds
+      if (l1_big && sp.scratch_words > 0 && big_room >= 4 * 2048) {
         w.big_state.ensure((size_t)F);
-        const size_t room = (size_t)160 * 1024 - 2048 - ((size_t)smax + 2) * 16;
-        a.big_cap = (uint32_t)std::min<size_t>((size_t)L1_BIG_E * L1_BIG_THREADS, room / 4 / 256 * 256);
+        a.big_cap = (uint32_t)std::min<int64_t>((int64_t)L1_BIG_E * L1_BIG_THREADS, big_room / 4 / 256 * 256);
         a.big_state = w.big_state.p; a.big_enabled = 1;
         const size_t lds = l1_big_lds_bytes(a.big_cap, smax);
         if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -702,6 +702,27 @@ def test_protein_small_k_and_wide_strings(golden_dir):
         assert len(got) == 1 and got[0].matches >= 9
 
 
+def test_huge_sketch_with_seed_overflow():
+    # protein mode (w = 1) with 12 000-residue fragments: a fragment keeps ~12 000 minimizers, far beyond what the LDS
+    # tables of the chunked L1 kernel are laid out for, and four copies of the reference give it ~48 000 seed hits, more
+    # than the LDS merge holds: the pass must take the HBM sort of k_l1 (k_l1_big stands aside) and still agree
+    g = syn.rng(98)
+    amino = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    prots = [bytes(amino[g.integers(0, 20, 13_000)]) for _ in range(3)]
+    params = dict(k=7, fragment_length=12_000, protein=True, minimum_fraction=0.0)
+    refs = [prots for _ in range(4)]
+    query = []
+    for p in prots:
+        a = np.frombuffer(p, dtype=np.uint8).copy()
+        m = g.random(len(a)) < 0.03
+        a[m] = amino[g.integers(0, 20, int(m.sum()))]
+        query.append(bytes(a))
+    mapper, hits, ohits, det = run_both(params, refs, query, threads=8)
+    assert len(ohits) == 4 and ohits[0][2] == 3
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+
+
 def test_sharding_all_vs_all_single_rank():
     from pyfastani_amd import sharding
     g = syn.rng(100)
