@@ -738,6 +738,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       auto go = [&](auto nt_tag) {
         constexpr int NTT = decltype(nt_tag)::value;
         const size_t lds = l1_lds_bytes(seed_slots, smax);
+        FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS tables of the L1 kernel");
         static const bool dbg = getenv("FA_DEBUG_L1") != nullptr;
         if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);
         if (seed_slots <= 16 * (uint32_t)NTT) {
