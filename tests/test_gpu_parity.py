@@ -479,6 +479,30 @@ def test_chunked_l1_and_its_fallback(layout):
     assert hit_tuples(hits) == ohits
 
 
+def test_chunked_l1_more_loci_than_its_scratch():
+    # 70 % identity needs only two seed hits per candidate, and the references hold 26-base pieces of the query more than
+    # a fragment apart: 31 370 seed hits (values from the oracle) in 7 605 separate loci.  k_l1_big collects loci in a
+    # fifth of the fragment's scratch (32 768 words: 6 553 loci); they do not fit, so it hands the fragment back to k_l1,
+    # whose HBM path writes them straight to their place.
+    g = syn.rng(972)
+    q = syn.random_codes(g, 3000)
+    refs = []
+    for _ in range(100):
+        c = syn.random_codes(g, 80 * 3100)
+        for j in range(80):
+            a = int(g.integers(0, 3000 - 26))
+            c[j * 3100 + 100: j * 3100 + 126] = q[a: a + 26]
+        refs.append([syn.to_ascii(c)])
+    params = dict(percentage_identity=70.0, minimum_fraction=0.0)
+    mapper, hits, ohits, det = run_both(params, refs, [syn.to_ascii(q)], threads=8)
+    n = C.c_int64(0)
+    arr = [np.empty(1 << 14, np.int32) for _ in range(4)]
+    check(lib.fa_mapper_debug_l1(mapper._h, *[a.ctypes.data for a in arr], 1 << 14, C.byref(n)))
+    assert n.value == 7605
+    assert gpu_mappings(mapper) == oracle_mappings(det) and len(det["mappings"]["rseq"]) > 5000
+    assert hit_tuples(hits) == ohits
+
+
 def test_chunked_l1_switched_off_matches():
     # FA_L1_BIG=0 keeps every oversized fragment on the HBM sort: same rows as the chunked path
     import textwrap
