@@ -782,7 +782,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         return ln;
       };
       const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
-      const size_t lds8 = scan_lds(lanes8, 1), lds16 = scan_lds(lanes16, 2);
+      static const size_t scan_pad = (size_t)env_u64("FA_SCAN_LDS_PAD", 0);   // experiment: fewer scan workgroups per CU
+      const size_t lds8 = scan_lds(lanes8, 1) + scan_pad, lds16 = scan_lds(lanes16, 2);
       auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
         if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
         hipLaunchKernelGGL(ev_kernel, dim3((unsigned)F), dim3(EV_THREADS), ev_lds, st, a);
