@@ -312,8 +312,19 @@ def cpu_baseline(args, anc):
         "value": repeats * n_refs / seconds, "unit": "pairs/s", "cores": cores, "kind": "port",
         "sample": f"1 query x {n_refs} refs ({n_related} related) of {args.length / 1e6:g} Mb, Mapper.query_draft only, "
                   f"repeated {repeats}x on all cores (~{repeats * det1['seconds']:.0f} s of CPU work)",
-        "seconds": seconds, "single_thread_value": n_refs / det1["seconds"], "hits": len(hits),
+        "seconds": seconds, "single_thread_value": n_refs / det1["seconds"], "hits": len(hits), "cpu_model": _cpu_model(),
     }
+
+
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 if __name__ == "__main__":
