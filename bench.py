@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """Headline benchmark: genome-pair ANI estimates per second on MI355X (BASELINE.json metric).
 
-Workload (BASELINE.json configs[1]): one 5 Mb query genome x 100 synthetic 5 Mb reference genomes (60 related to
-the query's ancestor at mixed divergence, 40 unrelated), k=16, fragment_length=3000 (w=24).  The index is built
-once, untimed, and stays resident in HBM; the query genome is packed 2-bit and resident in HBM before the timed
-region.  One *step* = one pass of the hot path over that query: K1 minimizer extraction of its 1666 fragments,
-sort/unique, index lookup, L1 candidate regions, L2 sliding-window Jaccard and the core-genome identity
-reduction, ending with the 100-pair hit table in device memory (= Mapper.query_draft up to computeCGI,
-src/pyfastani/_fastani.pyx:1006-1118 of the reference, which is also what the reference's own benchmark times).
+Workload (BASELINE.json configs[1], generator `pyfastani_amd.workloads.config2_*`, seed 1000): one 5 Mb query genome
+x 100 synthetic 5 Mb reference genomes (60 related to the query's ancestor at mixed divergence, 40 unrelated), k=16,
+fragment_length=3000 (w=24).  The index is built once, untimed, and stays resident in HBM.
 
-With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank holds a replica of the index
-and maps its own query genome (queries are sharded, weak scaling); each step ends with the RCCL all-gather of the
-per-pair hit tables.  value = pairs processed by all ranks / max-over-ranks time.
+`value` is the DEVICE-RESIDENT rate the bench contract asks for: the query genome is packed 2-bit and resident in HBM
+before the timed region, and one *step* = one pass of the hot path over it -- K1 minimizer extraction of its 1666
+fragments, sort/unique, index lookup, L1 candidate regions, L2 sliding-window Jaccard and the core-genome identity
+reduction -- ending with the 100-pair hit table in device memory (= Mapper.query_draft from the fragment loop up to
+computeCGI, src/pyfastani/_fastani.pyx:1097-1118 of the reference).  That is NOT the call the reference's own
+benchmark times: benches/mapping/bench.py:49-53 times `mapper.query_draft(contigs, threads)` from host bytes to the
+`Hit` list.  The `boundary_call` object of the JSON line reports exactly that call on the same workload (host packing,
+PCIe upload, the pass, row download, `Hit` construction), and `cpu_baseline` -- the same host call on the CPU oracle --
+is to be compared with `boundary_call`, not with `value`.
+
+The rows the timed steps wrote are compared with the CPU oracle's rows for the same query and index, outside the timed
+region (`parity_checked`, `rows_compared`); a wrong kernel fails the run instead of printing a number.
+
+With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling by default -- every rank holds
+a replica of the index (built cooperatively: sketch shards all-gathered over RCCL) and maps its own query genome, the
+hit tables of all steps are exchanged by ONE all-gather at the end of the timed region.  --strong maps BASELINE config
+3 instead (families x members genomes all-vs-all, 10^6 pairs at the default 20 x 50): the query genomes are dealt to
+the ranks balanced by fragment count, every rank maps its share against its replica, and one RCCL all-gather of the
+hit table ends each step; value = total pairs / max-over-ranks time.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,8 +39,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# Algorithmic bytes
-K1_BYTES_PER_BASE = 0.25 + 12.0 * 2.0 / 25.0      # 2-bit input + 12 B records at density 2/(w+1), w = 24
+TRAFFIC_PROFILE = "r02_traffic.json"
 
 
 def parse_args():
@@ -38,11 +50,21 @@ def parse_args():
     ap.add_argument("--refs", type=int, default=100, help="reference genomes in the index (60%% related)")
     ap.add_argument("--length", type=int, default=5_000_000)
     ap.add_argument("--batch", type=int, default=1, help="query genomes mapped per step and per GPU (1 = BASELINE configs[1])")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU oracle legs (no parity check, no cpu_baseline)")
     ap.add_argument("--clients", type=int, default=4, help="N=1 only: host threads of the informational concurrent-clients leg (0 = skip)")
     ap.add_argument("--replicated-index", action="store_true", help="N>1: every rank sketches all references itself")
-    ap.add_argument("--cpu-refs", type=int, default=10, help="references in the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-refs", type=int, default=0, help="references in the CPU-oracle sample (0 = all of --refs: the timed rows themselves are checked)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: BASELINE config 3 (all-vs-all) sharded by fragment count")
+    ap.add_argument("--families", type=int, default=20, help="--strong: families of config 3")
+    ap.add_argument("--members", type=int, default=50, help="--strong: members per family of config 3")
     return ap.parse_args()
+
+
+def git_head():
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:                              # noqa: BLE001 -- the GPU box holds a snapshot without .git
+        return None
 
 
 def main():
@@ -72,29 +94,44 @@ def main():
 
     import __graft_entry__ as entry
     entry.build()
-    import pyfastani_amd as pf
-    from pyfastani_amd import synthetic as syn, sharding
     from pyfastani_amd._lib import lib, check
 
     check(lib.fa_set_device(local_rank))
+    ctx = dict(args=args, rank=rank, world=world, share_gpu=share_gpu, torch=torch, dist=dist)
+    result = strong_scaling(ctx) if args.strong else weak_scaling(ctx)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
 
-    # ---- synthetic workload (identical index on every rank; one query genome per rank) ----
-    n_related = int(round(args.refs * 0.6))
-    g = syn.rng(1000)
-    anc = syn.random_codes(g, args.length)
-    names, refs = [], []
-    for i in range(args.refs):
-        if i < n_related:
-            d = syn.DIVERGENCES[i % len(syn.DIVERGENCES)]
-            names.append(f"A{i:03d}"); refs.append([syn.to_ascii(syn.mutate_codes(g, anc, d))])
-        else:
-            names.append(f"U{i:03d}"); refs.append([syn.to_ascii(syn.random_codes(g, args.length))])
+
+def fence(ctx):
+    if ctx["world"] > 1:
+        ctx["dist"].barrier()
+    ctx["torch"].cuda.synchronize()
+
+
+def max_over_ranks(ctx, seconds):
+    if ctx["world"] == 1:
+        return seconds
+    torch, dist = ctx["torch"], ctx["dist"]
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if ctx["share_gpu"] else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def build_mapper(ctx, names, refs):
+    """The index over `refs` on every rank: sketched cooperatively for N > 1, else one Sketch."""
+    import pyfastani_amd as pf
+    from pyfastani_amd import sharding
+    args, rank, world, share_gpu, torch, dist = (ctx[k] for k in ("args", "rank", "world", "share_gpu", "torch", "dist"))
     mapper, index_mode, t_pack, t_index = None, "single sketch", 0.0, 0.0
     if world > 1 and not args.replicated_index:
-        # every rank packs and sketches references rank, rank+world, ...; the minimizer shards are
-        # all-gathered (RCCL) and every rank indexes the merged records -- the same index a single Sketch builds
-        # (build_index_sharded votes before its first collective, so a rank-local failure raises on every rank; whatever
-        # happens after the exchange, every rank still reaches the agreement check below -- no rank is left in a collective)
+        # every rank packs and sketches references rank, rank+world, ...; the minimizer shards are all-gathered (RCCL) and
+        # every rank indexes the merged records -- the same index a single Sketch builds (build_index_sharded votes before
+        # its first collective, so a rank-local failure raises on every rank; whatever happens after the exchange, every
+        # rank still reaches the agreement check below -- no rank is left in a collective)
         failure, sig = None, [-1, -1, -1]
         t0 = time.time()
         try:
@@ -107,7 +144,8 @@ def main():
         try:
             check_t = torch.tensor(sig, dtype=torch.int64, device="cpu" if share_gpu else "cuda")
             lo, hi = check_t.clone(), check_t.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             if failure is None and (int(lo[0]) < 0 or not torch.equal(lo, hi)):
                 failure = RuntimeError("ranks disagree on the merged index (or another rank failed)")
         except Exception as e:                     # noqa: BLE001
@@ -124,10 +162,20 @@ def main():
         t0 = time.time()
         mapper = sk.index()
         t_index = time.time() - t0
+    return mapper, index_mode, t_pack, t_index
+
+
+def weak_scaling(ctx):
+    args, rank, world, share_gpu, torch, dist = (ctx[k] for k in ("args", "rank", "world", "share_gpu", "torch", "dist"))
+    from pyfastani_amd import workloads
+    from pyfastani_amd._batch import ROW_DTYPE
+    from pyfastani_amd._lib import lib, check
+
+    # ---- synthetic workload (identical index on every rank; one query genome per rank) ----
+    anc, names, refs = workloads.config2_references(args.refs, args.length)
+    mapper, index_mode, t_pack, t_index = build_mapper(ctx, names, refs)
     n_min = len(mapper.minimizers)
-    del refs
-    gq = syn.rng(5000 + rank)
-    queries = [[syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))] for _ in range(args.batch)]
+    queries = workloads.config2_query(anc, rank, args.batch)
     batch = mapper.upload_genomes(queries)
     n_pairs_step = args.refs * args.batch
 
@@ -135,6 +183,7 @@ def main():
     # single all-gather at the end of the timed region -- the only collective of the path (queries are independent).
     cap_rows = max(n_pairs_step, 1)
     table = torch.zeros((max(args.steps, args.warmup, 1), cap_rows + 1, 5), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()                    # the library writes on its own stream: the memset above must have landed
     counts = np.zeros(table.shape[0], dtype=np.int32)
     row_ptr = [table[i, 1:].data_ptr() for i in range(table.shape[0])]
 
@@ -153,16 +202,12 @@ def main():
         dist.all_gather_into_tensor(out, local.view(-1))
         return out.view(world, k, cap_rows + 1, 5)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for i in range(args.warmup):
         step(i)
     exchange(max(args.warmup, 1))
     phase_ms = np.zeros(5)
-    fence()
+    n_last = 0
+    fence(ctx)
     t0 = time.perf_counter()
     for i in range(args.steps):
         n_last = step(i)
@@ -170,70 +215,104 @@ def main():
         lib.fa_mapper_last_timings(mapper._h, ms, 8)     # HIP-event timings of this step, on the library's stream
         phase_ms += np.array(list(ms)[:5])
     gathered = exchange(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    fence(ctx)
+    elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
     # hits of one step over all ranks (every rank holds the whole table now)
     n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if world > 1 else int(n_last)
     phase_ms /= max(args.steps, 1)
+    if rank != 0:
+        return None
 
-    result = None
-    if rank == 0:
-        value = world * n_pairs_step * args.steps / elapsed
-        # ---- roofline of the dominant kernel, from the HIP-event timings taken inside the timed region ----
-        phase = dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase_ms]))
-        # K1 alone, repeated, for the minimizer-extraction roofline the north star asks for
-        k1_ms, bases, mins = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
-        check(lib.fa_bench_sketch_kernel(mapper._h, batch._h, 50, C.byref(k1_ms), C.byref(bases), C.byref(mins)))
-        k1_bytes = bases.value * 0.25 + mins.value * 12.0
-        k1_gbs = k1_bytes / (k1_ms.value * 1e-3) / 1e9
-        ms = (C.c_float * 8)()
-        lib.fa_mapper_last_timings(mapper._h, ms, 8)
-        l2_records, n_loci = float(ms[5]), float(ms[6])
-        # every reference record inside a locus range is one 12-byte MinimizerInfo of the reference's layout
-        l2_bytes = l2_records * 12.0
-        l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
-        l2_name = "k_l2_events+k_l2_scan"
-        dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
-        roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
-        traffic = profiled_traffic(["k_l2_events<unsigned short, true>", "k_l2_scan<unsigned short, unsigned char, 64>"]
-                                   if dominant == l2_name else ["k_sketch_tiles<16, false>"]) if args.batch == 1 and args.refs == 100 else None
-        result = {
-            "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
-            "value": value,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.batch} query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
-                       "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
-                       "index_minimizers": n_min, "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "kernel_ms": roof[1],
-                         "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes},
-            "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_tiles", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,
-                                "algorithmic_bytes": k1_bytes},
-            "phases_ms": phase,
-        }
-        if world == 1 and args.clients > 1:
+    value = world * n_pairs_step * args.steps / elapsed
+    # ---- roofline of the dominant kernel, from the HIP-event timings taken inside the timed region ----
+    phase = dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase_ms]))
+    # K1 alone, repeated, for the minimizer-extraction roofline the north star asks for
+    k1_ms, bases, mins = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
+    check(lib.fa_bench_sketch_kernel(mapper._h, batch._h, 50, C.byref(k1_ms), C.byref(bases), C.byref(mins)))
+    k1_bytes = bases.value * 0.25 + mins.value * 12.0   # 2-bit input + 12 B per emitted MinimizerInfo
+    k1_gbs = k1_bytes / (k1_ms.value * 1e-3) / 1e9
+    ms = (C.c_float * 8)()
+    lib.fa_mapper_last_timings(mapper._h, ms, 8)
+    l2_records, n_loci = float(ms[5]), float(ms[6])
+    # every reference record inside a locus range is one 12-byte MinimizerInfo of the reference's layout
+    l2_bytes = l2_records * 12.0
+    l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
+    l2_name = "k_l2_events+k_l2_scan"
+    dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
+    roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
+    traffic, traffic_source = (profiled_traffic("l2" if dominant == l2_name else "k1")
+                               if args.batch == 1 and args.refs == 100 and args.length == 5_000_000 else (None, None))
+    result = {
+        "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
+        "value": value,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.batch} query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
+                   "timed_region": "device-resident pass (packed query in HBM -> hit rows in HBM); the host-bytes -> Hit-list call is `boundary_call`",
+                   "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
+                   "index_minimizers": n_min, "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack, "head": git_head()},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": roof[1],
+                     "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes},
+        "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_tiles", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,
+                            "algorithmic_bytes": k1_bytes},
+        "phases_ms": phase,
+    }
+    if world == 1:
+        timed_rows = [table[i, 1: counts[i] + 1].cpu().numpy().reshape(-1).view(ROW_DTYPE) for i in range(args.steps)]
+        result["boundary_call"] = boundary_call(args, mapper, queries[0], timed_rows)
+        if args.clients > 1:
             result["concurrent_clients"] = concurrent_clients(args, batch, cap_rows, n_pairs_step)
-        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
-            result["cpu_baseline"] = cpu_baseline(args, anc)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+        if not args.no_cpu_baseline:              # the CPU oracle legs are an N=1 measurement (rank 0 only)
+            result.update(oracle_legs(args, anc, names, refs, mapper, queries[0], timed_rows))
+    return result
+
+
+def boundary_call(args, mapper, query, timed_rows):
+    """The call the reference's benchmark times (benches/mapping/bench.py:49-53): `Mapper.query_draft(contigs)` from host
+    bytes to the sorted `Hit` list -- host packing, PCIe upload, the device pass, row download, minimum-fraction filter
+    and `Hit` construction (_fastani.pyx:1138-1168 -> :1006-1136).  Never `value`; `cpu_baseline` is its CPU twin."""
+    from pyfastani_amd._lib import lib
+    contigs = [bytes(c) for c in query]             # plain host bytes, as a caller of the reference would hold them
+    for _ in range(max(args.warmup, 1)):
+        hits = mapper.query_draft(contigs)
+    n = max(args.steps, 1)
+    split = np.zeros(16)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        hits = mapper.query_draft(contigs)
+        ms = (C.c_float * 16)()
+        lib.fa_mapper_last_timings(mapper._h, ms, 16)
+        split += np.array(list(ms))
+    dt = (time.perf_counter() - t0) / n
+    split /= n
+    # the hits must be the rows of the timed steps, filtered and sorted (same query, same index)
+    want = mapper._rows_to_hits([_Row(r) for r in timed_rows[-1]], sum(len(c) for c in contigs)) if timed_rows else None
+    same = want is not None and [(h.name, h.identity, h.matches, h.fragments) for h in hits] == [(h.name, h.identity, h.matches, h.fragments) for h in want]
+    native = float(split[10] + split[11] + split[12] + split[13])
+    return {"call": "Mapper.query_draft(host bytes) -> list[Hit]", "ms_per_call": dt * 1e3, "value": args.refs / dt, "unit": "pairs/s",
+            "calls": n, "hits": len(hits), "hits_match_timed_rows": bool(same),
+            "split_ms": {"host_pack": float(split[10]), "fragment_tile_tables": float(split[11]), "h2d_upload": float(split[12]),
+                         "device_pass_and_rows_d2h": float(split[13]), "device_pass_events": float(split[4]),
+                         "python_binding_and_hits": dt * 1e3 - native}}
+
+
+class _Row:
+    __slots__ = ("query_id", "ref_genome_id", "count_seq", "total_query_fragments", "identity")
+
+    def __init__(self, r):
+        self.query_id, self.ref_genome_id = int(r["query_id"]), int(r["ref_genome_id"])
+        self.count_seq, self.total_query_fragments = int(r["count_seq"]), int(r["total_query_fragments"])
+        self.identity = float(r["identity"])
 
 
 def concurrent_clients(args, batch, cap_rows, n_pairs_step):
@@ -244,6 +323,7 @@ def concurrent_clients(args, batch, cap_rows, n_pairs_step):
     import torch
     k = args.clients
     tables = [torch.zeros((cap_rows, 5), dtype=torch.int32, device="cuda") for _ in range(k)]
+    torch.cuda.synchronize()                    # the library's streams do not wait for torch's memsets
 
     def run(i, n):
         for _ in range(n):
@@ -264,55 +344,154 @@ def concurrent_clients(args, batch, cap_rows, n_pairs_step):
             "ms_per_step": dt / (n * k) * 1e3}
 
 
-def profiled_traffic(kernels):
-    """HBM bytes per launch of the given kernels from the committed rocprofv3 PMC passes (profiles/r01_traffic.json,
-    collected on this exact workload): FETCH_SIZE and WRITE_SIZE come from separate passes, are in KB, and FETCH_SIZE is
-    doubled as MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read from inside the benchmark, so
-    this is the profiled value, not a live one; None if the profile is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+def profiled_traffic(which):
+    """HBM bytes per step of the dominant stage from the committed rocprofv3 PMC passes (profiles/r02_traffic.json,
+    collected on this exact workload by scripts/collect_profiles.sh): FETCH_SIZE and WRITE_SIZE come from separate
+    passes, are in KB, and FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read
+    from inside the benchmark, so this is the profiled value, not a live one; (None, None) if the profile is missing."""
+    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     try:
-        table = json.load(open(path))["kernels"]
-        return sum((2.0 * table[k]["fetch_size_kb"] + table[k]["write_size_kb"]) * 1024.0 for k in kernels)
+        doc = json.load(open(path))
+        table = doc["kernels"]
+        pick = [k for k in table if (k.startswith("k_l2_") if which == "l2" else k.startswith("k_sketch_tiles<16, false>"))]
+        if not pick:
+            return None, None
+        total = sum((2.0 * table[k]["fetch_size_kb"] + table[k]["write_size_kb"]) * 1024.0 * table[k].get("launches_per_step", 1) for k in pick)
+        return total, f"profiles/{TRAFFIC_PROFILE}@{doc.get('head', 'unknown')}"
     except (OSError, KeyError, ValueError):
-        return None
+        return None, None
 
 
-def cpu_baseline(args, anc):
-    """The CPU oracle (a restatement: the reference's own C++ cannot be built) timed on this box's host
-    cores on a bounded sample of the same workload: the same 5 Mb query against the first `cpu_refs` references
-    (same 60/40 related/unrelated mix), query_draft only -- the index build is excluded exactly as on the GPU."""
+def oracle_legs(args, anc, names, refs, mapper, query, timed_rows):
+    """Parity check and CPU baseline on the CPU oracle (a restatement: the reference's own C++ cannot be built,
+    DESIGN.md section 2), on this box's host cores, outside the timed region.
+
+    By default the oracle indexes ALL references of the workload, so (a) the rows every timed step wrote are compared
+    with the oracle's rows for the same query -- refGenomeId, countSeq, totalQueryFragments and the float32 identity bit
+    for bit -- and every L2 mapping of a boundary call with the oracle's mappings, and (b) `cpu_baseline` times the full
+    host call (`query_draft`: fragment sketching, lookup, L1, L2, computeCGI, hit filter) of the same step, repeated until
+    about 20-30 s of CPU work are done.  --cpu-refs N < --refs maps a smaller sample on both sides instead."""
+    import pyfastani_amd as pf
     from oracle.oracle import OracleSketch
-    from pyfastani_amd import synthetic as syn
+    from pyfastani_amd import _lib
+    from pyfastani_amd._lib import lib, check
     cores = os.cpu_count() or 1
-    n_refs = args.cpu_refs
-    n_related = int(round(n_refs * 0.6))
-    g = syn.rng(1000)
-    anc2 = syn.random_codes(g, args.length)  # same stream as the GPU workload: identical ancestor
-    assert np.array_equal(anc, anc2)
+    n_refs = args.cpu_refs if 0 < args.cpu_refs < args.refs else args.refs
+    full = n_refs == args.refs
+    if full:
+        s_names, s_refs, g_mapper = names, refs, mapper
+    else:
+        # the sample keeps the workload's 60/40 mix of related and unrelated references
+        n_rel, n_all_rel = int(round(n_refs * 0.6)), int(round(args.refs * 0.6))
+        pick = list(range(n_rel)) + list(range(n_all_rel, n_all_rel + n_refs - n_rel))
+        s_names, s_refs = [names[i] for i in pick], [refs[i] for i in pick]
+        sk = pf.Sketch()
+        for name, contigs in zip(s_names, s_refs):
+            sk.add_draft(name, contigs)
+        g_mapper = sk.index()
+    t0 = time.time()
     osk = OracleSketch()
-    for i in range(n_refs):
-        if i < n_related:
-            d = syn.DIVERGENCES[i % len(syn.DIVERGENCES)]
-            osk.add_genome(f"A{i:03d}", syn.to_ascii(syn.mutate_codes(g, anc, d)))
-        else:
-            osk.add_genome(f"U{i:03d}", syn.to_ascii(syn.random_codes(g, args.length)))
+    osk.add_drafts(s_names, s_refs, threads=cores)
     osk.index()
-    gq = syn.rng(5000)
-    query = syn.to_ascii(syn.mutate_codes(gq, anc, 0.05))
-    # single thread: one pass over the query (~1 s of CPU work); all cores: the same query repeated until about 20 s of
-    # CPU work have been done, so that thread start-up does not dominate a 20 ms measurement
-    hits1, det1 = osk.query_draft([query], threads=1, details=True)
-    repeats = 1 if cores == 1 else int(min(64, max(4, round(20.0 / max(det1["seconds"], 1e-3)))))
-    osk.query_draft([query], threads=cores)                      # warm the thread pool / page cache
+    t_oracle_index = time.time() - t0
+    ohits, det = osk.query_draft(query, threads=cores, details=True)
+    # ---- parity: rows ----
+    o = det["rows"]
+    if full:
+        gpu_row_sets = timed_rows
+    else:
+        gpu_row_sets = [g_mapper.upload_genomes([query]).query_rows(0, 1)]
+    rows_compared = 0
+    for rows in gpu_row_sets:
+        ok = (len(rows) == len(o["genome"]) and np.array_equal(rows["ref_genome_id"], o["genome"])
+              and np.array_equal(rows["count_seq"], o["count"]) and np.array_equal(rows["identity"], o["identity"])
+              and bool(np.all(rows["total_query_fragments"] == det["total_fragments"])))
+        if not ok:
+            raise SystemExit(f"PARITY FAILURE: the HIP rows differ from the CPU oracle's ({len(rows)} vs {len(o['genome'])} rows)")
+        rows_compared += len(rows)
+    # ---- parity: every L2 mapping of one boundary call, and its hits ----
+    hits = g_mapper.query_draft([bytes(c) for c in query])
+    cap = 1 << 20
+    buf = (_lib.Mapping * cap)()
+    n = C.c_int64(0)
+    check(lib.fa_mapper_debug_mappings(g_mapper._h, buf, cap, C.byref(n)))
+    got = sorted((buf[i].query_seq_id, buf[i].ref_seq_id, buf[i].ref_start_pos, buf[i].sketch_size, buf[i].conserved) for i in range(min(n.value, cap)))
+    m = det["mappings"]
+    want = sorted(zip(m["qseq"].tolist(), m["rseq"].tolist(), m["rstart"].tolist(), m["sketch"].tolist(), m["shared"].tolist()))
+    if n.value > cap or got != want:
+        raise SystemExit(f"PARITY FAILURE: the HIP L2 mappings differ from the CPU oracle's ({n.value} vs {len(want)})")
+    if [(h.name, h.identity, h.matches, h.fragments) for h in hits] != ohits:
+        raise SystemExit("PARITY FAILURE: the HIP hit list differs from the CPU oracle's")
+    # ---- CPU baseline: single thread once, then all cores until ~20-30 s of CPU work are done ----
+    _, det1 = osk.query_draft(query, threads=1, details=True)
+    repeats = 1 if cores == 1 else int(min(64, max(2, round(25.0 / max(det1["seconds"], 1e-3)))))
+    osk.query_draft(query, threads=cores)                      # warm the thread pool / page cache
     seconds = 0.0
     for _ in range(repeats):
-        hits, det = osk.query_draft([query], threads=cores, details=True)
-        seconds += det["seconds"]
+        _, d = osk.query_draft(query, threads=cores, details=True)
+        seconds += d["seconds"]
+    n_rel = sum(1 for x in s_names if x.startswith("A"))
     return {
-        "value": repeats * n_refs / seconds, "unit": "pairs/s", "cores": cores, "kind": "port",
-        "sample": f"1 query x {n_refs} refs ({n_related} related) of {args.length / 1e6:g} Mb, Mapper.query_draft only, "
-                  f"repeated {repeats}x on all cores (~{repeats * det1['seconds']:.0f} s of CPU work)",
-        "seconds": seconds, "single_thread_value": n_refs / det1["seconds"], "hits": len(hits), "cpu_model": _cpu_model(),
+        "parity_checked": True, "rows_compared": rows_compared, "mappings_compared": len(want),
+        "parity": {"against": "oracle/ (CPU restatement)", "index_refs": n_refs, "timed_steps_checked": len(gpu_row_sets) if full else 0,
+                   "hits_compared": len(ohits), "oracle_index_build_s": t_oracle_index},
+        "cpu_baseline": {
+            "value": repeats * n_refs / seconds, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 query x {n_refs} refs ({n_rel} related) of {args.length / 1e6:g} Mb"
+                      + (" = the full step" if full else "") + f", Mapper.query_draft (host bytes -> hits) only, "
+                      f"repeated {repeats}x on all cores (~{repeats * det1['seconds']:.0f} s of CPU work)",
+            "compare_with": "boundary_call", "seconds": seconds, "single_thread_value": n_refs / det1["seconds"],
+            "hits": len(ohits), "cpu_model": _cpu_model()},
+    }
+
+
+def strong_scaling(ctx):
+    """BASELINE config 3 (families x members genomes of --length, all-vs-all) with the QUERIES dealt to the ranks balanced by
+    fragment count, the index replicated, and ONE RCCL all-gather of the hit table per step."""
+    args, rank, world, share_gpu, torch, dist = (ctx[k] for k in ("args", "rank", "world", "share_gpu", "torch", "dist"))
+    from pyfastani_amd import workloads, sharding
+    from pyfastani_amd._batch import ROW_DTYPE
+    t0 = time.time()
+    genomes, fam = workloads.config3(args.families, args.members, args.length)
+    t_gen = time.time() - t0
+    n = len(genomes)
+    mapper, index_mode, t_pack, t_index = build_mapper(ctx, list(range(n)), genomes)
+    frag = mapper.fragment_length
+    weights = [sum(len(c) // frag for c in contigs) for contigs in genomes]
+    owned = sharding.shard_by_fragments(weights, world)[rank]
+    batch = mapper.upload_genomes([genomes[i] for i in owned])
+    max_rows = max(len(o) for o in sharding.shard_by_fragments(weights, world)) * n
+    dev = "cpu" if share_gpu else "cuda"
+    chunk = 24
+
+    def step():
+        parts = [batch.query_rows(first, min(chunk, len(owned) - first)) for first in range(0, len(owned), chunk)]
+        rows = np.concatenate(parts) if parts else np.zeros(0, ROW_DTYPE)
+        rows = sharding.remap_query_ids(rows, owned)
+        if world == 1:
+            return rows
+        return sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows, dev), max_rows=max_rows))
+
+    for _ in range(max(args.warmup, 1)):
+        rows = step()
+    fence(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rows = step()
+    fence(ctx)
+    elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
+    if rank != 0:
+        return None
+    self_rows = rows[rows["query_id"] == rows["ref_genome_id"]]
+    return {
+        "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)", "value": n * n * args.steps / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": f"{n} x {n} all-vs-all ({args.families} families x {args.members}), {args.length / 1e6:g} Mb genomes, k=16 frag=3000 w={mapper.window_size}",
+                   "pairs_per_step": n * n, "rows_per_step": int(len(rows)), "parallelism": f"queries sharded by fragment count x{world}, index replicated",
+                   "fragments_per_rank": [int(sum(weights[i] for i in o)) for o in sharding.shard_by_fragments(weights, world)],
+                   "index_minimizers": len(mapper.minimizers), "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack,
+                   "generate_s": t_gen, "self_rows_exact": bool(len(self_rows) == n and np.all(self_rows["identity"] == 100.0)), "head": git_head()},
     }
 
 

@@ -99,6 +99,10 @@ void fa_sketch_free(fa_sketch *s);
 int fa_sketch_add_contig(fa_sketch *s, const void *data, int64_t length, int char_width, int *added);
 /* tail of Sketch._add_draft, _fastani.pyx:686-690: closes the genome, records its fragment-rounded length */
 int fa_sketch_end_genome(fa_sketch *s);
+/* the exception path of Sketch._add_draft: the reference sums the genome length in a local (`total`, _fastani.pyx:618,680)
+ * that is lost when a contig raises half-way, while the contigs already added stay in the sketch; call this from the
+ * binding's exception handler so that the abandoned genome's length is not carried into the next one. */
+int fa_sketch_abort_genome(fa_sketch *s);
 /* Sketch.clear, _fastani.pyx:746-767 */
 int fa_sketch_clear(fa_sketch *s);
 /* len(Sketch.minimizers) / Minimizers.__getitem__, _fastani.pyx:1222-1235 (device -> host read-back) */
@@ -200,7 +204,9 @@ int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t 
 /* last-call statistics: [0] sketch ms (K1 + fragment sort/unique), [1] lookup + L1 ms, [2] L2 ms, [3] CGI ms,
  * [4] total ms -- measured with HIP events on the library's stream -- then counters of the call:
  * [5] reference records inside L2 locus ranges, [6] L2 loci, [7] L2 slide events, [8] loci redone with the wide
- * L2 state.  n <= 16. */
+ * L2 state, [9] passes repeated because a speculated buffer size was too small; after fa_mapper_query also the
+ * host-side wall-clock split of that call: [10] packing ms, [11] fragment / tile tables ms, [12] uploads ms,
+ * [13] device pass + row download ms.  n <= 16. */
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n);
 /* the HIP stream the library launches on (so callers can bracket it with their own events) */
 int fa_mapper_stream(fa_mapper *m, void **stream);

@@ -352,6 +352,45 @@ struct Sketch {
     sequencesByFileInfo.push_back((seqno_t)counter);
   }
 
+  // Test-speed helper (no reference analogue): the contigs of several genomes sketched by `threads` host threads, then
+  // appended in order with exactly the bookkeeping of add_contig / end_genome.  Equivalent to the sequential calls
+  // because add_minimizers only ever compares against out.back(), which at the start of a contig is either absent or
+  // a record of another seqId (S2.6) -- tests/test_oracle_golden.py checks the two paths against each other.
+  struct ContigRef { const void *data; int width; int64_t len; };
+  void add_genomes_parallel(const std::vector<std::vector<ContigRef>> &genomes, int threads) {
+    struct Job { const ContigRef *c; seqno_t seq; std::vector<MinimizerInfo> out; };
+    std::vector<Job> jobs;
+    size_t ctr = counter;
+    for (const auto &g : genomes)
+      for (const auto &c : g) {
+        if (c.len >= param.windowSize && c.len >= param.kmerSize) jobs.push_back(Job{&c, (seqno_t)ctr, {}});
+        ctr++;
+      }
+    std::atomic<size_t> next(0);
+    auto worker = [&]() {
+      for (size_t i; (i = next.fetch_add(1)) < jobs.size();)
+        add_minimizers(jobs[i].out, jobs[i].c->data, jobs[i].c->width, jobs[i].c->len, param.kmerSize, param.windowSize,
+                       jobs[i].seq, param.alphabetSize != 4);
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < std::max(1, threads); t++) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    size_t j = 0;
+    for (const auto &g : genomes) {
+      for (const auto &c : g) {
+        if (j < jobs.size() && jobs[j].c == &c) {
+          minimizerIndex.insert(minimizerIndex.end(), jobs[j].out.begin(), jobs[j].out.end());
+          std::vector<MinimizerInfo>().swap(jobs[j].out);
+          j++;
+        }
+        cur_total += (size_t)(c.len / param.minReadLength) * param.minReadLength;
+        counter += 1;
+      }
+      end_genome();
+    }
+  }
+
   // S5  [UPSTREAM] Sketch::index(): hash -> positions, in insertion order
   void index() {
     minimizerPosLookupIndex.clear();

@@ -59,6 +59,8 @@ def lib():
         L.fo_add_contig.restype = i32
         L.fo_add_contig.argtypes = [vp, vp, i64, i32]
         L.fo_end_genome.argtypes = [vp]
+        L.fo_add_genomes.restype = None
+        L.fo_add_genomes.argtypes = [vp, P(vp), P(i64), vp, i64, i32, i32, i32]
         L.fo_num_minimizers.restype = i64
         L.fo_num_minimizers.argtypes = [vp]
         L.fo_get_minimizers.argtypes = [vp, vp, vp, vp]
@@ -140,6 +142,23 @@ class OracleSketch:
 
     def add_genome(self, name, seq):
         return self.add_draft(name, [seq])
+
+    def add_drafts(self, names, genomes, threads=0):
+        """Several draft genomes at once, sketched by `threads` host threads (0 = all cores); the records are those
+        of one `add_draft` call per genome (checked in tests/test_oracle_golden.py)."""
+        threads = threads or (os.cpu_count() or 1)
+        bufs, cg = [], []
+        for gi, contigs in enumerate(genomes):
+            for c in contigs:
+                bufs.append(_as_bytes(c))
+                cg.append(gi)
+        n = len(bufs)
+        keep = [np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(1, np.uint8) for b in bufs]
+        arr = (C.c_void_p * max(n, 1))(*[k.ctypes.data for k in keep])
+        lens = (C.c_int64 * max(n, 1))(*[len(b) for b in bufs])
+        cga = np.asarray(cg, dtype=np.int32)
+        lib().fo_add_genomes(self._h, arr, lens, cga.ctypes.data if n else None, n, len(genomes), 1, threads)
+        self.names.extend(names)
 
     def minimizers(self):
         n = lib().fo_num_minimizers(self._h)

@@ -51,6 +51,13 @@ int fo_add_contig(void *hh, const void *data, int64_t len, int width) {
   return ((OracleHandle *)hh)->sk.add_contig(data, width, len);
 }
 void fo_end_genome(void *hh) { ((OracleHandle *)hh)->sk.end_genome(); }
+// several genomes at once, sketched by `threads` host threads (test-speed helper: same records as the calls above)
+void fo_add_genomes(void *hh, const void **contigs, const int64_t *lens, const int32_t *contig_genome, int64_t n_contigs,
+                    int32_t n_genomes, int width, int threads) {
+  std::vector<std::vector<Sketch::ContigRef>> genomes((size_t)n_genomes);
+  for (int64_t i = 0; i < n_contigs; i++) genomes[(size_t)contig_genome[i]].push_back(Sketch::ContigRef{contigs[i], width, lens[i]});
+  ((OracleHandle *)hh)->sk.add_genomes_parallel(genomes, threads);
+}
 int64_t fo_num_minimizers(void *hh) { return (int64_t)((OracleHandle *)hh)->sk.minimizerIndex.size(); }
 void fo_get_minimizers(void *hh, uint32_t *hash, int32_t *seq, int32_t *wpos) {
   const auto &v = ((OracleHandle *)hh)->sk.minimizerIndex;

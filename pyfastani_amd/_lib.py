@@ -1,7 +1,9 @@
 """ctypes binding of ``libfastani_hip.so`` (the C ABI declared in ``include/fastani_hip.h``).
 
-The library is the only compute backend: if it is missing, importing this module raises
-``ImportError`` with build instructions -- there is no CPU fallback.
+The product binding is the Cython module ``pyfastani_amd._fastani``; this table of every exported symbol serves the
+tests (symbol / layout checks), the debug and timing entry points used by ``bench.py`` and ``scripts/``, and as the
+ctypes stub shown in INTEGRATION.md.  The library is the only compute backend: if it is missing, importing this module
+raises ``ImportError`` with build instructions -- there is no CPU fallback.
 """
 import ctypes as C
 import os
@@ -64,6 +66,7 @@ SIGNATURES = {
     "fa_sketch_free": (None, [_vp]),
     "fa_sketch_add_contig": (_i32, [_vp, _vp, _i64, _i32, _P(_i32)]),
     "fa_sketch_end_genome": (_i32, [_vp]),
+    "fa_sketch_abort_genome": (_i32, [_vp]),
     "fa_sketch_clear": (_i32, [_vp]),
     "fa_sketch_num_minimizers": (_i32, [_vp, _P(_i64)]),
     "fa_sketch_get_minimizers": (_i32, [_vp, _vp, _vp, _vp]),
@@ -112,26 +115,10 @@ if not os.path.exists(LIB_PATH):
 
 
 
-def _share_hip_runtime_with_torch():
-    """PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64, and two HIP runtimes in one process cannot
-    both drive the GPU (whichever initialises second sees no device).  The multi-GPU layer hands torch tensors to this
-    library, so both must sit on ONE runtime: torch is imported first -- its copies are then the ones the DT_NEEDED
-    entries of libfastani_hip.so resolve to by SONAME.  Importing torch only AFTER this library has initialised HIP
-    also works but is pathologically slow (torch then registers its thousands of kernels with a live runtime: 10 s to
-    minutes, measured), hence the eager import.  ``FA_SYSTEM_HIP=1`` skips it and keeps the system runtime (no torch
-    interoperability in that process)."""
-    # concurrent query calls each use their own stream; the runtime's default of 4 hardware queues would put several of
-    # them on one queue (measured: two part streams serialised), so ask for more before HIP starts
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    if os.environ.get("FA_SYSTEM_HIP"):
-        return
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
-
-
-_share_hip_runtime_with_torch()
+# Concurrent query calls each use their own stream; the runtime's default of 4 hardware queues would put several of them
+# on one queue (measured: two part streams serialised), so ask for more before HIP starts.  Nothing else is touched at
+# import: in particular PyTorch is NOT imported here (a process that uses both imports torch first, see sharding.py).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 lib = C.CDLL(LIB_PATH)
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here means the library and the header disagree

@@ -317,6 +317,8 @@ struct fa_mapper {
   DevBuf<uint32_t> rec_geo;       // packed window geometry + flags for k_l2_events (empty when cmw >= 8191)
   DevBuf<uint16_t> rec_prev16;
   DevBuf<int2> rec_sw;            // (rec_seq, rec_wpos) interleaved for k_l1
+  DevBuf<uint32_t> ev_bits;       // merged admit / drop order of the slide (k_event_bits), 2 bits per record
+  DevBuf<uint2> rec_hf;           // hash + flags + distance to the previous record of the hash (k_pack_hf), for k_l2_fused
   bool packed_geo = false;
   int64_t N = 0, U = 0;
   int32_t C = 0, G = 0, table_bits = 4, freq_threshold = INT_MAX, total_bins = 0;
@@ -352,6 +354,7 @@ struct fa_mapper {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
     v.rec_geo = packed_geo ? rec_geo.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_sw = rec_sw.p;
+    v.ev_bits = ev_bits.p; v.rec_hf = rec_hf.p;
     v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.table = table.p;
     v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
     v.N = N; v.U = U; v.C = C; v.G = G; v.table_bits = table_bits; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
@@ -482,6 +485,14 @@ static void build_index(fa_mapper &m) {
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
     m.rec_sw.ensure((size_t)N + 4);
     hipLaunchKernelGGL(k_interleave_seq_wpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, N, m.rec_sw.p);
+    {
+      const size_t words = ((size_t)2 * (size_t)N + 31) / 32 + 4;
+      m.ev_bits.ensure(words);
+      FA_HIP(hipMemsetAsync(m.ev_bits.p, 0, words * sizeof(uint32_t), st));
+      hipLaunchKernelGGL(k_event_bits, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_bwd.p, m.contig_rec.p, N, m.ev_bits.p);
+      m.rec_hf.ensure((size_t)N + 4);
+      hipLaunchKernelGGL(k_pack_hf, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_hash.p, m.rec_flags.p, m.rec_prev.p, N, m.rec_hf.p);
+    }
     m.packed_geo = m.cmw + 1 < (1 << GEO_BITS);
     if (m.packed_geo) {
       m.rec_geo.ensure((size_t)N + 4); m.rec_prev16.ensure((size_t)N + 4);
@@ -808,8 +819,24 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
           hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
         }
       };
+      // fused form (events generated into an LDS ring and consumed in place: no event arena in HBM) whenever 64 loci
+      // per workgroup fit; FA_L2_FUSED=0 keeps the two-kernel form (k_l2_events + k_l2_scan) for comparison
+      static const bool fused_on = !(getenv("FA_L2_FUSED") && atoi(getenv("FA_L2_FUSED")) == 0);
+      const size_t fl8 = fused_lds_bytes<uint8_t>(a.cnt_slots, wide ? 4 : 2), fl16 = fused_lds_bytes<uint16_t>(a.cnt_slots, wide ? 4 : 2);
+      const bool fused = fused_on && fl16 <= 150 * 1024 && m.cmw < 65535;   // rec_hf keeps same-hash distances in 16 bits
+      auto launch_fused = [&](auto k8, auto k16) {
+        if (fl8 > 60 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl8));
+        const unsigned grid = (unsigned)(((F + 7) / 8) * 8);                // blockIdx -> (XCD, fragment of that XCD)
+        hipLaunchKernelGGL(k8, dim3(grid), dim3(FU_THREADS), fl8, st, a, F);
+        if (!sp.redo) return;
+        if (fl16 > 60 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl16));
+        hipLaunchKernelGGL(k16, dim3(grid), dim3(FU_THREADS), fl16, st, a, F);
+      };
       const bool pk = m.packed_geo && !getenv("FA_NO_PACKED_GEO");
-      if (wide) {
+      if (fused) {
+        if (wide) launch_fused(k_l2_fused<uint32_t, uint8_t, false>, k_l2_fused<uint32_t, uint16_t, true>);
+        else launch_fused(k_l2_fused<uint16_t, uint8_t, false>, k_l2_fused<uint16_t, uint16_t, true>);
+      } else if (wide) {
         if (pk) launch(k_l2_events<uint32_t, true>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
         else launch(k_l2_events<uint32_t, false>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
       } else {
@@ -965,8 +992,15 @@ struct WorkspaceLease {
 
 // pack + cut into fragments + tiles + upload
 static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
-                                                  const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width) {
+                                                  const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width,
+                                                  float *host_ms = nullptr) {
   require_device();
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto lap = [&, last = t_begin](int slot) mutable {
+    const auto now = std::chrono::steady_clock::now();
+    if (host_ms) host_ms[slot] = std::chrono::duration<float, std::milli>(now - last).count();
+    last = now;
+  };
   FA_REQUIRE(width == 1 || width == 2 || width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
   std::unique_ptr<fa_genomes> g(new fa_genomes());
   g->P = P;
@@ -992,6 +1026,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   StageTrace tr("upload_genomes");
   hs.append_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width);
   tr.mark("pack", st);
+  lap(0);
   // pass 2: fragments, tiles and per-genome bookkeeping, in contig order
   int32_t cur = 0;
   size_t used = 0;
@@ -1020,6 +1055,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   g->frag_tile_lo.push_back((int32_t)tiles.size());
   g->ntiles = (int64_t)tiles.size();
   tr.mark("fragments_tiles", st);
+  lap(1);
   g->store.upload(hs, st);
   g->tiles.upload(tiles, st);
   g->d_frag_tile_lo.upload(g->frag_tile_lo, st);
@@ -1032,6 +1068,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   g->d_total_frag.upload(tf, st);
   FA_HIP(hipStreamSynchronize(st));
   tr.mark("uploads", st);
+  lap(2);
   return g;
 }
 
@@ -1178,6 +1215,9 @@ int fa_sketch_end_genome(fa_sketch *s) {
     s->cur_total = 0;
     s->seqs_by_file.push_back((int32_t)s->counter);      // :690
   });
+}
+int fa_sketch_abort_genome(fa_sketch *s) {
+  return guarded([&] { std::lock_guard<std::mutex> lock(s->mtx); s->cur_total = 0; });
 }
 int fa_sketch_clear(fa_sketch *s) {
   return guarded([&] { std::lock_guard<std::mutex> lock(s->mtx); s->reset_data(); });
@@ -1448,11 +1488,16 @@ int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *len
   return guarded([&] {
     WorkspaceLease lease(*m);
     std::vector<int32_t> cg((size_t)std::max(n_contigs, 1), 0);
-    auto g = upload_genomes(m->P, lease.w->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width);
+    float host_ms[3] = {0, 0, 0};
+    auto g = upload_genomes(m->P, lease.w->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width, host_ms);
     if (n_short) *n_short = g->n_short[0];
     if (total_fragments) *total_fragments = g->total_fragments[0];
     if (total_length) *total_length = g->total_length[0];
+    const auto t0 = std::chrono::steady_clock::now();
     *n_rows = run_query(*m, *lease.w, *g, 0, 1, rows, cap, false);
+    // host-side split of the boundary call (wall clock): packing, fragment/tile tables, H2D, pass + rows D2H
+    for (int i = 0; i < 3; i++) lease.w->last_ms[10 + i] = host_ms[i];
+    lease.w->last_ms[13] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     lease.w->last_genomes = nullptr;
   });
 }

@@ -304,6 +304,23 @@ __global__ void k_pack_geometry(const int32_t *rec_prev, const int32_t *rec_fwd,
   rec_prev16[i] = (uint16_t)(pv < 0 ? 65535 : min((int32_t)i - pv, 65535));
 }
 
+// The time order of the slide's events is a property of the contig, not of the query: record i is admitted at window
+// position wpos[i] - cmw + 1 and dropped at wpos[i+1]; at one position the drop comes first.  Numbering the events of a
+// contig in that order, the admit of record i is event  i + rec_bwd[i]  (i admits and rec_bwd[i] drops precede it, in
+// absolute record numbers) and the drop of record j is event  j + rec_fwd[j+1] - same_step(j).  ev_bits holds bit 1 at
+// the admit positions: a slide that is at event E with A admits behind it finds, in the next 64 bits, which of its
+// next events are admits (of records A, A+1, ...) and which are drops (of records E-A, E-A+1, ...) -- by popcount, without
+// a search, and any stretch of the stream can be generated on its own.  Records of the first super-window of a contig
+// are never admitted by a slide (they are its initial content), so their bits stay clear.
+__global__ void k_event_bits(const int32_t *rec_seq, const int32_t *rec_bwd, const int32_t *contig_rec, int64_t N, uint32_t *ev_bits) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int32_t b = rec_bwd[i];
+  if (b < contig_rec[rec_seq[i]]) return;
+  const uint64_t pos = (uint64_t)i + (uint64_t)b;
+  atomicOr(&ev_bits[pos >> 5], 1u << (pos & 31));
+}
+
 // ----------------------------------------------------------------------------------------------------------
 // resident index view passed to the mapping kernels
 // ----------------------------------------------------------------------------------------------------------
@@ -317,6 +334,8 @@ struct IndexView {
   const uint32_t *rec_geo;      // packed geometry (k_pack_geometry), null when cmw is too large for it
   const uint16_t *rec_prev16;
   const int2 *rec_sw;           // (rec_seq, rec_wpos) interleaved: one 8-byte gather per seed hit in k_l1
+  const uint32_t *ev_bits;      // merged admit / drop order of the L2 slide, one bit per event (k_event_bits)
+  const uint2 *rec_hf;          // (hash, flags | distance to the previous record of the hash << 8) for k_l2_fused
   const uint32_t *uniq_hash;
   const uint32_t *uniq_off;
   const uint32_t *pos_ridx;
@@ -1402,6 +1421,336 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   if (best >= a.pass_lut[s]) {
     unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)(0xFFFFFFFFu - l);
     atomicMax(&a.group_best[a.l_group[l]], key);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------------
+// L2, fused: the event stream of a locus never leaves the compute unit (k_l2_events + k_l2_scan in one launch, no
+// round trip of the events through HBM).
+//
+// One workgroup per query fragment, two waves.  Wave 0 is the *slider*: one lane per candidate locus of the fragment
+// (64 at a time), the same branch-free sequential slide as k_l2_scan, reading its events from a ring in LDS.  Wave 1
+// is the *producer*: for every locus it generates the next FU_C events of its time-ordered stream straight into the
+// ring, one lane per EVENT -- which record an event belongs to comes from the merged admit/drop order kept as one bit
+// per event in the index (k_event_bits): with A admits behind a stream that stands at event E, the set bits of the
+// next FU_C positions are the admits of records A, A+1, ... and the clear bits the drops of records E-A, E-A+1, ...
+// So the reads of the records (rec_hf: hash + flags + distance to the previous record of the same hash, 8 bytes) are two
+// short coalesced runs per locus, the rank of the hash in the query sketch is one bucket probe + a short search in LDS
+// (done once for the admit and once for the drop of a record: cheaper than carrying 240 ranks per locus in LDS), and
+// the event lands at a fixed ring slot -- no scatter, no event arena.  The ring is double buffered by row (FU_C events
+// per locus): the producer fills row r+1 while the slider consumes row r, one workgroup barrier per row, and the
+// producer's loads run one (records) and two (order bits) rows ahead of the row it composes.  The first rows carry the
+// initial super-window (admits in record order, applied without the pivot logic), padded so that every lane reads the
+// pivot off its state at the same row.
+//
+// LDS per workgroup at sketches <= 256: 16.1 KB of slide state + 1 KB sketch + 4 KB ring + 1.3 KB tables = 22.4 KB, i.e.
+// seven workgroups per CU -- the 1666 fragments of a 5 Mb query are resident at once (the slide is a latency-bound
+// chain per locus: a second round of workgroups would double the time).  blockIdx is mapped to fragments so that
+// neighbouring fragments -- whose loci overlap on the reference -- share an XCD and its L2.
+// ----------------------------------------------------------------------------------------------------------
+constexpr int FU_THREADS = 128;
+constexpr int FU_C = 16;                    // events per locus and ring row
+constexpr int FU_UPI = 64 / FU_C;           // loci per producer iteration
+constexpr int FU_ITERS = 64 / FU_UPI;       // producer iterations per row
+constexpr int FU_QT_BITS = 8;               // bucket table resolution
+
+template <typename ST>
+__host__ __device__ inline size_t fused_lds_bytes(int cnt_slots, int ev_bytes) {
+  size_t state = ((size_t)(cnt_slots + 1) * 64 * sizeof(ST) + 15) / 16 * 16;
+  size_t q = ((size_t)cnt_slots * 4 + 15) / 16 * 16;
+  return state + q + (size_t)2 * FU_C * 64 * ev_bytes;
+}
+
+// hash, flags and the (saturated) distance to the previous record of the same hash in one 8-byte record for the fused
+// kernel: y = flags | min(i - rec_prev[i], 65535) << 8   (65535 also for "no earlier record of this hash in the contig")
+__global__ void k_pack_hf(const uint32_t *rec_hash, const uint8_t *rec_flags, const int32_t *rec_prev, int64_t N, uint2 *rec_hf) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int32_t pv = rec_prev[i];
+  const uint32_t d = pv < 0 ? 65535u : (uint32_t)min((int64_t)65535, i - (int64_t)pv);
+  rec_hf[i] = make_uint2(rec_hash[i], (uint32_t)rec_flags[i] | (d << 8));
+}
+
+template <typename T, typename ST, bool REDO>
+__global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_frag) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int RB = EvBits<T>::RANK;
+  constexpr int SBITS = 8 * (int)sizeof(ST);
+  __shared__ uint16_t QT[(1 << FU_QT_BITS) + 2];
+  __shared__ int32_t u_beg[64];                                      // first record of the locus range (-1: lane unused)
+  __shared__ uint32_t u_e0[64], u_nmain[64];                         // events behind the first super-window; events of the slide
+  __shared__ int sh_fill_rows, sh_rows;
+  // fragments of one XCD (blockIdx % 8, the dispatch order of workgroups) are consecutive
+  const int64_t per_xcd = (n_frag + 7) / 8;
+  const int64_t f64 = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((int64_t)(blockIdx.x >> 3) >= per_xcd || f64 >= n_frag) return;
+  const int f = (int)f64;
+  const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
+  if (l_n == 0) return;
+  const int s = a.q_size[f];
+  if (a.counters[2] || s > a.cnt_slots - 1) return;                  // loci overflowed / sketch larger than speculated: void pass
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  ST *st = (ST *)lds;                                                // [cnt_slots + 1][64], lane-interleaved
+  uint32_t *Q = (uint32_t *)(lds + ((size_t)(a.cnt_slots + 1) * 64 * sizeof(ST) + 15) / 16 * 16);
+  T *ring = (T *)((unsigned char *)Q + ((size_t)a.cnt_slots * 4 + 15) / 16 * 16);   // [2][FU_C][64]
+  for (int i = tid; i < s; i += FU_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  __syncthreads();
+  // bucket table over the hash range the sketch spans (see k_l2_events)
+  const uint32_t hmax = s > 0 ? Q[s - 1] : 0u;
+  const int qshift = max(0, (32 - __clz((int)(hmax | 1u))) - FU_QT_BITS);
+  for (int b = tid; b <= (1 << FU_QT_BITS); b += FU_THREADS) {
+    int x = 0, y = s;
+    const uint64_t key = (uint64_t)b << qshift;
+    while (x < y) { int mid = (x + y) >> 1; if ((uint64_t)Q[mid] < key) x = mid + 1; else y = mid; }
+    QT[b] = (uint16_t)x;
+  }
+  if (tid == 0) QT[(1 << FU_QT_BITS) + 1] = (uint16_t)s;
+  // rank of a reference hash in the query sketch: slot = rank + 1, found = the hash is in the sketch
+  auto rank_of = [&](uint32_t h, bool &found) __attribute__((always_inline)) {
+    const uint32_t qb = min(h >> qshift, (uint32_t)(1 << FU_QT_BITS));
+    int x = QT[qb], y = QT[qb + 1];
+    while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
+    found = x < s && Q[x] == h;
+    return (uint32_t)(x + 1);
+  };
+  typedef __attribute__((address_space(3))) ST *lds_ptr;
+  constexpr int STB = (int)sizeof(ST);
+  constexpr int LNB = 64 * STB;                                      // bytes between consecutive slots of one lane
+  const int lbase = (int)(uint32_t)(uintptr_t)(lds_ptr)st + lane * STB;
+  const int32_t *wpos = a.ix.rec_wpos;
+
+  for (uint32_t g0 = 0; g0 < l_n; g0 += 64) {
+    // ---- the loci of this group: record ranges (the three searchIndex calls of computeL2MappedRegions) ----
+    __syncthreads();
+    int32_t my_locus = -1;                                             // slider lanes: the locus of this lane
+    if (wv == 0) {
+      const uint32_t l = l_lo + g0 + lane;
+      bool active = g0 + lane < l_n;
+      if (active) { if (REDO) active = a.l_redo[l] != 0; else a.l_redo[l] = 0; }
+      int beg = -1, fill_rows = 0, main_rows = 0;
+      uint32_t e0 = 0, nmain = 0, records = 0, nev = 0;
+      if (active) {
+        const int lo = a.ix.contig_rec[a.l_seq[l]];
+        const int rfirst = a.l_rfirst[l], target = a.l_start[l];
+        int x = max(lo, rfirst - a.frag_len), y = rfirst;
+        while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+        beg = x;
+        const int end0 = a.ix.rec_fwd[beg];
+        const int last = a.ix.rec_fwd[a.l_rlast[l]];
+        const int ndrop = last > end0 ? a.ix.rec_bwd[last - 1] - beg : 0;
+        e0 = (uint32_t)beg + (uint32_t)end0;                           // events behind the first super-window
+        nmain = last > end0 ? (uint32_t)(last - end0) + (uint32_t)ndrop : 0u;
+        fill_rows = (end0 - beg + FU_C - 1) / FU_C;
+        main_rows = (int)((nmain + FU_C - 1) / FU_C);
+        records = (uint32_t)(last - beg);
+        nev = (uint32_t)(end0 - beg) + nmain;
+        my_locus = (int32_t)l;
+      }
+      u_beg[lane] = beg; u_e0[lane] = e0; u_nmain[lane] = nmain;
+      int fr = fill_rows, mr = main_rows;
+      uint32_t rsum = records, esum = nev;
+      for (int d = 32; d > 0; d >>= 1) {
+        fr = max(fr, __shfl_xor(fr, d)); mr = max(mr, __shfl_xor(mr, d));
+        rsum += __shfl_xor(rsum, d); esum += __shfl_xor(esum, d);
+      }
+      if (lane == 0) {
+        sh_fill_rows = fr; sh_rows = fr ? fr + mr : 0;
+        if (!REDO && rsum) { atomicAdd(a.rec_total, (unsigned long long)rsum); atomicAdd(&a.pinfo[0], (unsigned long long)esum); }
+      }
+    }
+    for (int i = tid; i < (s + 2) * 64; i += FU_THREADS) st[i] = (ST)0;
+    __syncthreads();
+    const int R_fill = sh_fill_rows, R_all = sh_rows;
+    if (R_all == 0) continue;
+
+    // ---- producer: a three-stage pipeline over the rows, so that no stage waits for the loads it issued itself ----
+    //   A(row)  main rows: load the merged-order bits of the row                         (global, one row-time ahead of B)
+    //   B(row)  which record every event of the row belongs to; load that record (rec_hf) (global, one row-time ahead of C)
+    //   C(row)  rank of the hash in the query sketch, compose the event, store it in ring buffer row & 1    (LDS only)
+    // One producer step runs C(t), B(t+1), A(t+2); the slider consumes row t-1 meanwhile.
+    const int pe = lane & (FU_C - 1);                                  // event of the row this producer lane composes
+    const int pu = lane / FU_C;                                        // its locus inside an iteration
+    // per-locus cursors live in ONE lane each (lane (pu, pe) owns locus pe * FU_UPI + pu) and are fetched by the 16 lanes
+    // that compose the locus's events with a cross-lane read: 16 registers less than a copy per iteration
+    const int own = pe * FU_UPI + pu;
+    uint32_t own_bits = 0u;                                            // A -> B: the order bits of the owned locus's row
+    uint32_t own_ia = 0u;                                              // admits behind the stream of the owned locus
+    uint2 phf[FU_ITERS];                                               // B -> C: the record; y bit 31 = admit, bit 30 = valid
+    auto stage_a = [&](int row) __attribute__((always_inline)) {
+      if (row < R_fill || row >= R_all) return;
+      const uint32_t off = (uint32_t)(row - R_fill) * FU_C;
+      const bool ok = u_beg[own] >= 0 && off < u_nmain[own];
+      const uint32_t p0 = u_e0[own] + off;
+      const uint32_t w0 = ok ? a.ix.ev_bits[p0 >> 5] : 0u;
+      const uint32_t w1 = ok ? a.ix.ev_bits[(p0 >> 5) + 1] : 0u;
+      own_bits = __funnelshift_r(w0, w1, p0 & 31u) & ((1u << FU_C) - 1u);
+    };
+    auto stage_b = [&](int row) __attribute__((always_inline)) {
+      if (row >= R_all) return;
+      if (row < R_fill) {
+#pragma unroll
+        for (int it = 0; it < FU_ITERS; it++) {
+          const int u = it * FU_UPI + pu;
+          const int beg = u_beg[u];
+          const int k = row * FU_C + pe;                               // k-th record of the first super-window
+          const bool ok = beg >= 0 && (uint32_t)k < u_e0[u] - 2u * (uint32_t)beg;   // e0 = beg + end0
+          phf[it] = ok ? a.ix.rec_hf[beg + k] : make_uint2(0u, 0u);
+          // the hash is already in the window when its previous occurrence lies at or after `beg`: a no-op admit (bit 29)
+          const uint32_t dist = (phf[it].y >> 8) & 0xFFFFu;
+          phf[it].y = (phf[it].y & 0xFFu) | (ok ? 0x40000000u : 0u) | ((ok && dist <= (uint32_t)k) ? 0x20000000u : 0u);
+        }
+      } else {
+        const uint32_t off = (uint32_t)(row - R_fill) * FU_C;
+        const uint32_t my_bits = own_bits, my_ia = own_ia;
+        own_ia = my_ia + (uint32_t)__popc(my_bits);
+#pragma unroll
+        for (int it = 0; it < FU_ITERS; it++) {
+          const int u = it * FU_UPI + pu;
+          const int src = pu * FU_C + it;                              // the lane that owns locus u
+          const uint32_t bits = (uint32_t)__shfl((int)my_bits, src), ia = (uint32_t)__shfl((int)my_ia, src);
+          const bool ok = u_beg[u] >= 0 && off + (uint32_t)pe < u_nmain[u];
+          const uint32_t p0 = u_e0[u] + off;
+          const uint32_t before = (uint32_t)__popc(bits & ((1u << pe) - 1u));
+          const uint32_t admit = (bits >> pe) & 1u;
+          const uint32_t rec = admit ? ia + before : (p0 - ia) + ((uint32_t)pe - before);
+          phf[it] = ok ? a.ix.rec_hf[rec] : make_uint2(0u, 0u);
+          phf[it].y = (phf[it].y & 0xFFu) | (admit << 31) | (ok ? 0x40000000u : 0u);
+        }
+      }
+    };
+    auto stage_c = [&](int row) __attribute__((always_inline)) {
+      if (row >= R_all) return;
+      T *out = ring + (size_t)(row & 1) * FU_C * 64 + (size_t)pe * 64 + pu;
+      const bool fill = row < R_fill;
+#pragma unroll
+      for (int it = 0; it < FU_ITERS; it++) {
+        uint32_t ev = 0;
+        const uint32_t y = phf[it].y;
+        if (y & 0x40000000u) {
+          bool found;
+          const uint32_t base = rank_of(phf[it].x, found);
+          const int dsh = found ? RB : RB + 2;
+          if (fill) {
+            ev = base | (((y & 0x20000000u) ? 0u : 1u) << dsh);
+          } else if (y >> 31) {
+            // admit: after the drops of all records before the one active at its window position; carries the
+            // comparison; a no-op when linked to the previous record of the same hash
+            ev = base | (((y & FLAG_INS_LINKED) ? 0u : 1u) << dsh) | (1u << (RB + 5));
+          } else {
+            // drop at window position wpos[i+1], before the admit of that same position (FLAG_SAME_STEP), which then
+            // carries the comparison
+            const uint32_t same = (y & FLAG_SAME_STEP) ? 1u : 0u;
+            ev = base | (((y & FLAG_DEL_LINKED) ? 0u : 3u) << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5));
+          }
+        }
+        out[it * FU_UPI] = (T)ev;
+      }
+    };
+
+    // slider state (wave 0 only)
+    uint32_t overflow = 0;
+    int rl = 0, F = 0, shared = 0, best = -1, beg = 0, opt_s = 0, opt_e = 0;
+    if (wv == 0) {
+      beg = max(u_beg[lane], 0); opt_s = beg; opt_e = beg;
+      __builtin_amdgcn_s_setprio(2);
+    } else {
+      own_ia = u_e0[own] - (uint32_t)max(u_beg[own], 0);               // = end0: the records of the first window count as admitted
+      stage_a(0); stage_b(0); stage_a(1); stage_c(0); stage_b(1); stage_a(2);
+    }
+    __syncthreads();
+    for (int row = 0; row < R_all; row++) {
+      if (wv != 0) {
+        stage_c(row + 1); stage_b(row + 2); stage_a(row + 3);
+      } else {
+        const T *in = ring + (size_t)(row & 1) * FU_C * 64 + lane;
+        uint32_t word[FU_C];
+#pragma unroll
+        for (int q = 0; q < FU_C; q++) word[q] = (uint32_t)in[q * 64];
+        if (row < R_fill) {
+          // the first super-window: its admits only change the per-rank state
+#pragma unroll
+          for (int q = 0; q < FU_C; q++) {
+            const int slot = (int)__builtin_amdgcn_ubfe(word[q], 0, RB);
+            const int dM = __builtin_amdgcn_sbfe(word[q], RB, 2), dW = __builtin_amdgcn_sbfe(word[q], RB + 2, 2);
+            const int addr = slot * LNB + lbase;
+            const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
+            const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+            overflow |= nv;
+            *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
+          }
+          if (row == R_fill - 1) {
+            // pivot of the filled window: r* = min{r : r + sum_{c <= r} cnt[c] >= s} (s if there is none)
+            int rstar = s, acc = 0, m_acc = 0;
+            F = s;
+            bool hit = false;
+            for (int r = 0; r < s; r++) {
+              const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)((r + 1) * LNB + lbase);
+              const int c = (int)(v >> 1), mt = (int)(v & 1u);
+              const bool now = !hit && r + acc + c >= s;
+              rstar = now ? r : rstar;
+              F = now ? r + acc : F;
+              shared = now ? m_acc : shared;
+              hit = hit || now;
+              acc += c; m_acc += mt;
+            }
+            F = hit ? F : s + acc;
+            shared = hit ? shared : m_acc;
+            rl = rstar * LNB + lbase;
+            best = shared;                                             // the comparison after the last admit of the first window
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < FU_C; q++) {
+            // straight-line selects only: the 64 lanes follow 64 different loci (see k_l2_scan)
+            const uint32_t wd = word[q];
+            const int slot = (int)__builtin_amdgcn_ubfe(wd, 0, RB);
+            const int dM = __builtin_amdgcn_sbfe(wd, RB, 2), dW = __builtin_amdgcn_sbfe(wd, RB + 2, 2);
+            const int drp = (int)__builtin_amdgcn_ubfe(wd, RB + 4, 1);
+            const bool evl = ((wd >> (RB + 5)) & 1u) != 0;
+            const int addr = slot * LNB + lbase;
+            const int addrb = rl + drp * LNB;                          // slot of rank r* (drop) or r*-1 (admit)
+            const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
+            const uint32_t vb0 = *(lds_ptr)(uintptr_t)(uint32_t)addrb;
+            const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+            overflow |= nv;
+            *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
+            const bool below = addr <= rl;                             // rank < r*
+            shared += below ? dM : 0;
+            F += below ? dW : 0;
+            const uint32_t vb = (addrb == addr) ? nv : vb0;
+            const int cb = (int)(vb >> 1), mb = (int)(vb & 1u);
+            const bool up = ((dW & (F + cb - s)) < 0);
+            const bool down = dW > 0 && below && F > s;
+            const int delta = up ? 1 : (down ? -1 : 0);
+            F += __mul24(delta, cb + 1);
+            shared += __mul24(delta, mb);
+            rl += __mul24(delta, LNB);
+            beg += drp;
+            const bool gt = evl && shared > best, ge = evl && shared >= best;
+            best = gt ? shared : best;
+            opt_s = gt ? beg : opt_s;
+            opt_e = ge ? beg : opt_e;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (wv == 0) {
+      __builtin_amdgcn_s_setprio(0);
+      if (my_locus >= 0) {
+        const int32_t l = my_locus;
+        if ((overflow >> SBITS) && !REDO) {
+          a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u);
+        } else {
+          a.l_shared[l] = best < 0 ? 0 : best;
+          a.l_pos[l] = (wpos[opt_s] + wpos[opt_e]) / 2;
+          if (best >= a.pass_lut[s]) {
+            unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)l);
+            atomicMax(&a.group_best[a.l_group[l]], key);
+          }
+        }
+      }
+    }
   }
 }
 

@@ -5,6 +5,11 @@ rank maps queries ``rank, rank + world, ...`` against its own resident copy of t
 collective on the data path.  The only exchange is the final all-gather of the per-pair hit table
 (``cgi::CGI_Results`` rows, 20 bytes each) over RCCL (``torch.distributed`` backend ``nccl``) or gloo on CPU.
 Rows have variable count per rank, so counts are gathered first and the payload is padded to the maximum.
+
+PyTorch is imported by the functions that need it, never at module import.  The library and torch must share ONE HIP
+runtime in a process that uses both: import torch BEFORE the first pyfastani_amd call touches the GPU (bench.py and the
+tests do) -- torch's bundled runtime is then the one ``libfastani_hip.so`` binds to, and torch does not have to register
+its kernels with a runtime that is already live (which works but takes 10 s to minutes).
 """
 import numpy as np
 
@@ -14,6 +19,25 @@ from ._batch import ROW_DTYPE
 def shard_indices(n_items, rank, world_size):
     """Query genomes owned by ``rank``: a strided partition balances families that are listed together."""
     return list(range(rank, n_items, world_size))
+
+
+def shard_by_fragments(fragment_counts, world_size):
+    """Deal query genomes to ``world_size`` ranks balanced by FRAGMENT count (a fragment is the unit of work
+    of the path, _fastani.pyx:1099-1102, and draft assemblies differ in size), not by genome count.
+
+    Longest-processing-time rule: genomes in descending fragment count (ties by index) each go to the rank with the
+    fewest fragments so far (ties to the lowest rank).  Deterministic, so every rank computes the same partition without
+    a collective; each rank's list is returned in ascending genome order.  The maximum load exceeds the mean by less
+    than one genome."""
+    import heapq
+    w = [int(x) for x in fragment_counts]
+    heap = [(0, r) for r in range(world_size)]
+    owned = [[] for _ in range(world_size)]
+    for i in sorted(range(len(w)), key=lambda i: (-w[i], i)):
+        load, r = heapq.heappop(heap)
+        owned[r].append(i)
+        heapq.heappush(heap, (load + w[i], r))
+    return [sorted(o) for o in owned]
 
 
 def rows_to_tensor(rows, device="cpu"):
@@ -76,14 +100,19 @@ def remap_query_ids(rows, owned):
     return rows
 
 
-def all_vs_all(mapper, genomes, rank, world_size, device=None, group=None, chunk=64):
+def all_vs_all(mapper, genomes, rank, world_size, device=None, group=None, chunk=64, balance="fragments"):
     """Map this rank's share of ``genomes`` against ``mapper`` and return the hit table of ALL ranks.
 
-    ``genomes`` is the full list (every rank holds the same list); only the owned ones are uploaded.
+    ``genomes`` is the full list (every rank holds the same list); only the owned ones are uploaded.  The share is
+    balanced by fragment count (`shard_by_fragments`) unless ``balance="count"`` asks for the strided deal.
     """
     import torch
 
-    owned = shard_indices(len(genomes), rank, world_size)
+    if balance == "fragments":
+        frag = mapper.fragment_length
+        owned = shard_by_fragments([sum(len(c) // frag for c in contigs) for contigs in genomes], world_size)[rank]
+    else:
+        owned = shard_indices(len(genomes), rank, world_size)
     batch = mapper.upload_genomes([genomes[i] for i in owned])
     parts = []
     for first in range(0, len(owned), chunk):
@@ -197,7 +226,7 @@ def build_index_sharded(genomes, names=None, rank=0, world_size=1, group=None, d
     ``r, r + world, ...``.  Every rank returns a `Mapper` over the complete, identical index.
     """
     import torch
-    from ._api import Sketch
+    from ._fastani import Sketch
     n = len(genomes)
     names = list(range(n)) if names is None else list(names)
     dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
@@ -310,7 +339,7 @@ def build_ref_sharded_mapper(genomes, names=None, rank=0, world_size=1, group=No
 
     Returns ``(mapper, owned)``: ``owned[i]`` is the global number of the mapper's i-th reference genome."""
     import torch
-    from ._api import Sketch
+    from ._fastani import Sketch
     n = len(genomes)
     names = list(range(n)) if names is None else list(names)
     dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))

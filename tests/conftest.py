@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# A process that uses both PyTorch (the multi-GPU tests) and libfastani_hip.so must load torch first, so that both sit on
+# the HIP runtime torch bundles (pyfastani_amd/sharding.py); the package itself never imports torch.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

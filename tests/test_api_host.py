@@ -107,4 +107,6 @@ def test_threads_argument_validation():
     # _fastani.pyx:1050; checked before any device work
     mapper = pf.Mapper.__new__(pf.Mapper)
     with pytest.raises(ValueError):
-        pf.Mapper._query_draft(mapper, [], threads=-1)
+        mapper.query_draft([], threads=-1)
+    with pytest.raises(ValueError):
+        mapper.query_genome("ACGT", threads=-2)

@@ -113,3 +113,27 @@ def test_canonical_strand():
     # same multiset of minimizer hashes up to boundary effects
     inter = len(set(hf.tolist()) & set(hr.tolist()))
     assert inter > 0.95 * len(set(hf.tolist()))
+
+
+def test_parallel_add_matches_sequential():
+    """OracleSketch.add_drafts (threaded, used by the full-size GPU tests) gives the records, counters and lengths of
+    one add_draft call per genome -- including short contigs, empty contigs and the boundary between contigs."""
+    g = syn.rng(77)
+    genomes = []
+    for i in range(5):
+        seq = syn.to_ascii(syn.random_codes(g, 60_000 + 1000 * i))
+        genomes.append(syn.split_contigs(g, seq, 4) + ([b"ACGT", b""] if i % 2 else []))
+    genomes.append([b"ACGTTGCA" * 40])                     # leading duplicate run at the start of a contig
+    names = [f"g{i}" for i in range(len(genomes))]
+    a, b = OracleSketch(), OracleSketch()
+    for n, c in zip(names, genomes):
+        a.add_draft(n, c)
+    b.add_drafts(names, genomes, threads=3)
+    for x, y in zip(a.minimizers(), b.minimizers()):
+        assert np.array_equal(x, y)
+    assert a.names == b.names
+    L = olib()
+    assert L.fo_num_genomes(a._h) == L.fo_num_genomes(b._h) == len(genomes)
+    assert [L.fo_genome_length(a._h, i) for i in range(len(genomes))] == [L.fo_genome_length(b._h, i) for i in range(len(genomes))]
+    a.index(); b.index()
+    assert a.index_size == b.index_size and a.freq_threshold == b.freq_threshold

@@ -251,3 +251,67 @@ def test_global_frequency_world2(tmp_path):
     res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert (tmp_path / "freq0.ok").read_text() == (tmp_path / "freq1.ok").read_text()
+
+
+def test_shard_by_fragments_balances_work():
+    """The fragment-balanced deal: a partition, deterministic, and within one genome of the mean load --
+    where the strided deal by genome count can be far off on draft assemblies of uneven size."""
+    rng = np.random.default_rng(5)
+    for world in (1, 2, 3, 8):
+        for weights in ([], [7], [1666] * 1000, rng.integers(1, 4000, 500).tolist(), [10_000] + [10] * 99, [0, 0, 5, 0]):
+            owned = sharding.shard_by_fragments(weights, world)
+            assert len(owned) == world and sorted(i for o in owned for i in o) == list(range(len(weights)))
+            assert all(o == sorted(o) for o in owned)
+            assert owned == sharding.shard_by_fragments(list(weights), world)
+            loads = [sum(weights[i] for i in o) for o in owned]
+            if weights:
+                assert max(loads) - min(loads) <= max(weights)
+    # uneven drafts: a few big assemblies listed first would all land on rank 0 of a strided deal
+    weights = [5000, 100, 5000, 100, 5000, 100, 5000, 100]
+    strided = [sum(weights[i] for i in sharding.shard_indices(len(weights), r, 2)) for r in range(2)]
+    balanced = [sum(weights[i] for i in o) for o in sharding.shard_by_fragments(weights, 2)]
+    assert max(strided) == 20000 and max(balanced) == 10200
+
+
+STRONG_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from pyfastani_amd import sharding
+    from pyfastani_amd._batch import ROW_DTYPE
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    # the strong-scaling step of bench.py --strong with the mapping replaced by a formula: 9 query genomes of uneven
+    # fragment counts, 4 references; query q hits reference r when (q + r) % 2 == 0
+    weights = [1666, 40, 900, 1666, 5, 300, 1200, 64, 700]
+    shards = sharding.shard_by_fragments(weights, world)
+    owned = shards[rank]
+    rows = np.array([(local, r, weights[q] // 2, weights[q], 80.0 + q + r / 8) for local, q in enumerate(owned) for r in range(4) if (q + r) % 2 == 0],
+                    dtype=ROW_DTYPE)
+    rows = sharding.remap_query_ids(rows, owned)
+    max_rows = max(len(o) for o in shards) * 4
+    out = sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows), max_rows=max_rows))   # ONE collective
+    out = out[np.lexsort((out["ref_genome_id"], out["query_id"]))]
+    want = np.array([(q, r, weights[q] // 2, weights[q], 80.0 + q + r / 8) for q in range(9) for r in range(4) if (q + r) % 2 == 0], dtype=ROW_DTYPE)
+    assert out.tobytes() == want.tobytes(), (rank, out.tolist())
+    loads = [sum(weights[i] for i in o) for o in shards]
+    assert max(loads) - min(loads) <= max(weights)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join({out!r}, f"rank{{rank}}.ok"), "w").write(str(len(out)))
+""")
+
+
+def test_strong_scaling_step_world2(tmp_path):
+    """bench.py --strong's exchange on CPU: fragment-balanced shards, one fixed-size all-gather, rows in global numbering."""
+    script = tmp_path / "worker.py"
+    script.write_text(STRONG_WORKER.format(root=ROOT, out=str(tmp_path)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "rank0.ok").read_text() == "18" and (tmp_path / "rank1.ok").read_text() == "18"
