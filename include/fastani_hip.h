@@ -201,6 +201,11 @@ int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashe
 int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t length, int char_width,
                              uint32_t *hash, int32_t *wpos, int64_t cap, int64_t *n);
 
+/* development probe: workgroups of 128 threads with `lds_bytes` of dynamic LDS the chip holds at once */
+int fa_debug_probe_occupancy(int lds_bytes, int *peak_alive);
+/* raw bytes of the last call's event arena (two-kernel L2 form: the slide events; FA_FUSED_DEBUG=8: per-workgroup time
+ * stamps of k_l2_fused) -- development aid */
+int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes);
 /* last-call statistics: [0] sketch ms (K1 + fragment sort/unique), [1] lookup + L1 ms, [2] L2 ms, [3] CGI ms,
  * [4] total ms -- measured with HIP events on the library's stream -- then counters of the call:
  * [5] reference records inside L2 locus ranges, [6] L2 loci, [7] L2 slide events, [8] loci redone with the wide

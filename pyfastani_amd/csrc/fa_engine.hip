@@ -114,12 +114,12 @@ struct StageTrace {
   }
 };
 
-static void launch_sketch_tiles(const fa_params &P, const DevStore &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
+static void launch_sketch_tiles(const fa_params &P, const StoreView &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
                                 int32_t *stage_wpos, int32_t *tile_count, hipStream_t st) {
   if (ntiles <= 0) return;
   SketchArgs a;
   a.tiles = d_tiles;
-  a.packed = store.packed.p; a.bytes = store.bytes.p; a.exc_pos = store.exc_pos.p; a.exc_val = store.exc_val.p;
+  a.packed = store.packed; a.bytes = store.bytes; a.exc_pos = store.exc_pos; a.exc_val = store.exc_val;
   a.stage_hash = stage_hash; a.stage_wpos = stage_wpos; a.tile_count = tile_count;
   a.k = P.kmer_size; a.w = P.window_size; a.levels = floor_log2(P.window_size);
   a.protein = P.alphabet_size != 4;
@@ -205,7 +205,7 @@ struct fa_sketch {
         work.tile_off.ensure(ntiles + 1);
         FA_HIP(hipMemsetAsync(work.tile_count.p + ntiles, 0, sizeof(int32_t), stream));
         tr.mark("alloc_tiles", stream);
-        launch_sketch_tiles(P, store, work.tiles.p, ntiles, work.stage_hash.p, work.stage_wpos.p, work.tile_count.p, stream);
+        launch_sketch_tiles(P, store.view(), work.tiles.p, ntiles, work.stage_hash.p, work.stage_wpos.p, work.tile_count.p, stream);
         tr.mark("k_sketch", stream);
         d_seq_tile_lo.upload(seq_tile_lo, stream);
         d_seq_ids.upload(seq_ids, stream);
@@ -245,9 +245,34 @@ struct fa_sketch {
 // ------------------------------------------------------------------------------------------------------------
 // fa_genomes: packed query genomes resident in HBM, cut into fragments and tiles
 // ------------------------------------------------------------------------------------------------------------
+// Pinned host staging memory (grows, never shrinks; one per workspace / upload)
+struct PinnedBuf {
+  unsigned char *p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf &) = delete;
+  PinnedBuf &operator=(const PinnedBuf &) = delete;
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  void ensure(size_t n) {
+    if (n <= cap) return;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t ncap = std::max(n, cap * 2);
+    FA_HIP(hipHostMalloc((void **)&p, ncap, hipHostMallocDefault));
+    cap = ncap;
+  }
+};
+
+// Everything the kernels read of a batch sits in ONE device allocation, filled by ONE host-to-device copy from a staging
+// image of the same layout: [packed 2-bit words | residue bytes | tiles | frag_tile_lo | frag_query | frag_qseq |
+// total_frag], every part 16-byte aligned.  Only the exception lists (rare: N runs, IUPAC codes) are separate.
 struct fa_genomes {
   fa_params P;
-  DevStore store;
+  DevBuf<unsigned char> blob;
+  DevBuf<int64_t> exc_pos;
+  DevBuf<uint8_t> exc_val;
+  StoreView store;                          // pointers into blob / the exception buffers
+  const Tile *tiles = nullptr;
+  const int32_t *d_frag_tile_lo = nullptr, *d_frag_query = nullptr, *d_frag_qseq = nullptr, *d_total_frag = nullptr;
   int32_t n_genomes = 0;
   std::vector<int64_t> genome_frag_lo;      // [n_genomes + 1] fragment range of each genome
   std::vector<int32_t> frag_tile_lo;        // [F + 1]
@@ -255,8 +280,7 @@ struct fa_genomes {
   std::vector<int32_t> n_short;
   int64_t F = 0, ntiles = 0;
   uint64_t total_bases = 0;                 // bases inside fragments
-  DevBuf<Tile> tiles;
-  DevBuf<int32_t> d_frag_tile_lo, d_frag_query, d_frag_qseq, d_total_frag;
+  std::vector<unsigned char> host_image;    // staging image when no pinned buffer is supplied
 };
 
 // Every small counter / statistic of a pass in ONE device block, mirrored into pinned host memory by one copy.
@@ -294,6 +318,10 @@ struct Workspace {
   const fa_genomes *last_genomes = nullptr;
   float last_ms[16] = {0};
   hipEvent_t ev[6] = {nullptr};
+  // the one-query-at-a-time call (fa_mapper_query) recycles its batch object -- no device allocation per call -- and
+  // builds the upload image in pinned memory; its rows come back through a pinned block too
+  std::unique_ptr<fa_genomes> query_batch;
+  PinnedBuf pin_image, pin_rows;
   ~Workspace() {
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -371,6 +399,12 @@ __global__ void k_contig_bins(const int32_t *contig_rec, const int32_t *rec_wpos
     if (hi > lo) n = rec_wpos[hi - 1] / bin_len + 1;
   }
   nbins[c] = n;
+}
+
+// FA_L2_FUSED=1: build the extra index arrays of the fused L2 kernel and use it (see run_query_pass)
+static bool fused_l2_enabled() {
+  static const bool on = getenv("FA_L2_FUSED") && atoi(getenv("FA_L2_FUSED")) != 0;
+  return on;
 }
 
 // Sketch_t::index() + computeFreqHist() on the device
@@ -485,7 +519,7 @@ static void build_index(fa_mapper &m) {
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
     m.rec_sw.ensure((size_t)N + 4);
     hipLaunchKernelGGL(k_interleave_seq_wpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, N, m.rec_sw.p);
-    {
+    if (fused_l2_enabled()) {
       const size_t words = ((size_t)2 * (size_t)N + 31) / 32 + 4;
       m.ev_bits.ensure(words);
       FA_HIP(hipMemsetAsync(m.ev_bits.p, 0, words * sizeof(uint32_t), st));
@@ -609,7 +643,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     fa_mapper::Spec &ms = m.spec;
     if (!ms.init) {
       ms.init = true;
-      ms.smax = 256;
+      ms.smax = (int)env_u64("FA_SMAX_INIT", 256);                  // (development: a smaller first guess for small fragments)
       ms.seed_slots = 4096;
       ms.scratch_words = 0;
       ms.l_cap = (int64_t)env_u64("FA_LOCI_CAP_MIN", 1u << 18);   // the tests force the retry path with a tiny value
@@ -698,10 +732,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       cl.launch(st);
     }
     // ---- K1 + per-fragment sort/unique ----
-    launch_sketch_tiles(m.P, g.store, g.tiles.p + t0, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, st);
+    launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, st);
     {
       QuerySketchArgs a;
-      a.frag_tile_lo = g.d_frag_tile_lo.p + f0;
+      a.frag_tile_lo = g.d_frag_tile_lo + f0;
       a.tile_count = w.sk.tile_count.p; a.stage_hash = w.sk.stage_hash.p; a.stage_wpos = w.sk.stage_wpos.p;
       a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
       a.q_hash = w.q_hash.p; a.q_size = w.q_size.p; a.stats = d_stats; a.qcap = qcap;
@@ -781,6 +815,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.l_redo = w.l_redo.p;
       a.redo_count = d_counters + 3;
       a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
+      static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
+      a.dbg = fused_dbg;
       a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
       const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
       FA_REQUIRE(ev_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
@@ -819,23 +855,57 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
           hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
         }
       };
-      // fused form (events generated into an LDS ring and consumed in place: no event arena in HBM) whenever 64 loci
-      // per workgroup fit; FA_L2_FUSED=0 keeps the two-kernel form (k_l2_events + k_l2_scan) for comparison
-      static const bool fused_on = !(getenv("FA_L2_FUSED") && atoi(getenv("FA_L2_FUSED")) == 0);
-      const size_t fl8 = fused_lds_bytes<uint8_t>(a.cnt_slots, wide ? 4 : 2), fl16 = fused_lds_bytes<uint16_t>(a.cnt_slots, wide ? 4 : 2);
+      // FA_L2_FUSED=1 selects the fused form (events generated into an LDS ring and consumed in place: no event arena in
+      // HBM, L2-stage traffic 0.45 GB instead of 1.08 GB per bench step).  It is bit-exact but measured SLOWER than the
+      // two-kernel form on the bench step (0.81 ms against 0.42 ms): one or two producer waves per 64
+      // loci cannot hide their LDS round trips the way the 32 waves per CU of k_l2_events do, and the slide state (16-18 KB
+      // per 64 loci) leaves no LDS for more.  Kept as an experiment; the default is k_l2_events + k_l2_scan.
+      static const bool fused_on = fused_l2_enabled();
+      // ring rows of 16 events per locus unless the 2 KB a row of 8 saves buy one more workgroup per CU AND the
+      // fragments of this pass then fit the chip in one round (the slide is a latency-bound chain: rounds add up)
+      static const int fu_forced = (int)env_u64("FA_FUSED_C", 0);
+      const int evb = wide ? 4 : 2;
+      auto wg_bytes = [&](int c) { return (fused_lds_bytes<uint8_t>(a.cnt_slots, evb, c) + FU_STATIC_LDS + 511) / 512 * 512; };
+      auto per_cu = [&](int c) { return (int64_t)((160 * 1024) / wg_bytes(c)); };
+      int fu_c = 16;
+      if (fu_forced == 8 || fu_forced == 16) fu_c = fu_forced;
+      else if (per_cu(8) > per_cu(16) && F > per_cu(16) * 256 && F <= per_cu(8) * 256) fu_c = 8;
+      static const size_t fused_pad = (size_t)env_u64("FA_FUSED_LDS_PAD", 0);   // development: unused LDS behind the ring
+      const size_t fl8 = fused_lds_bytes<uint8_t>(a.cnt_slots, evb, fu_c) + fused_pad, fl16 = fused_lds_bytes<uint16_t>(a.cnt_slots, evb, fu_c);
       const bool fused = fused_on && fl16 <= 150 * 1024 && m.cmw < 65535;   // rec_hf keeps same-hash distances in 16 bits
+      static const int fu_nprod = (int)env_u64("FA_FUSED_PRODUCERS", 2) == 1 ? 1 : 2;
+      const int fu_threads = 64 * (1 + fu_nprod);
       auto launch_fused = [&](auto k8, auto k16) {
         if (fl8 > 60 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl8));
         const unsigned grid = (unsigned)(((F + 7) / 8) * 8);                // blockIdx -> (XCD, fragment of that XCD)
-        hipLaunchKernelGGL(k8, dim3(grid), dim3(FU_THREADS), fl8, st, a, F);
+        static const bool dbg_launch = getenv("FA_DEBUG_FUSED") != nullptr;
+        if (dbg_launch) {
+          int nb = -1;
+          (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k8, fu_threads, fl8);
+          hipFuncAttributes fa_;
+          (void)hipFuncGetAttributes(&fa_, (const void *)k8);
+          fprintf(stderr, "k_l2_fused: F=%lld grid=%u lds=%zu (+%zu static) fu_c=%d cnt_slots=%d redo=%d | occupancy API %d blocks/CU, numRegs %d, sharedSizeBytes %zu, maxDynShared %d\n",
+                  (long long)F, grid, fl8, FU_STATIC_LDS, fu_c, a.cnt_slots, (int)sp.redo, nb, fa_.numRegs, fa_.sharedSizeBytes, fa_.maxDynamicSharedSizeBytes);
+        }
+        hipLaunchKernelGGL(k8, dim3(grid), dim3(fu_threads), fl8, st, a, F);
         if (!sp.redo) return;
         if (fl16 > 60 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl16));
-        hipLaunchKernelGGL(k16, dim3(grid), dim3(FU_THREADS), fl16, st, a, F);
+        hipLaunchKernelGGL(k16, dim3(grid), dim3(fu_threads), fl16, st, a, F);
       };
       const bool pk = m.packed_geo && !getenv("FA_NO_PACKED_GEO");
       if (fused) {
-        if (wide) launch_fused(k_l2_fused<uint32_t, uint8_t, false>, k_l2_fused<uint32_t, uint16_t, true>);
-        else launch_fused(k_l2_fused<uint16_t, uint8_t, false>, k_l2_fused<uint16_t, uint16_t, true>);
+        auto pick = [&](auto ev_tag) {
+          using EV = decltype(ev_tag);
+          if (fu_nprod == 2) {
+            if (fu_c == 8) launch_fused(k_l2_fused<EV, uint8_t, false, 8, 2>, k_l2_fused<EV, uint16_t, true, 8, 2>);
+            else launch_fused(k_l2_fused<EV, uint8_t, false, 16, 2>, k_l2_fused<EV, uint16_t, true, 16, 2>);
+          } else {
+            if (fu_c == 8) launch_fused(k_l2_fused<EV, uint8_t, false, 8, 1>, k_l2_fused<EV, uint16_t, true, 8, 1>);
+            else launch_fused(k_l2_fused<EV, uint8_t, false, 16, 1>, k_l2_fused<EV, uint16_t, true, 16, 1>);
+          }
+        };
+        if (wide) pick(uint32_t()); else pick(uint16_t());
+        w.last_ms[14] = (float)smax; w.last_ms[15] = (float)fu_c;
       } else if (wide) {
         if (pk) launch(k_l2_events<uint32_t, true>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
         else launch(k_l2_events<uint32_t, false>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
@@ -852,7 +922,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       CgiArgs a;
       a.ix = ix; a.group_best = w.group_best.p; a.counters = d_counters; a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p;
       a.l_pos = w.l_pos.p; a.q_size = w.q_size.p; a.ident_lut = w.lut_ident;
-      a.frag_query = g.d_frag_query.p + f0; a.frag_qseq = g.d_frag_qseq.p + f0; a.bins = w.bins.p;
+      a.frag_query = g.d_frag_query + f0; a.frag_qseq = g.d_frag_qseq + f0; a.bins = w.bins.p;
       a.bin_len = m.P.fragment_length - 20;
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
@@ -862,7 +932,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       ra.bins = w.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
       ra.row_count = w.row_count.p; ra.row_ident = w.row_ident.p;
       ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
-      ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag.p + g0; ra.query_id_base = g0;
+      ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag + g0; ra.query_id_base = g0;
       ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = d_total_rows;
       hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
       if (ra.emit) {
@@ -872,7 +942,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         exclusive_sum_i32(w.sk.cub_temp, w.row_flag.p, w.row_off.p, (int)npairs + 1, st);
         FA_HIP(hipMemcpyAsync(d_total_rows, w.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, w.row_ident.p, w.row_off.p, m.G,
-                           npairs, g.d_total_frag.p + g0, g0, rows_dev + row_base, cap - row_base);
+                           npairs, g.d_total_frag + g0, g0, rows_dev + row_base, cap - row_base);
       }
     }
     FA_HIP(hipGetLastError());
@@ -954,8 +1024,12 @@ static int64_t run_query(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_
     g0 = g1;
   }
   if (!rows_device && nrows) {
-    FA_HIP(hipMemcpyAsync(rows, w.rows_dev.p, (size_t)nrows * sizeof(fa_cgi_row), hipMemcpyDeviceToHost, w.stream));
+    // through pinned memory: a device-to-pageable copy of a few KB costs more in staging than the copy itself
+    const size_t bytes = (size_t)nrows * sizeof(fa_cgi_row);
+    w.pin_rows.ensure(std::max<size_t>(bytes, 4096));
+    FA_HIP(hipMemcpyAsync(w.pin_rows.p, w.rows_dev.p, bytes, hipMemcpyDeviceToHost, w.stream));
     FA_HIP(hipStreamSynchronize(w.stream));
+    memcpy(rows, w.pin_rows.p, bytes);
   }
   return nrows;
 }
@@ -990,10 +1064,12 @@ struct WorkspaceLease {
   }
 };
 
-// pack + cut into fragments + tiles + upload
+// pack + cut into fragments + tiles + upload.  `reuse` (a batch object whose device buffers are recycled, contents
+// replaced) and `pin` (pinned staging memory the image is built in, so that the one upload is a plain DMA) serve the
+// one-query-at-a-time call; without them the image is built in pageable memory.
 static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
                                                   const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width,
-                                                  float *host_ms = nullptr) {
+                                                  float *host_ms = nullptr, std::unique_ptr<fa_genomes> reuse = nullptr, PinnedBuf *pin = nullptr) {
   require_device();
   const auto t_begin = std::chrono::steady_clock::now();
   auto lap = [&, last = t_begin](int slot) mutable {
@@ -1002,71 +1078,109 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
     last = now;
   };
   FA_REQUIRE(width == 1 || width == 2 || width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
-  std::unique_ptr<fa_genomes> g(new fa_genomes());
+  std::unique_ptr<fa_genomes> g = reuse ? std::move(reuse) : std::unique_ptr<fa_genomes>(new fa_genomes());
   g->P = P;
   g->n_genomes = n_genomes;
   g->total_fragments.assign(n_genomes, 0); g->total_length.assign(n_genomes, 0); g->n_short.assign(n_genomes, 0);
+  g->total_bases = 0;
   HostStore hs;
   hs.protein = P.alphabet_size != 4;
-  std::vector<Tile> tiles;
-  std::vector<int32_t> frag_query, frag_qseq;
   g->genome_frag_lo.assign((size_t)n_genomes + 1, 0);
   g->frag_tile_lo.clear();
   const int frag = P.fragment_length;
   const int64_t min_len = std::min<int64_t>(std::min(P.window_size, P.kmer_size), frag);
-  // pass 1: which contigs are mapped, and how many whole fragments each holds; pack them all at once (threaded)
+  // pass 1: which contigs are mapped, and how many whole fragments each holds -- this fixes every size of the image
   std::vector<const void *> use_ptr;
-  std::vector<int64_t> use_len, use_contig;
+  std::vector<int64_t> use_len;
+  int64_t F = 0;
   for (int64_t c = 0; c < n_contigs; c++) {
     const int64_t len = lengths[c];
     if (len < min_len) continue;
     const int64_t nfrag = len / frag;
-    if (nfrag > 0) { use_ptr.push_back(contigs[c]); use_len.push_back(nfrag * frag); use_contig.push_back(c); }   // the tail past the last whole fragment is never read
+    if (nfrag > 0) { use_ptr.push_back(contigs[c]); use_len.push_back(nfrag * frag); F += nfrag; }   // the tail past the last whole fragment is never read
   }
+  const int64_t npos_frag = (int64_t)frag - P.kmer_size + 1;
+  const int64_t tiles_per_frag = npos_frag > 0 ? (npos_frag + TILE - 1) / TILE : 0;
+  const int64_t ntiles = F * tiles_per_frag;
+  FA_REQUIRE(ntiles < (1LL << 31) - 1 && F < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "too many fragments in one batch");
+  const size_t bases = (size_t)HostStore::padded_bases(use_len.data(), (int64_t)use_len.size());
+  auto al = [](size_t x) { return (x + 15) / 16 * 16; };
+  const size_t o_packed = 0, n_packed = hs.protein ? 0 : al(bases / 4 + 64);
+  const size_t o_bytes = o_packed + n_packed, n_bytes = hs.protein ? al(bases + 64) : 0;
+  const size_t o_tiles = o_bytes + n_bytes, n_tiles = al((size_t)std::max<int64_t>(ntiles, 1) * sizeof(Tile));
+  const size_t o_ftl = o_tiles + n_tiles, n_ftl = al(((size_t)F + 1) * 4);
+  const size_t o_fq = o_ftl + n_ftl, n_fq = al((size_t)std::max<int64_t>(F, 1) * 4);
+  const size_t o_fs = o_fq + n_fq, n_fs = n_fq;
+  const size_t o_tf = o_fs + n_fs, n_tf = al((size_t)std::max(n_genomes, 1) * 4);
+  const size_t image_bytes = o_tf + n_tf;
+  unsigned char *img;
+  if (pin) { pin->ensure(image_bytes); img = pin->p; }
+  else { g->host_image.resize(image_bytes); img = g->host_image.data(); }
   StageTrace tr("upload_genomes");
-  hs.append_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width);
+  // the slack behind the packed words / bytes (the sketch kernel's funnel shift reads one word past the end)
+  if (!hs.protein) memset(img + o_packed + bases / 4, 0, n_packed - bases / 4); else memset(img + o_bytes + bases, 0, n_bytes - bases);
+  hs.pack_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width, (uint32_t *)(img + o_packed), img + o_bytes);
   tr.mark("pack", st);
   lap(0);
-  // pass 2: fragments, tiles and per-genome bookkeeping, in contig order
+  // pass 2: fragments, tiles and per-genome bookkeeping, in contig order, written straight into the image
+  Tile *tiles = (Tile *)(img + o_tiles);
+  int32_t *frag_query = (int32_t *)(img + o_fq), *frag_qseq = (int32_t *)(img + o_fs), *tf = (int32_t *)(img + o_tf);
+  g->frag_tile_lo.reserve((size_t)F + 1);
+  std::vector<Tile> scratch;
   int32_t cur = 0;
   size_t used = 0;
+  int64_t nf = 0, nt = 0;
   for (int64_t c = 0; c < n_contigs; c++) {
     int32_t gi = contig_genome ? contig_genome[c] : 0;
     FA_REQUIRE(gi >= cur && gi < n_genomes, FA_ERR_INVALID, "contig_genome must be non-decreasing and < n_genomes");
-    while (cur < gi) { cur++; g->genome_frag_lo[cur] = (int64_t)frag_query.size(); }
+    while (cur < gi) { cur++; g->genome_frag_lo[cur] = nf; }
     const int64_t len = lengths[c];
     if (len < min_len) { g->n_short[gi]++; continue; }               // _fastani.pyx:1061-1070
     const int64_t nfrag = len / frag;                                 // :1097
     if (nfrag > 0) {
       const int64_t si = (int64_t)used++;
       for (int64_t i = 0; i < nfrag; i++) {
-        g->frag_tile_lo.push_back((int32_t)tiles.size());
-        make_tiles(tiles, hs, hs.seq_off[si] + i * frag, frag, (int)frag_query.size(), P.kmer_size, P.window_size);
-        frag_qseq.push_back((int32_t)(g->total_fragments[gi] + i));   // :985
-        frag_query.push_back(gi);
+        g->frag_tile_lo.push_back((int32_t)nt);
+        scratch.clear();
+        make_tiles(scratch, hs, hs.seq_off[si] + i * frag, frag, (int)nf, P.kmer_size, P.window_size);
+        for (const Tile &t : scratch) tiles[nt++] = t;
+        frag_qseq[nf] = (int32_t)(g->total_fragments[gi] + i);        // :985
+        frag_query[nf] = gi;
+        nf++;
       }
     }
     g->total_fragments[gi] += (uint64_t)nfrag;                        // :1104
     g->total_length[gi] += (uint64_t)len;                             // :1105
     g->total_bases += (uint64_t)(nfrag * frag);
   }
-  while (cur < n_genomes) { cur++; g->genome_frag_lo[cur] = (int64_t)frag_query.size(); }
-  g->F = (int64_t)frag_query.size();
-  g->frag_tile_lo.push_back((int32_t)tiles.size());
-  g->ntiles = (int64_t)tiles.size();
+  while (cur < n_genomes) { cur++; g->genome_frag_lo[cur] = nf; }
+  FA_REQUIRE(nf == F && nt == ntiles, FA_ERR_INTERNAL, "fragment / tile count mismatch while building the batch image");
+  g->F = F;
+  g->frag_tile_lo.push_back((int32_t)nt);
+  g->ntiles = ntiles;
+  memcpy(img + o_ftl, g->frag_tile_lo.data(), ((size_t)F + 1) * 4);
+  for (int i = 0; i < n_genomes; i++) tf[i] = (int32_t)g->total_fragments[i];
   tr.mark("fragments_tiles", st);
   lap(1);
-  g->store.upload(hs, st);
-  g->tiles.upload(tiles, st);
-  g->d_frag_tile_lo.upload(g->frag_tile_lo, st);
+  g->blob.ensure(image_bytes);
+  FA_HIP(hipMemcpyAsync(g->blob.p, img, image_bytes, hipMemcpyHostToDevice, st));
+  const int64_t n_exc = (int64_t)hs.exc_pos.size();
+  if (n_exc) { g->exc_pos.upload(hs.exc_pos, st); g->exc_val.upload(hs.exc_val, st); }
+  g->store = StoreView();
+  g->store.packed = hs.protein ? nullptr : (const uint32_t *)(g->blob.p + o_packed);
+  g->store.bytes = hs.protein ? (const uint8_t *)(g->blob.p + o_bytes) : nullptr;
+  g->store.exc_pos = g->exc_pos.p; g->store.exc_val = g->exc_val.p; g->store.n_exc = n_exc;
+  g->tiles = (const Tile *)(g->blob.p + o_tiles);
+  g->d_frag_tile_lo = (const int32_t *)(g->blob.p + o_ftl);
   // the CGI bins of a pass are indexed by the genome number relative to the first genome of the pass; passes start at
-  // genome boundaries, so store per-fragment genome numbers and let the kernel subtract via the bins pointer offset
-  g->d_frag_query.upload(frag_query, st);
-  g->d_frag_qseq.upload(frag_qseq, st);
-  std::vector<int32_t> tf(n_genomes);
-  for (int i = 0; i < n_genomes; i++) tf[i] = (int32_t)g->total_fragments[i];
-  g->d_total_frag.upload(tf, st);
+  // genome boundaries, so the per-fragment genome numbers are batch-wide and the kernel subtracts the pass's first genome
+  g->d_frag_query = (const int32_t *)(g->blob.p + o_fq);
+  g->d_frag_qseq = (const int32_t *)(g->blob.p + o_fs);
+  g->d_total_frag = (const int32_t *)(g->blob.p + o_tf);
+  // the staging image must stay untouched until the copy has left it (pageable copies return after staging, pinned ones
+  // are asynchronous): one synchronisation per upload
   FA_HIP(hipStreamSynchronize(st));
+  if (!pin) { std::vector<unsigned char>().swap(g->host_image); }
   tr.mark("uploads", st);
   lap(2);
   return g;
@@ -1489,7 +1603,8 @@ int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *len
     WorkspaceLease lease(*m);
     std::vector<int32_t> cg((size_t)std::max(n_contigs, 1), 0);
     float host_ms[3] = {0, 0, 0};
-    auto g = upload_genomes(m->P, lease.w->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width, host_ms);
+    auto g = upload_genomes(m->P, lease.w->stream, contigs, lengths, cg.data(), n_contigs, 1, char_width, host_ms,
+                            std::move(lease.w->query_batch), &lease.w->pin_image);
     if (n_short) *n_short = g->n_short[0];
     if (total_fragments) *total_fragments = g->total_fragments[0];
     if (total_length) *total_length = g->total_length[0];
@@ -1499,6 +1614,7 @@ int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *len
     for (int i = 0; i < 3; i++) lease.w->last_ms[10 + i] = host_ms[i];
     lease.w->last_ms[13] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     lease.w->last_genomes = nullptr;
+    lease.w->query_batch = std::move(g);                 // keep the device buffers for the next call
   });
 }
 
@@ -1581,6 +1697,40 @@ int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t 
   });
 }
 
+// development probe: how many 128-thread workgroups with `lds_bytes` of dynamic LDS does the chip hold at once, right now?
+__global__ void k_probe_occupancy(unsigned *alive, unsigned *peak, int spin) {
+  extern __shared__ unsigned char probe_lds[];
+  if (threadIdx.x == 0) { unsigned a = atomicAdd(alive, 1u) + 1u; atomicMax(peak, a); }
+  probe_lds[threadIdx.x] = (unsigned char)threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)spin) __builtin_amdgcn_s_sleep(8);
+  __syncthreads();
+  if (threadIdx.x == 0) atomicSub(alive, 1u);
+  if (probe_lds[(threadIdx.x + 1) & 63] == 255 && spin < 0) alive[1] = 1;
+}
+int fa_debug_probe_occupancy(int lds_bytes, int *peak_alive) {
+  return guarded([&] {
+    require_device();
+    DevBuf<unsigned> d;
+    d.ensure(16);
+    FA_HIP(hipMemset(d.p, 0, 64));
+    hipLaunchKernelGGL(k_probe_occupancy, dim3(4096), dim3(128), (size_t)lds_bytes, 0, d.p, d.p + 4, 200000);
+    FA_HIP(hipDeviceSynchronize());
+    unsigned h[8];
+    FA_HIP(hipMemcpy(h, d.p, 32, hipMemcpyDeviceToHost));
+    *peak_alive = (int)h[4];
+  });
+}
+int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
+    Workspace &w = m->ws[m->last_ws];
+    FA_REQUIRE(bytes >= 0 && (size_t)bytes <= w.items.cap, FA_ERR_INVALID, "more bytes than the event arena holds");
+    FA_HIP(hipMemcpy(out, w.items.p, (size_t)bytes, hipMemcpyDeviceToHost));
+  });
+}
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {
   std::lock_guard<std::mutex> lock(m->mtx);
   for (int i = 0; i < n && i < 16; i++) ms[i] = m->ws[m->last_ws].last_ms[i];
@@ -1600,10 +1750,10 @@ int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_pe
     w.sk.tile_count.ensure((size_t)ntiles + 1);
     hipEvent_t e0, e1;
     FA_HIP(hipEventCreate(&e0)); FA_HIP(hipEventCreate(&e1));
-    launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
+    launch_sketch_tiles(m->P, g->store, g->tiles, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
     FA_HIP(hipEventRecord(e0, w.stream));
     for (int i = 0; i < repeat; i++)
-      launch_sketch_tiles(m->P, g->store, g->tiles.p, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
+      launch_sketch_tiles(m->P, g->store, g->tiles, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
     FA_HIP(hipEventRecord(e1, w.stream));
     FA_HIP(hipEventSynchronize(e1));
     float ms = 0;

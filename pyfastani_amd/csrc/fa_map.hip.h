@@ -1104,6 +1104,8 @@ struct L2Args {
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
   const uint32_t *f_loci_lo, *f_loci_n;   // [F] loci of each fragment
+  int32_t dbg;                       // FA_FUSED_DEBUG (timing experiments only, results are void): 1 = slider idles,
+                                     // 2 = producer composes no events, 4 = producer issues no loads
 };
 
 constexpr int L2_THREADS = 64;
@@ -1448,18 +1450,17 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
 // chain per locus: a second round of workgroups would double the time).  blockIdx is mapped to fragments so that
 // neighbouring fragments -- whose loci overlap on the reference -- share an XCD and its L2.
 // ----------------------------------------------------------------------------------------------------------
-constexpr int FU_THREADS = 128;
-constexpr int FU_C = 16;                    // events per locus and ring row
-constexpr int FU_UPI = 64 / FU_C;           // loci per producer iteration
-constexpr int FU_ITERS = 64 / FU_UPI;       // producer iterations per row
 constexpr int FU_QT_BITS = 8;               // bucket table resolution
+constexpr int FU_PROBE = 4;                 // sketch entries compared at once per rank lookup
 
+// FU_C = events per locus and ring row (16, or 8 when the longer ring would cost a workgroup per CU)
 template <typename ST>
-__host__ __device__ inline size_t fused_lds_bytes(int cnt_slots, int ev_bytes) {
+__host__ __device__ inline size_t fused_lds_bytes(int cnt_slots, int ev_bytes, int fu_c) {
   size_t state = ((size_t)(cnt_slots + 1) * 64 * sizeof(ST) + 15) / 16 * 16;
-  size_t q = ((size_t)cnt_slots * 4 + 15) / 16 * 16;
-  return state + q + (size_t)2 * FU_C * 64 * ev_bytes;
+  size_t q = ((size_t)(cnt_slots + FU_PROBE) * 4 + 15) / 16 * 16;
+  return state + q + (size_t)2 * fu_c * 64 * ev_bytes;
 }
+constexpr size_t FU_STATIC_LDS = 528;       // QT + the three scalars (checked against the compiler's figure at launch)
 
 // hash, flags and the (saturated) distance to the previous record of the same hash in one 8-byte record for the fused
 // kernel: y = flags | min(i - rec_prev[i], 65535) << 8   (65535 also for "no earlier record of this hash in the contig")
@@ -1471,15 +1472,26 @@ __global__ void k_pack_hf(const uint32_t *rec_hash, const uint8_t *rec_flags, co
   rec_hf[i] = make_uint2(rec_hash[i], (uint32_t)rec_flags[i] | (d << 8));
 }
 
-template <typename T, typename ST, bool REDO>
-__global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_frag) {
+// Workgroup barrier that orders LDS accesses only: __syncthreads() also drains every outstanding global load
+// (s_waitcnt vmcnt(0)), which would expose the latency of the producer's prefetches at every ring row.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// NPROD producer waves per workgroup (each serves 64 / NPROD loci); FU_C events per locus and ring row
+template <typename T, typename ST, bool REDO, int FU_C, int NPROD>
+__global__ __launch_bounds__(64 * (1 + NPROD), (NPROD == 2 && FU_C == 8) ? 6 : 4) void k_l2_fused(L2Args a, int64_t n_frag) {
   extern __shared__ __align__(16) unsigned char lds[];
+  constexpr int FU_THREADS = 64 * (1 + NPROD);
+  constexpr int FU_UPI = 64 / FU_C;                    // loci per producer iteration (of one wave)
+  constexpr int FU_ITERS = 64 / NPROD / FU_UPI;        // producer iterations per row (of one wave)
+  static_assert(FU_ITERS >= 2 && FU_ITERS <= FU_C, "every locus of a producer wave needs an owner lane");
   constexpr int RB = EvBits<T>::RANK;
   constexpr int SBITS = 8 * (int)sizeof(ST);
   __shared__ uint16_t QT[(1 << FU_QT_BITS) + 2];
-  __shared__ int32_t u_beg[64];                                      // first record of the locus range (-1: lane unused)
-  __shared__ uint32_t u_e0[64], u_nmain[64];                         // events behind the first super-window; events of the slide
-  __shared__ int sh_fill_rows, sh_rows;
+  __shared__ int sh_fill_rows, sh_rows, sh_steps;
   // fragments of one XCD (blockIdx % 8, the dispatch order of workgroups) are consecutive
   const int64_t per_xcd = (n_frag + 7) / 8;
   const int64_t f64 = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
@@ -1490,29 +1502,46 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
   const int s = a.q_size[f];
   if (a.counters[2] || s > a.cnt_slots - 1) return;                  // loci overflowed / sketch larger than speculated: void pass
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // FA_FUSED_DEBUG & 8: per-workgroup time stamps {start, first row, end, hardware id, rows, loci} into the (otherwise
+  // unused) event arena, read back with fa_mapper_debug_items
+  unsigned long long *stamp = (a.dbg & 8) ? (unsigned long long *)a.items + (size_t)blockIdx.x * 8 : nullptr;
+  if (stamp && tid == 0) { stamp[0] = __builtin_amdgcn_s_memrealtime(); stamp[3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); stamp[5] = l_n; stamp[6] = 0; stamp[7] = 0;
+    // workgroups alive when this one starts (a running count kept behind the stamps)
+    stamp[5] |= (unsigned long long)atomicAdd((unsigned int *)((unsigned long long *)a.items + (size_t)gridDim.x * 8), 1u) << 32; }
   ST *st = (ST *)lds;                                                // [cnt_slots + 1][64], lane-interleaved
   uint32_t *Q = (uint32_t *)(lds + ((size_t)(a.cnt_slots + 1) * 64 * sizeof(ST) + 15) / 16 * 16);
-  T *ring = (T *)((unsigned char *)Q + ((size_t)a.cnt_slots * 4 + 15) / 16 * 16);   // [2][FU_C][64]
-  for (int i = tid; i < s; i += FU_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  T *ring = (T *)((unsigned char *)Q + ((size_t)(a.cnt_slots + FU_PROBE) * 4 + 15) / 16 * 16);   // [2][FU_C][64]
+  // between groups the ring doubles as the hand-over of the locus ranges from the slider's lanes to the producer's
+  int32_t *u_beg = (int32_t *)ring;                                   // first record of the locus range (-1: lane unused)
+  uint32_t *u_e0 = (uint32_t *)ring + 64, *u_nmain = (uint32_t *)ring + 128;   // events behind the first window; events of the slide
+  for (int i = tid; i < s + FU_PROBE; i += FU_THREADS) Q[i] = i < s ? a.q_hash[(size_t)f * a.qcap + i] : 0xFFFFFFFFu;   // + sentinels
   __syncthreads();
-  // bucket table over the hash range the sketch spans (see k_l2_events)
+  // Bucket table for the rank lookups.  Minimizer hashes are window minima: their density falls off exponentially from 0,
+  // so the buckets are laid over 1 - 2^(-c h) (monotone, one v_exp_f32) rather than over h itself -- about one sketch
+  // entry per bucket everywhere, instead of a dozen in the first buckets.  QT[b] = first rank whose bucket is >= b.
   const uint32_t hmax = s > 0 ? Q[s - 1] : 0u;
-  const int qshift = max(0, (32 - __clz((int)(hmax | 1u))) - FU_QT_BITS);
-  for (int b = tid; b <= (1 << FU_QT_BITS); b += FU_THREADS) {
-    int x = 0, y = s;
-    const uint64_t key = (uint64_t)b << qshift;
-    while (x < y) { int mid = (x + y) >> 1; if ((uint64_t)Q[mid] < key) x = mid + 1; else y = mid; }
-    QT[b] = (uint16_t)x;
-  }
-  if (tid == 0) QT[(1 << FU_QT_BITS) + 1] = (uint16_t)s;
-  // rank of a reference hash in the query sketch: slot = rank + 1, found = the hash is in the sketch
-  auto rank_of = [&](uint32_t h, bool &found) __attribute__((always_inline)) {
-    const uint32_t qb = min(h >> qshift, (uint32_t)(1 << FU_QT_BITS));
-    int x = QT[qb], y = QT[qb + 1];
-    while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
-    found = x < s && Q[x] == h;
-    return (uint32_t)(x + 1);
+  const float bscale = -8.0f / (float)max(hmax, 1u);                 // 2^-8 of the mass beyond the largest hash
+  auto bucket_of = [&](uint32_t h) __attribute__((always_inline)) {
+    const float t = __builtin_amdgcn_exp2f((float)h * bscale);      // 1 .. 2^-8 .. 0
+    return (uint32_t)min(255.0f, 256.0f - 256.0f * t);              // 0 .. 255 (monotone in h)
   };
+  if (tid == 0) sh_steps = 0;
+  for (int b = tid; b <= (1 << FU_QT_BITS) + 1; b += FU_THREADS) QT[b] = (uint16_t)s;
+  __syncthreads();
+  for (int i = tid; i < s; i += FU_THREADS) {
+    const uint32_t bi = bucket_of(Q[i]), bp = i > 0 ? bucket_of(Q[i - 1]) : 0xFFFFFFFFu;
+    // rank i opens every bucket in (bucket of rank i-1, bucket of rank i]
+    if (i == 0) { for (uint32_t b = 0; b <= bi; b++) QT[b] = 0; }
+    else for (uint32_t b = bp + 1; b <= bi; b++) QT[b] = (uint16_t)i;
+  }
+  __syncthreads();
+  {
+    // sh_steps: further FU_PROBE-wide probes that the fullest bucket needs after the first one
+    int width = 0;
+    for (int b = tid; b < (1 << FU_QT_BITS); b += FU_THREADS) width = max(width, (int)QT[b + 1] - (int)QT[b]);
+    for (int d = 32; d > 0; d >>= 1) width = max(width, __shfl_xor(width, d));
+    if (lane == 0 && width > FU_PROBE) atomicMax(&sh_steps, (width - 1) / FU_PROBE);
+  }
   typedef __attribute__((address_space(3))) ST *lds_ptr;
   constexpr int STB = (int)sizeof(ST);
   constexpr int LNB = 64 * STB;                                      // bytes between consecutive slots of one lane
@@ -1523,6 +1552,7 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
     // ---- the loci of this group: record ranges (the three searchIndex calls of computeL2MappedRegions) ----
     __syncthreads();
     int32_t my_locus = -1;                                             // slider lanes: the locus of this lane
+    int my_beg = 0;
     if (wv == 0) {
       const uint32_t l = l_lo + g0 + lane;
       bool active = g0 + lane < l_n;
@@ -1545,6 +1575,7 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
         records = (uint32_t)(last - beg);
         nev = (uint32_t)(end0 - beg) + nmain;
         my_locus = (int32_t)l;
+        my_beg = beg;
       }
       u_beg[lane] = beg; u_e0[lane] = e0; u_nmain[lane] = nmain;
       int fr = fill_rows, mr = main_rows;
@@ -1560,90 +1591,146 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
     }
     for (int i = tid; i < (s + 2) * 64; i += FU_THREADS) st[i] = (ST)0;
     __syncthreads();
-    const int R_fill = sh_fill_rows, R_all = sh_rows;
+    const int R_fill = sh_fill_rows, R_all = sh_rows, n_steps = sh_steps;
     if (R_all == 0) continue;
+    if (stamp && tid == 0 && g0 == 0) { stamp[1] = __builtin_amdgcn_s_memrealtime(); stamp[4] = (unsigned long long)R_all | ((unsigned long long)R_fill << 32); }
 
     // ---- producer: a three-stage pipeline over the rows, so that no stage waits for the loads it issued itself ----
     //   A(row)  main rows: load the merged-order bits of the row                         (global, one row-time ahead of B)
     //   B(row)  which record every event of the row belongs to; load that record (rec_hf) (global, one row-time ahead of C)
     //   C(row)  rank of the hash in the query sketch, compose the event, store it in ring buffer row & 1    (LDS only)
-    // One producer step runs C(t), B(t+1), A(t+2); the slider consumes row t-1 meanwhile.
+    // One producer step runs C(t), B(t+1), A(t+2); the slider consumes row t-1 meanwhile.  Everything is straight-line,
+    // select-based code with the sixteen iterations of a row independent of each other, so that their LDS round trips
+    // overlap: one wave produces for 64 loci and cannot afford a chain of dependent probes per iteration.
     const int pe = lane & (FU_C - 1);                                  // event of the row this producer lane composes
     const int pu = lane / FU_C;                                        // its locus inside an iteration
-    // per-locus cursors live in ONE lane each (lane (pu, pe) owns locus pe * FU_UPI + pu) and are fetched by the 16 lanes
-    // that compose the locus's events with a cross-lane read: 16 registers less than a copy per iteration
-    const int own = pe * FU_UPI + pu;
-    uint32_t own_bits = 0u;                                            // A -> B: the order bits of the owned locus's row
-    uint32_t own_ia = 0u;                                              // admits behind the stream of the owned locus
-    uint2 phf[FU_ITERS];                                               // B -> C: the record; y bit 31 = admit, bit 30 = valid
+    // the cursors of a locus live in ONE lane (lane (pu, pe) owns locus pe * FU_UPI + pu) and reach the 16 lanes that
+    // compose the locus's events by cross-lane reads
+    const int ubase = (wv > 0 ? wv - 1 : 0) * (64 / NPROD);           // first locus this producer wave serves
+    const int own = ubase + (pe < FU_ITERS ? pe : 0) * FU_UPI + pu;    // (lanes with pe >= FU_ITERS own nothing)
+    const bool owner = pe < FU_ITERS;
+    int own_beg = -1;
+    uint32_t own_e0 = 0u, own_nfill = 0u, own_nmain = 0u, own_ia = 0u;
+    uint32_t own_w0 = 0u, own_w1 = 0u;                                 // A -> B: order bits of the owned locus's row (raw words)
+    uint2 phf[FU_ITERS];                                               // B -> C: the raw records
+    uint32_t pok = 0u, padmit = 0u;                                    // B -> C: bit it = event of iteration it exists / is an admit
     auto stage_a = [&](int row) __attribute__((always_inline)) {
       if (row < R_fill || row >= R_all) return;
       const uint32_t off = (uint32_t)(row - R_fill) * FU_C;
-      const bool ok = u_beg[own] >= 0 && off < u_nmain[own];
-      const uint32_t p0 = u_e0[own] + off;
-      const uint32_t w0 = ok ? a.ix.ev_bits[p0 >> 5] : 0u;
-      const uint32_t w1 = ok ? a.ix.ev_bits[(p0 >> 5) + 1] : 0u;
-      own_bits = __funnelshift_r(w0, w1, p0 & 31u) & ((1u << FU_C) - 1u);
+      const uint32_t wi = (own_beg >= 0 && off < own_nmain) ? ((own_e0 + off) >> 5) : 0u;   // unconditional loads (see stage B)
+      own_w0 = a.ix.ev_bits[wi];
+      own_w1 = a.ix.ev_bits[wi + 1];
     };
     auto stage_b = [&](int row) __attribute__((always_inline)) {
+      pok = 0u; padmit = 0u;
       if (row >= R_all) return;
+      uint32_t prec[FU_ITERS];
       if (row < R_fill) {
+        const uint32_t k0 = (uint32_t)row * FU_C;
+        const uint32_t my_first = (uint32_t)max(own_beg, 0) + k0;       // first record of the owned locus's row
+        const uint32_t my_n = own_nfill > k0 ? min(own_nfill - k0, (uint32_t)FU_C) : 0u;
 #pragma unroll
         for (int it = 0; it < FU_ITERS; it++) {
-          const int u = it * FU_UPI + pu;
-          const int beg = u_beg[u];
-          const int k = row * FU_C + pe;                               // k-th record of the first super-window
-          const bool ok = beg >= 0 && (uint32_t)k < u_e0[u] - 2u * (uint32_t)beg;   // e0 = beg + end0
-          phf[it] = ok ? a.ix.rec_hf[beg + k] : make_uint2(0u, 0u);
-          // the hash is already in the window when its previous occurrence lies at or after `beg`: a no-op admit (bit 29)
-          const uint32_t dist = (phf[it].y >> 8) & 0xFFFFu;
-          phf[it].y = (phf[it].y & 0xFFu) | (ok ? 0x40000000u : 0u) | ((ok && dist <= (uint32_t)k) ? 0x20000000u : 0u);
+          const int src = pu * FU_C + it;                              // the lane that owns locus it * FU_UPI + pu
+          const uint32_t first = (uint32_t)__shfl((int)my_first, src), n = (uint32_t)__shfl((int)my_n, src);
+          const bool ok = (uint32_t)pe < n;
+          prec[it] = ok ? first + (uint32_t)pe : 0u;
+          pok |= (ok ? 1u : 0u) << it;
         }
       } else {
         const uint32_t off = (uint32_t)(row - R_fill) * FU_C;
-        const uint32_t my_bits = own_bits, my_ia = own_ia;
+        const uint32_t my_n = (own_beg >= 0 && own_nmain > off) ? min(own_nmain - off, (uint32_t)FU_C) : 0u;
+        const uint32_t my_p0 = own_e0 + off;
+        const uint32_t my_bits = __funnelshift_r(own_w0, own_w1, my_p0 & 31u) & ((1u << FU_C) - 1u);
+        const uint32_t my_ia = own_ia;
+        const uint32_t my_bn = my_bits | (my_n << 16);
+        const uint32_t my_jd = my_p0 - my_ia;                          // drops behind the stream = the next record to drop
         own_ia = my_ia + (uint32_t)__popc(my_bits);
+        const uint32_t below = (1u << pe) - 1u;
 #pragma unroll
         for (int it = 0; it < FU_ITERS; it++) {
-          const int u = it * FU_UPI + pu;
-          const int src = pu * FU_C + it;                              // the lane that owns locus u
-          const uint32_t bits = (uint32_t)__shfl((int)my_bits, src), ia = (uint32_t)__shfl((int)my_ia, src);
-          const bool ok = u_beg[u] >= 0 && off + (uint32_t)pe < u_nmain[u];
-          const uint32_t p0 = u_e0[u] + off;
-          const uint32_t before = (uint32_t)__popc(bits & ((1u << pe) - 1u));
-          const uint32_t admit = (bits >> pe) & 1u;
-          const uint32_t rec = admit ? ia + before : (p0 - ia) + ((uint32_t)pe - before);
-          phf[it] = ok ? a.ix.rec_hf[rec] : make_uint2(0u, 0u);
-          phf[it].y = (phf[it].y & 0xFFu) | (admit << 31) | (ok ? 0x40000000u : 0u);
+          const int src = pu * FU_C + it;
+          const uint32_t bn = (uint32_t)__shfl((int)my_bn, src), ia = (uint32_t)__shfl((int)my_ia, src), jd = (uint32_t)__shfl((int)my_jd, src);
+          const bool ok = (uint32_t)pe < (bn >> 16);
+          const uint32_t before = (uint32_t)__popc(bn & below);
+          const uint32_t admit = (bn >> pe) & 1u;
+          const uint32_t rec = admit ? ia + before : jd + ((uint32_t)pe - before);
+          prec[it] = ok ? rec : 0u;
+          pok |= (ok ? 1u : 0u) << it;
+          padmit |= admit << it;
         }
       }
+      // the loads of the row back to back and unconditional (lanes without an event read record 0): a predicated load
+      // into a register that an earlier load may still be writing makes the compiler wait for that load first, which
+      // would serialise the sixteen round trips
+      if (a.dbg & 4) return;
+#pragma unroll
+      for (int it = 0; it < FU_ITERS; it++) phf[it] = a.ix.rec_hf[prec[it]];
     };
     auto stage_c = [&](int row) __attribute__((always_inline)) {
-      if (row >= R_all) return;
-      T *out = ring + (size_t)(row & 1) * FU_C * 64 + (size_t)pe * 64 + pu;
+      if (row >= R_all || (a.dbg & 2)) return;
+      T *out = ring + (size_t)(row & 1) * FU_C * 64 + (size_t)pe * 64 + ubase + pu;
       const bool fill = row < R_fill;
+      const uint32_t k = (uint32_t)(row * FU_C + pe);
+      constexpr int HALF = FU_ITERS > 8 ? FU_ITERS / 2 : FU_ITERS;     // lookups in flight together
 #pragma unroll
-      for (int it = 0; it < FU_ITERS; it++) {
-        uint32_t ev = 0;
-        const uint32_t y = phf[it].y;
-        if (y & 0x40000000u) {
-          bool found;
-          const uint32_t base = rank_of(phf[it].x, found);
-          const int dsh = found ? RB : RB + 2;
-          if (fill) {
-            ev = base | (((y & 0x20000000u) ? 0u : 1u) << dsh);
-          } else if (y >> 31) {
-            // admit: after the drops of all records before the one active at its window position; carries the
-            // comparison; a no-op when linked to the previous record of the same hash
-            ev = base | (((y & FLAG_INS_LINKED) ? 0u : 1u) << dsh) | (1u << (RB + 5));
-          } else {
-            // drop at window position wpos[i+1], before the admit of that same position (FLAG_SAME_STEP), which then
-            // carries the comparison
-            const uint32_t same = (y & FLAG_SAME_STEP) ? 1u : 0u;
-            ev = base | (((y & FLAG_DEL_LINKED) ? 0u : 3u) << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5));
+      for (int hf = 0; hf < FU_ITERS / HALF; hf++) {
+        // ranks of HALF hashes at once.  rank = first rank of the bucket + the entries of the bucket below the hash: the
+        // bucket start, then FU_PROBE sketch entries read together (entries past the bucket are larger anyway, the
+        // sketch being sorted; past the sketch sit sentinels) -- two dependent LDS round trips, HALF of them in flight.
+        // Buckets wider than FU_PROBE (n_steps > 0, rare) get further probes, the same number in every lane.
+        int x[HALF];
+        bool eq[HALF];
+#pragma unroll
+        for (int q = 0; q < HALF; q++) x[q] = QT[bucket_of(phf[hf * HALF + q].x)];
+#pragma unroll
+        for (int q = 0; q < HALF; q++) {
+          const uint32_t h = phf[hf * HALF + q].x;
+          const uint32_t *e = Q + x[q];
+          uint32_t v[FU_PROBE];
+#pragma unroll
+          for (int j = 0; j < FU_PROBE; j++) v[j] = e[j];
+          int below = 0;
+          bool hit = false;
+#pragma unroll
+          for (int j = 0; j < FU_PROBE; j++) { below += v[j] < h ? 1 : 0; hit = hit || v[j] == h; }
+          x[q] += below; eq[q] = hit;
+        }
+        for (int stp = 0; stp < n_steps; stp++) {
+#pragma unroll
+          for (int q = 0; q < HALF; q++) {
+            // continues only where all FU_PROBE entries were below the hash (x advanced by a full probe each time)
+            const uint32_t h = phf[hf * HALF + q].x;
+            const uint32_t *e = Q + x[q];
+            // (where the previous probe stopped short, Q[x] >= h already and nothing changes)
+            int below = 0;
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < FU_PROBE; j++) { const uint32_t vj = e[j]; below += vj < h ? 1 : 0; hit = hit || vj == h; }
+            x[q] += below; eq[q] = eq[q] || hit;
           }
         }
-        out[it * FU_UPI] = (T)ev;
+#pragma unroll
+        for (int q = 0; q < HALF; q++) {
+          const int it = hf * HALF + q;
+          const uint32_t y_ = phf[it].y;
+          const bool found = eq[q] && x[q] < s;                        // (an equal entry at rank >= s is a sentinel)
+          const uint32_t base = (uint32_t)(x[q] + 1);
+          const int dsh = found ? RB : RB + 2;
+          const uint32_t dist = (y_ >> 8) & 0xFFFFu;
+          // fill: a no-op admit when the hash is already in the window (its previous occurrence lies at or after `beg`)
+          const uint32_t ev_fill = base | ((dist <= k ? 0u : 1u) << dsh);
+          // admit: after the drops of all records before the one active at its window position; carries the comparison;
+          // a no-op when linked to the previous record of the same hash
+          const uint32_t ev_admit = base | (((y_ & FLAG_INS_LINKED) ? 0u : 1u) << dsh) | (1u << (RB + 5));
+          // drop at window position wpos[i+1], before the admit of that same position (FLAG_SAME_STEP), which then
+          // carries the comparison
+          const uint32_t same = (y_ & FLAG_SAME_STEP) ? 1u : 0u;
+          const uint32_t ev_drop = base | (((y_ & FLAG_DEL_LINKED) ? 0u : 3u) << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5));
+          uint32_t ev = fill ? ev_fill : (((padmit >> it) & 1u) ? ev_admit : ev_drop);
+          ev = ((pok >> it) & 1u) ? ev : 0u;
+          out[it * FU_UPI] = (T)ev;
+        }
       }
     };
 
@@ -1651,17 +1738,21 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
     uint32_t overflow = 0;
     int rl = 0, F = 0, shared = 0, best = -1, beg = 0, opt_s = 0, opt_e = 0;
     if (wv == 0) {
-      beg = max(u_beg[lane], 0); opt_s = beg; opt_e = beg;
-      __builtin_amdgcn_s_setprio(2);
+      beg = my_beg; opt_s = beg; opt_e = beg;
     } else {
-      own_ia = u_e0[own] - (uint32_t)max(u_beg[own], 0);               // = end0: the records of the first window count as admitted
-      stage_a(0); stage_b(0); stage_a(1); stage_c(0); stage_b(1); stage_a(2);
+      own_beg = owner ? u_beg[own] : -1; own_e0 = u_e0[own]; own_nmain = u_nmain[own];
+      own_nfill = own_beg >= 0 ? own_e0 - 2u * (uint32_t)own_beg : 0u;  // e0 = beg + end0
+      own_ia = own_e0 - (uint32_t)max(own_beg, 0);                     // = end0: the records of the first window count as admitted
     }
-    __syncthreads();
+    __syncthreads();                                                   // the hand-over has been read: the ring is the ring again
+    if (wv != 0) { stage_a(0); stage_b(0); stage_a(1); stage_c(0); stage_b(1); stage_a(2); }
+    lds_barrier();
+    unsigned long long t_work = 0;                                     // FA_FUSED_DEBUG & 8: cycles between the barriers
     for (int row = 0; row < R_all; row++) {
+      const unsigned long long t_in = stamp ? __builtin_amdgcn_s_memtime() : 0ULL;
       if (wv != 0) {
         stage_c(row + 1); stage_b(row + 2); stage_a(row + 3);
-      } else {
+      } else if (!(a.dbg & 1)) {
         const T *in = ring + (size_t)(row & 1) * FU_C * 64 + lane;
         uint32_t word[FU_C];
 #pragma unroll
@@ -1733,10 +1824,11 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
           }
         }
       }
-      __syncthreads();
+      if (stamp) t_work += __builtin_amdgcn_s_memtime() - t_in;
+      lds_barrier();
     }
+    if (stamp && lane == 0) atomicAdd(&stamp[6 + (wv ? 1 : 0)], t_work);
     if (wv == 0) {
-      __builtin_amdgcn_s_setprio(0);
       if (my_locus >= 0) {
         const int32_t l = my_locus;
         if ((overflow >> SBITS) && !REDO) {
@@ -1752,6 +1844,7 @@ __global__ __launch_bounds__(FU_THREADS, 4) void k_l2_fused(L2Args a, int64_t n_
       }
     }
   }
+  if (stamp && tid == 0) { stamp[2] = __builtin_amdgcn_s_memrealtime(); atomicSub((unsigned int *)((unsigned long long *)a.items + (size_t)gridDim.x * 8), 1u); }
 }
 
 // ----------------------------------------------------------------------------------------------------------
