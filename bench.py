@@ -287,20 +287,31 @@ def boundary_call(args, mapper, query, timed_rows):
         hits = mapper.query_draft(contigs)
     n = max(args.steps, 1)
     split = np.zeros(16)
-    t0 = time.perf_counter()
+    per_call = []
+    # as `timeit` does, the cyclic garbage collector is off while timing: with torch imported a full collection walks about
+    # a million objects (12 ms, once every few calls of this loop) and has nothing to do with the call under test
+    import gc
+    gc_was_on = gc.isenabled()
+    gc.disable()
     for _ in range(n):
+        t0 = time.perf_counter()
         hits = mapper.query_draft(contigs)
+        per_call.append(time.perf_counter() - t0)
         ms = (C.c_float * 16)()
         lib.fa_mapper_last_timings(mapper._h, ms, 16)
         split += np.array(list(ms))
-    dt = (time.perf_counter() - t0) / n
+    if gc_was_on:
+        gc.enable()
+    dt = float(np.mean(per_call))                  # the mean: what a caller issuing calls back to back sees
     split /= n
     # the hits must be the rows of the timed steps, filtered and sorted (same query, same index)
     want = mapper._rows_to_hits([_Row(r) for r in timed_rows[-1]], sum(len(c) for c in contigs)) if timed_rows else None
     same = want is not None and [(h.name, h.identity, h.matches, h.fragments) for h in hits] == [(h.name, h.identity, h.matches, h.fragments) for h in want]
     native = float(split[10] + split[11] + split[12] + split[13])
     return {"call": "Mapper.query_draft(host bytes) -> list[Hit]", "ms_per_call": dt * 1e3, "value": args.refs / dt, "unit": "pairs/s",
-            "calls": n, "hits": len(hits), "hits_match_timed_rows": bool(same),
+            "calls": n, "ms_min_median_max": [1e3 * min(per_call), 1e3 * float(np.median(per_call)), 1e3 * max(per_call)],
+            "slowest_call_index": int(np.argmax(per_call)),
+            "hits": len(hits), "hits_match_timed_rows": bool(same),
             "split_ms": {"host_pack": float(split[10]), "fragment_tile_tables": float(split[11]), "h2d_upload": float(split[12]),
                          "device_pass_and_rows_d2h": float(split[13]), "device_pass_events": float(split[4]),
                          "python_binding_and_hits": dt * 1e3 - native}}

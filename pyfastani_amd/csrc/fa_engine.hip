@@ -1,7 +1,9 @@
 // fa_engine.hip -- host side of libfastani_hip.so: owns the HIP stream and all HBM allocations, drives the
 // kernels of fa_sketch.hip.h / fa_map.hip.h, and exports the C ABI declared in include/fastani_hip.h.
 // There is no CPU fallback anywhere in this file: without a HIP device every compute entry point fails.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -137,11 +139,12 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   FA_HIP(hipGetLastError());
 }
 
-static void exclusive_sum_i32(DevBuf<unsigned char> &temp, const int32_t *in, int32_t *out, int n, hipStream_t st) {
+// rocPRIM directly (device-wide scan / radix sort / run-length encode; sizes are size_t)
+static void exclusive_sum_i32(DevBuf<unsigned char> &temp, const int32_t *in, int32_t *out, size_t n, hipStream_t st) {
   size_t bytes = 0;
-  FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, n, st));
+  FA_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), st));
   temp.ensure(bytes + 16);
-  FA_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, in, out, n, st));
+  FA_HIP(rocprim::exclusive_scan(temp.p, bytes, in, out, (int32_t)0, n, rocprim::plus<int32_t>(), st));
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -411,7 +414,9 @@ static bool fused_l2_enabled() {
 static void build_index(fa_mapper &m) {
   hipStream_t st = m.stream;
   const int64_t N = m.N;
-  FA_REQUIRE(N < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "more than 2^31 minimizers in one index");
+  // record numbers are 32-bit throughout the mapping kernels (a seed hit IS a record number): 2^31 minimizers, about 5 000
+  // genomes of 5 Mb, per index -- beyond that shard the references (sharding.build_ref_sharded_mapper)
+  FA_REQUIRE(N < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "more than 2^31 minimizers in one index (shard the references)");
   m.C = m.seqs_by_file.empty() ? 0 : m.seqs_by_file.back();
   m.G = (int32_t)m.seqs_by_file.size();
   // minimizer windows per fragment.  When it is <= 0 no fragment holds a window, query sketches are empty and L2 never
@@ -467,15 +472,15 @@ static void build_index(fa_mapper &m) {
     tr.mark("alloc", st);
     hipLaunchKernelGGL(k_iota, dim3(ceil_div(N, 256)), dim3(256), 0, st, iota.p, N);
     size_t bytes = 0;
-    FA_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (int)N, 0, 32, st));
+    FA_HIP(rocprim::radix_sort_pairs(nullptr, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (size_t)N, 0u, 32u, st));
     temp.ensure(bytes + 16);
-    FA_HIP(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (int)N, 0, 32, st));
+    FA_HIP(rocprim::radix_sort_pairs(temp.p, bytes, m.rec_hash.p, sorted_hash.p, iota.p, m.pos_ridx.p, (size_t)N, 0u, 32u, st));
     tr.mark("sort", st);
     m.uniq_hash.ensure((size_t)N + 1);
     bytes = 0;
-    FA_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, sorted_hash.p, m.uniq_hash.p, counts.p, num_runs.p, (int)N, st));
+    FA_HIP(rocprim::run_length_encode(nullptr, bytes, sorted_hash.p, (size_t)N, m.uniq_hash.p, counts.p, num_runs.p, st));
     temp.ensure(bytes + 16);
-    FA_HIP(hipcub::DeviceRunLengthEncode::Encode(temp.p, bytes, sorted_hash.p, m.uniq_hash.p, counts.p, num_runs.p, (int)N, st));
+    FA_HIP(rocprim::run_length_encode(temp.p, bytes, sorted_hash.p, (size_t)N, m.uniq_hash.p, counts.p, num_runs.p, st));
     int32_t U = 0;
     num_runs.download(&U, 1, st);
     FA_HIP(hipStreamSynchronize(st));
@@ -483,18 +488,18 @@ static void build_index(fa_mapper &m) {
     FA_HIP(hipMemsetAsync(counts.p + U, 0, sizeof(uint32_t), st));
     m.uniq_off.ensure((size_t)U + 2);
     bytes = 0;
-    FA_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, counts.p, m.uniq_off.p, U + 1, st));
+    FA_HIP(rocprim::exclusive_scan(nullptr, bytes, counts.p, m.uniq_off.p, 0u, (size_t)U + 1, rocprim::plus<uint32_t>(), st));
     temp.ensure(bytes + 16);
-    FA_HIP(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, counts.p, m.uniq_off.p, U + 1, st));
+    FA_HIP(rocprim::exclusive_scan(temp.p, bytes, counts.p, m.uniq_off.p, 0u, (size_t)U + 1, rocprim::plus<uint32_t>(), st));
     tr.mark("rle_scan", st);
     // frequency threshold (computeFreqHist): walk the distinct list lengths from the most frequent down
     int64_t to_ignore = (int64_t)((float)(int64_t)U * 0.001f / 100);
     int64_t M = std::min<int64_t>(U, to_ignore + 1);
     counts_sorted.ensure((size_t)U);
     bytes = 0;
-    FA_HIP(hipcub::DeviceRadixSort::SortKeysDescending(nullptr, bytes, counts.p, counts_sorted.p, U, 0, 32, st));
+    FA_HIP(rocprim::radix_sort_keys_desc(nullptr, bytes, counts.p, counts_sorted.p, (size_t)U, 0u, 32u, st));
     temp.ensure(bytes + 16);
-    FA_HIP(hipcub::DeviceRadixSort::SortKeysDescending(temp.p, bytes, counts.p, counts_sorted.p, U, 0, 32, st));
+    FA_HIP(rocprim::radix_sort_keys_desc(temp.p, bytes, counts.p, counts_sorted.p, (size_t)U, 0u, 32u, st));
     std::vector<uint32_t> top((size_t)M);
     counts_sorted.download(top.data(), (size_t)M, st);
     FA_HIP(hipStreamSynchronize(st));
@@ -818,7 +823,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
       a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
-      const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
+      const size_t ev_lds = ((size_t)(smax + EV_PROBE) * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
       FA_REQUIRE(ev_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
       // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
       auto scan_lds = [&](int ln, int bytes) { return ((size_t)(a.cnt_slots + 1) * ln * bytes + 15) / 16 * 16; };

@@ -1004,6 +1004,17 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         got = [hit_tuples(h) for h in m1.upload_fasta(files).query()]
         want = [hit_tuples(m2.query_draft([r.seq for r in Parser(path)])) for path in files]
     assert got == want and all(len(w) == 3 for w in want)
+    # ... and against the ORACLE fed by a plain-Python reader of the same files (no native code on that side): the records
+    # the native ingest produces, the sketch built from them and the hits of every file used as a query
+    osk = OracleSketch()
+    for i, path in enumerate(files):
+        osk.add_draft(i, read_fasta(path))
+    for x, y in zip(a, osk.minimizers()):
+        assert np.array_equal(x, y)
+    osk.index()
+    for path, hits in zip(files, got):
+        assert hits == osk.query_draft(read_fasta(path), threads=2)
+    assert [r.seq for r in Parser(files[0])] == [c.upper().encode() for c in read_fasta(files[0])]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert hit_tuples(m1.query_fasta(files[1])) == want[1]
@@ -1011,6 +1022,53 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         pf.Sketch().add_fasta("x", files[0])                 # the 6-base contig is reported like add_draft does
     with pytest.raises(OSError):
         pf.Sketch().add_fasta("x", str(tmp_path / "missing.fna"))
+
+
+def test_fastani_style_outputs_from_device_rows(tmp_path):
+    """the identity matrix / hit list of an all-vs-all run built from the rows the DEVICE returns, against
+    the same outputs built from the ORACLE's rows (per-pair CGI results of every query)."""
+    from pyfastani_amd import outputs
+    from pyfastani_amd._batch import ROW_DTYPE
+    g = syn.rng(654)
+    genomes, names = [], []
+    for fam in range(2):
+        anc = syn.random_codes(g, 150_000)
+        for d in (0.0, 0.03, 0.08, 0.14):
+            genomes.append([syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc)])
+            names.append(f"f{fam}_d{d}")
+    sk, osk = pf.Sketch(), OracleSketch()
+    for n, c in zip(names, genomes):
+        sk.add_draft(n, c)
+        osk.add_draft(n, c)
+    mapper = sk.index()
+    osk.index()
+    rows = mapper.upload_genomes(genomes).query_rows()
+    want = []
+    for q, c in enumerate(genomes):
+        _, det = osk.query_draft(c, threads=2, details=True)
+        r = det["rows"]
+        want += [(q, int(gi), int(cnt), int(det["total_fragments"]), float(ident)) for gi, ident, cnt in zip(r["genome"], r["identity"], r["count"])]
+    want = np.array(want, dtype=ROW_DTYPE)
+    assert rows.tobytes() == want.tobytes()
+    lengths = [sum((len(x) // 3000) * 3000 for x in c) for c in genomes]
+    qlen = [sum(len(x) for x in c) for c in genomes]
+    kept, okept = outputs.filter_rows(rows, qlen, lengths, 3000, 0.2), outputs.filter_rows(want, qlen, lengths, 3000, 0.2)
+    m, om = outputs.identity_matrix(kept, 8, 8, symmetric=True), outputs.identity_matrix(okept, 8, 8, symmetric=True)
+    assert np.array_equal(np.isnan(m), np.isnan(om)) and np.array_equal(m[~np.isnan(m)], om[~np.isnan(om)])
+    # (a self mapping is 100.0 up to the end-of-contig effect the oracle shows too: the slide stops when the last record of
+    # the contig is admitted, so the fragment that ends exactly at the contig end can miss one minimizer)
+    assert np.all(np.diag(m) >= 99.999) and np.isnan(m[0, 4]) and m[0, 1] > 95.0     # families do not mix
+    outputs.write_matrix(str(tmp_path / "gpu.matrix"), names, m)
+    outputs.write_matrix(str(tmp_path / "cpu.matrix"), names, om)
+    outputs.write_hits(str(tmp_path / "gpu.tsv"), names, names, kept)
+    outputs.write_hits(str(tmp_path / "cpu.tsv"), names, names, okept)
+    assert (tmp_path / "gpu.matrix").read_text() == (tmp_path / "cpu.matrix").read_text()
+    assert (tmp_path / "gpu.tsv").read_text() == (tmp_path / "cpu.tsv").read_text()
+    # the hit list a user gets per query is the filtered table, best identity first
+    per_query = [hit_tuples(h) for h in mapper.upload_genomes(genomes).query()]
+    for q in range(8):
+        mine = kept[kept["query_id"] == q]
+        assert sorted((names[r["ref_genome_id"]], float(r["identity"])) for r in mine) == sorted((n, i) for n, i, _, _ in per_query[q])
 
 
 def test_concurrent_queries_on_one_mapper():

@@ -1,0 +1,105 @@
+"""The multi-GPU layer on real devices.  The RCCL tests need two GPUs (`nccl` backend, one rank per GPU) and skip on the
+one-GPU boxes; the strong-scaling mode of bench.py is also run on ONE GPU (N = 1, and two ranks sharing the device over
+gloo) so that its code path is exercised by the driver-run suite."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(script_or_args, n, env=None, timeout=1200):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + list(script_or_args)
+    e = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    e.update(env or {})
+    return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+STRONG_SMALL = ["--strong", "--families", "2", "--members", "5", "--length", "300000", "--steps", "2", "--warmup", "1"]
+
+
+def _check_strong_line(out, n_gpus):
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == n_gpus and line["unit"] == "pairs/s"
+    assert line["config"]["pairs_per_step"] == 100 and line["config"]["self_rows_exact"] is True
+    assert len(line["config"]["fragments_per_rank"]) == n_gpus and sum(line["config"]["fragments_per_rank"]) == 10 * 100
+    assert line["value"] > 0 and line["steps"] == 2
+    return line
+
+
+def test_bench_strong_one_gpu():
+    """bench.py --strong at N = 1: config 3 in miniature, every genome hits itself at exactly 100.0."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + STRONG_SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout + res.stderr
+    _check_strong_line(res.stdout, 1)
+
+
+def test_bench_strong_two_ranks_sharing_one_gpu():
+    """The N = 2 strong-scaling path (queries dealt by fragment count, sketch shards and hit tables exchanged) with both
+    ranks on GPU 0 and gloo as the transport (RCCL refuses two ranks on one device)."""
+    res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2"] + STRONG_SMALL, 2, env={"FA_BENCH_SHARE_GPU": "1"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = _check_strong_line(res.stdout, 2)
+    assert "sharded sketching x2" in line["config"]["index_build"]
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")
+def test_bench_strong_rccl_two_gpus():
+    res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2"] + STRONG_SMALL, 2)
+    assert res.returncode == 0, res.stdout + res.stderr
+    _check_strong_line(res.stdout, 2)
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")
+def test_rccl_index_and_hit_table_two_gpus(tmp_path):
+    """Sketch shards all-gathered over RCCL into the replicated index, queries dealt by fragment count, hit tables
+    all-gathered over RCCL: the table every rank ends up with is the one a single process computes."""
+    code = textwrap.dedent("""
+        import os, sys, warnings
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        rank = int(os.environ["LOCAL_RANK"])
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", rank))
+        import pyfastani_amd as pf
+        from pyfastani_amd import sharding, workloads
+        pf.set_device(rank)
+        genomes, fam = workloads.families(77, 2, 4, 200_000, contigs=3)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = pf.Sketch()
+            for i, c in enumerate(genomes):
+                sk.add_draft(i, c)
+            direct = sk.index()
+            want = sharding.all_vs_all(direct, genomes, 0, 1)
+            m = sharding.build_index_sharded(genomes, rank=rank, world_size=2, device="cuda")
+            assert len(m.minimizers) == len(direct.minimizers) and m.occurences_threshold == direct.occurences_threshold
+            got = sharding.all_vs_all(m, genomes, rank, 2, device="cuda")
+        assert got.tobytes() == want.tobytes(), (rank, len(got), len(want))
+        dist.barrier(); dist.destroy_process_group()
+        open(os.path.join(%r, f"rccl{rank}.ok"), "w").write(str(len(got)))
+    """ % (ROOT, str(tmp_path)))
+    script = tmp_path / "worker.py"
+    script.write_text(code)
+    res = _run_ranks([str(script)], 2)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "rccl0.ok").read_text() == (tmp_path / "rccl1.ok").read_text()
