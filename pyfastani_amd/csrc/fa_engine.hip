@@ -823,7 +823,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
       a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
-      const size_t ev_lds = ((size_t)(smax + EV_PROBE) * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
+      const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
       FA_REQUIRE(ev_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
       // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
       auto scan_lds = [&](int ln, int bytes) { return ((size_t)(a.cnt_slots + 1) * ln * bytes + 15) / 16 * 16; };
@@ -1303,23 +1303,34 @@ int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int6
     read_fasta_records(path, seqs);
     std::lock_guard<std::mutex> lock(s->mtx);
     bind_device(s->device);
+    // everything is validated and staged in locals first and committed only after the packer has succeeded: a record that
+    // is refused, or an allocation failure half-way, leaves the sketch exactly as it was (the reference keeps `total` in a
+    // local for the same reason, _fastani.pyx:618,680)
     std::vector<const void *> ptrs;
     std::vector<int64_t> lens;
-    int64_t shorts = 0;
+    std::vector<int32_t> contig_ids;
+    int64_t shorts = 0, counter = s->counter;
+    uint64_t total = 0;
     for (auto &q : seqs) {
       const int64_t length = (int64_t)q.size;
       FA_REQUIRE(length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
       if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
         ptrs.push_back(q.data.get()); lens.push_back(length);
-        s->pending_contig.push_back((int32_t)s->counter);
+        contig_ids.push_back((int32_t)counter);
       } else {
         shorts++;
       }
-      s->cur_total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
-      s->counter += 1;                                                                     // :683
+      total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
+      counter += 1;                                                                // :683
     }
+    s->pending_contig.reserve(s->pending_contig.size() + contig_ids.size());
+    s->lengths.reserve(s->lengths.size() + 1);
+    s->seqs_by_file.reserve(s->seqs_by_file.size() + 1);
     if (!ptrs.empty()) s->pending.append_many(ptrs.data(), lens.data(), (int64_t)ptrs.size(), 1);
-    s->lengths.push_back(s->cur_total);                  // :687
+    // commit (nothing below can throw: the vectors have room)
+    s->pending_contig.insert(s->pending_contig.end(), contig_ids.begin(), contig_ids.end());
+    s->counter = counter;
+    s->lengths.push_back(s->cur_total + total);          // :687
     s->cur_total = 0;
     s->seqs_by_file.push_back((int32_t)s->counter);      // :690
     if (n_records) *n_records = (int64_t)seqs.size();

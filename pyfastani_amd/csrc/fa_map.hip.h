@@ -1110,7 +1110,6 @@ struct L2Args {
 
 constexpr int L2_THREADS = 64;
 constexpr int EV_THREADS = 256;
-constexpr int EV_PROBE = 4;        // sketch entries compared at once per rank lookup of k_l2_events
 
 // Event word: slot (= query rank + 1; 0 is the padding no-op) | dM:2 | dW:2 | drop | eval, where dM / dW are two's
 // complement -1 / 0 / +1: the change of the matched bit of that rank, resp. of its count of window-only hashes.  A
@@ -1122,17 +1121,16 @@ template <> struct EvBits<uint32_t> { static constexpr int RANK = 24; };
 template <typename T, bool PACKED>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  uint32_t *Q = (uint32_t *)lds;                                     // [smax + EV_PROBE], staged once per fragment (+ sentinels)
+  uint32_t *Q = (uint32_t *)lds;                                     // [smax], staged once per fragment
   constexpr int QT_BITS = 10;                                        // bucket table resolution
   __shared__ uint16_t QT[(1 << QT_BITS) + 2];
-  __shared__ int sh_steps;
   const int f = blockIdx.x;
   const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
   if (l_n == 0) return;
   const int s = a.q_size[f];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (a.counters[2] || s > a.cnt_slots - 1) return;                  // loci overflowed / sketch larger than speculated: void pass
-  for (int i = threadIdx.x; i < s + EV_PROBE; i += EV_THREADS) Q[i] = i < s ? a.q_hash[(size_t)f * a.qcap + i] : 0xFFFFFFFFu;
+  for (int i = threadIdx.x; i < s; i += EV_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
   // ---- record range of every locus (the three searchIndex calls of computeL2MappedRegions) and its event count ----
   __shared__ uint32_t sh_wave[EV_THREADS / 64];
   __shared__ uint32_t sh_run, sh_base, sh_ok;
@@ -1185,37 +1183,19 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     atomicAdd(a.rec_total, sh_records);
   }
   __syncthreads();
-  // Bucket table for the rank lookups.  Minimizer hashes are window minima: their density falls off exponentially from 0
-  // (a bucket table over the hash value itself left a dozen sketch entries in the first buckets and none in the last).
-  // The buckets are therefore laid over 1 - 2^(-c h) -- monotone in h, one v_exp_f32 -- with c set by the largest query
-  // hash: about s / 1024 entries per bucket everywhere.  QT[b] = first query rank whose bucket is >= b.  A lookup is the
-  // bucket start plus the entries of the bucket below the hash: EV_PROBE sketch entries read together (the sketch is
-  // sorted, entries past the bucket are larger anyway, past the sketch sit sentinels), i.e. two dependent LDS round trips
-  // and no data-dependent loop.  Buckets wider than EV_PROBE (sh_steps > 0, rare) get further probes, wave-uniformly.
+  // Bucket table over the hash range the query sketch actually spans: minimizer hashes are window minima, i.e. heavily
+  // skewed towards 0, so the buckets divide [0, 2^bits) with 2^bits > the largest query hash rather than the full 32-bit
+  // range.  QT[b] = first query rank whose hash is >= b << qshift; a reference hash beyond the range ranks after all.
   const uint32_t hmax = s > 0 ? Q[s - 1] : 0u;
-  const float bscale = -8.0f / (float)max(hmax, 1u);
-  auto bucket_of = [&](uint32_t h) __attribute__((always_inline)) {
-    const float t = __builtin_amdgcn_exp2f((float)h * bscale);
-    return (uint32_t)min((float)((1 << QT_BITS) - 1), (float)(1 << QT_BITS) - (float)(1 << QT_BITS) * t);
-  };
-  if (threadIdx.x == 0) sh_steps = 0;
-  for (int b = threadIdx.x; b <= (1 << QT_BITS) + 1; b += EV_THREADS) QT[b] = (uint16_t)s;
-  __syncthreads();
-  for (int i = threadIdx.x; i < s; i += EV_THREADS) {
-    // rank i opens every bucket in (bucket of rank i-1, bucket of rank i]
-    const uint32_t bi = bucket_of(Q[i]);
-    uint32_t b = i > 0 ? bucket_of(Q[i - 1]) + 1 : 0u;
-    for (; b <= bi; b++) QT[b] = (uint16_t)i;
+  const int qshift = max(0, (32 - __clz((int)(hmax | 1u))) - QT_BITS);   // hmax < 2^(qshift + QT_BITS)
+  for (int b = threadIdx.x; b <= (1 << QT_BITS); b += EV_THREADS) {
+    int x = 0, y = s;
+    const uint64_t key = (uint64_t)b << qshift;
+    while (x < y) { int mid = (x + y) >> 1; if ((uint64_t)Q[mid] < key) x = mid + 1; else y = mid; }
+    QT[b] = (uint16_t)x;
   }
+  if (threadIdx.x == 0) QT[(1 << QT_BITS) + 1] = (uint16_t)s;
   __syncthreads();
-  {
-    int width = 0;
-    for (int b = threadIdx.x; b < (1 << QT_BITS); b += EV_THREADS) width = max(width, (int)QT[b + 1] - (int)QT[b]);
-    for (int d = 32; d > 0; d >>= 1) width = max(width, __shfl_xor(width, d));
-    if (lane == 0 && width > EV_PROBE) atomicMax(&sh_steps, (width - 1) / EV_PROBE);
-  }
-  __syncthreads();
-  const int n_steps = sh_steps;
   if (!sh_ok) {                                                      // the event buffer is too small: void pass
     for (uint32_t i = threadIdx.x; i < l_n; i += EV_THREADS) a.l_nev[l_lo + i] = 0;
     return;
@@ -1233,20 +1213,14 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     // events land at scattered 2-byte positions: build the stream of a locus in LDS and stream it out in 16-byte
     // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
     const bool staged = padded <= (uint32_t)a.ev_stage;
-    T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1 + EV_PROBE) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
+    T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
     for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)0;
     if (lane < n_init_pad - n_init) out[n_init + lane] = (T)0;
     auto emit = [&](int i, uint32_t h, uint32_t rf, bool prev_in, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
-      int x = QT[bucket_of(h)];
-      bool hit = false;
-      for (int stp = 0; stp <= n_steps; stp++) {                          // (one pass unless a bucket holds more than EV_PROBE entries)
-        const uint32_t *e = Q + x;
-        int below = 0;
-#pragma unroll
-        for (int j = 0; j < EV_PROBE; j++) { const uint32_t vj = e[j]; below += vj < h ? 1 : 0; hit = hit || vj == h; }
-        x += below;
-      }
-      const bool found = hit && x < s;                                    // (an equal entry at rank >= s is a sentinel)
+      const uint32_t qb = min(h >> qshift, (uint32_t)(1 << QT_BITS));     // the last bucket is [2^bits, inf): rank s
+      int x = QT[qb], y = QT[qb + 1];
+      while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
+      const bool found = x < s && Q[x] == h;
       constexpr int RB = EvBits<T>::RANK;
       // both events carry slot = rank + 1 and ONE signed delta: of the matched bit (field at RB) when the hash is in the
       // query sketch, of the window-only count (field at RB + 2) otherwise; branch-free apart from the store predicates

@@ -235,16 +235,23 @@ struct HostStore {
     // geometric: an exact reserve on every call would copy the whole store once per added contig)
     const size_t add = (size_t)padded_bases(lens, n);
     auto grow = [](auto &v, size_t need) { if (need > v.capacity()) v.reserve(std::max(need, v.capacity() * 2)); };
-    if (protein) {
-      const size_t base = bytes.size();
-      grow(bytes, base + add);
-      bytes.resize(base + add, 0);
-      pack_many(datas, lens, n, width, nullptr, bytes.data() + base);
-    } else {
-      const size_t base = packed.size();
-      grow(packed, base + add / 16);
-      packed.resize(base + add / 16, 0u);
-      pack_many(datas, lens, n, width, packed.data() + base, nullptr);
+    // all or nothing: a failure half-way (an allocation while collecting exceptions, say) leaves the store as it was
+    const size_t o_packed = packed.size(), o_bytes = bytes.size(), o_seq = seq_off.size(), o_exc = exc_pos.size();
+    const int64_t o_total = total;
+    try {
+      if (protein) {
+        grow(bytes, o_bytes + add);
+        bytes.resize(o_bytes + add, 0);
+        pack_many(datas, lens, n, width, nullptr, bytes.data() + o_bytes);
+      } else {
+        grow(packed, o_packed + add / 16);
+        packed.resize(o_packed + add / 16, 0u);
+        pack_many(datas, lens, n, width, packed.data() + o_packed, nullptr);
+      }
+    } catch (...) {
+      packed.resize(o_packed); bytes.resize(o_bytes); seq_off.resize(o_seq); seq_len.resize(o_seq);
+      exc_pos.resize(o_exc); exc_val.resize(o_exc); total = o_total;
+      throw;
     }
   }
 
