@@ -502,7 +502,9 @@ def strong_scaling(ctx):
                    "pairs_per_step": n * n, "rows_per_step": int(len(rows)), "parallelism": f"queries sharded by fragment count x{world}, index replicated",
                    "fragments_per_rank": [int(sum(weights[i] for i in o)) for o in sharding.shard_by_fragments(weights, world)],
                    "index_minimizers": len(mapper.minimizers), "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack,
-                   "generate_s": t_gen, "self_rows_exact": bool(len(self_rows) == n and np.all(self_rows["identity"] == 100.0)), "head": git_head()},
+                   "generate_s": t_gen, # (exactly 100.0 except for the end-of-contig effect the oracle shows too: the fragment that ends at the contig end)
+                   "self_rows_ok": bool(len(self_rows) == n and np.all(self_rows["identity"] >= 99.999)),
+                   "self_rows_exactly_100": int(np.sum(self_rows["identity"] == 100.0)), "head": git_head()},
     }
 
 

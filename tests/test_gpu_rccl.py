@@ -40,7 +40,7 @@ STRONG_SMALL = ["--strong", "--families", "2", "--members", "5", "--length", "30
 def _check_strong_line(out, n_gpus):
     line = json.loads(out.strip().splitlines()[-1])
     assert line["scaling"] == "strong" and line["n_gpus"] == n_gpus and line["unit"] == "pairs/s"
-    assert line["config"]["pairs_per_step"] == 100 and line["config"]["self_rows_exact"] is True
+    assert line["config"]["pairs_per_step"] == 100 and line["config"]["self_rows_ok"] is True
     assert len(line["config"]["fragments_per_rank"]) == n_gpus and sum(line["config"]["fragments_per_rank"]) == 10 * 100
     assert line["value"] > 0 and line["steps"] == 2
     return line
