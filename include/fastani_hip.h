@@ -206,6 +206,8 @@ int fa_debug_probe_occupancy(int lds_bytes, int *peak_alive);
 /* raw bytes of the last call's event arena (two-kernel L2 form: the slide events; FA_FUSED_DEBUG=8: per-workgroup time
  * stamps of k_l2_fused) -- development aid */
 int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes);
+/* slide events per L2 locus of the last call (two-kernel form), in locus order -- development aid */
+int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, int64_t *n);
 /* last-call statistics: [0] sketch ms (K1 + fragment sort/unique), [1] lookup + L1 ms, [2] L2 ms, [3] CGI ms,
  * [4] total ms -- measured with HIP events on the library's stream -- then counters of the call:
  * [5] reference records inside L2 locus ranges, [6] L2 loci, [7] L2 slide events, [8] loci redone with the wide

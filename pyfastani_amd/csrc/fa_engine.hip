@@ -724,7 +724,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     w.l_beg.ensure((size_t)l_cap); w.l_end0.ensure((size_t)l_cap); w.l_last.ensure((size_t)l_cap); w.l_ndrop.ensure((size_t)l_cap);
     w.l_nev.ensure((size_t)l_cap); w.l_ioff.ensure((size_t)l_cap); w.l_redo.ensure((size_t)l_cap + 4);
     w.ovf_buf.ensure((size_t)sp.scratch_words + 4);
-    const bool wide = smax > 1022;                                      // slot = rank + 1 must fit the 10-bit field
+    const bool wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
     w.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
 
     FA_HIP(hipEventRecord(w.ev[0], st));
@@ -1745,6 +1745,16 @@ int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes) {
     Workspace &w = m->ws[m->last_ws];
     FA_REQUIRE(bytes >= 0 && (size_t)bytes <= w.items.cap, FA_ERR_INVALID, "more bytes than the event arena holds");
     FA_HIP(hipMemcpy(out, w.items.p, (size_t)bytes, hipMemcpyDeviceToHost));
+  });
+}
+int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, int64_t *n) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
+    Workspace &w = m->ws[m->last_ws];
+    *n = w.last_loci;
+    const size_t c = (size_t)std::min<int64_t>(w.last_loci, cap);
+    if (c) { w.l_nev.download(events, c, w.stream); FA_HIP(hipStreamSynchronize(w.stream)); }
   });
 }
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {

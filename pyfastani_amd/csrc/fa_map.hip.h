@@ -1111,12 +1111,19 @@ struct L2Args {
 constexpr int L2_THREADS = 64;
 constexpr int EV_THREADS = 256;
 
-// Event word: slot (= query rank + 1; 0 is the padding no-op) | dM:2 | dW:2 | drop | eval, where dM / dW are two's
-// complement -1 / 0 / +1: the change of the matched bit of that rank, resp. of its count of window-only hashes.  A
-// record whose admit / drop is a no-op by the duplicate-linking rule carries dM = dW = 0 but keeps drop / eval.
+// Event word, from the low end: dM:2 | dW:2 | spare | drop | slot (= query rank + 1; 0 is the padding no-op) | no-eval
+// (the top bit), where dM / dW are two's complement -1 / 0 / +1: the change of the matched bit of that rank, resp. of
+// its count of window-only hashes.  A record whose admit / drop is a no-op by the duplicate-linking rule carries
+// dM = dW = 0 but keeps drop / no-eval.  The layout is chosen for the slide (k_l2_scan): the slot field sits at bit 6,
+// so with 64 one-byte lanes per slot row the masked event IS the row's LDS offset, and a set top bit turns the shared
+// count of an event that carries no comparison into a negative number instead of costing a select.
 template <typename T> struct EvBits;
-template <> struct EvBits<uint16_t> { static constexpr int RANK = 10; };   // sketches up to 1022 minimizers
+template <> struct EvBits<uint16_t> { static constexpr int RANK = 9; };    // sketches up to 510 minimizers
 template <> struct EvBits<uint32_t> { static constexpr int RANK = 24; };
+constexpr int EV_DM = 0, EV_DW = 2, EV_DROP = 5, EV_SLOT = 6;
+template <typename T> constexpr uint32_t ev_noeval() { return 1u << (8 * sizeof(T) - 1); }
+template <typename T> constexpr uint32_t ev_slot_mask() { return ((1u << EvBits<T>::RANK) - 1u) << EV_SLOT; }
+static_assert(EV_SLOT + EvBits<uint16_t>::RANK == 15 && EV_SLOT + EvBits<uint32_t>::RANK <= 31, "event fields overlap");
 
 template <typename T, bool PACKED>
 __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
@@ -1214,33 +1221,32 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
     const bool staged = padded <= (uint32_t)a.ev_stage;
     T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
-    for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)0;
-    if (lane < n_init_pad - n_init) out[n_init + lane] = (T)0;
+    for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)ev_noeval<T>();      // padding: slot 0, no comparison
+    if (lane < n_init_pad - n_init) out[n_init + lane] = (T)ev_noeval<T>();
     auto emit = [&](int i, uint32_t h, uint32_t rf, bool prev_in, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
       const uint32_t qb = min(h >> qshift, (uint32_t)(1 << QT_BITS));     // the last bucket is [2^bits, inf): rank s
       int x = QT[qb], y = QT[qb + 1];
       while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
       const bool found = x < s && Q[x] == h;
-      constexpr int RB = EvBits<T>::RANK;
-      // both events carry slot = rank + 1 and ONE signed delta: of the matched bit (field at RB) when the hash is in the
-      // query sketch, of the window-only count (field at RB + 2) otherwise; branch-free apart from the store predicates
-      const uint32_t base = (uint32_t)(x + 1);
-      const int dsh = found ? RB : RB + 2;
+      // both events carry slot = rank + 1 and ONE signed delta: of the matched bit when the hash is in the query sketch,
+      // of the window-only count otherwise; branch-free apart from the store predicates
+      const uint32_t base = (uint32_t)(x + 1) << EV_SLOT;
+      const int dsh = found ? EV_DM : EV_DW;
       const bool first = i < end0;
       // admit.  First super-window: inserted in record order, compared once after the last one, a no-op when the hash
       // is already in the window (prev_in).  Later: after the drops of all records before the one active at its window
       // position (rec_bwd), a no-op when linked to the previous record of the same hash.
       const uint32_t on = first ? (prev_in ? 0u : 1u) : ((rf & FLAG_INS_LINKED) ? 0u : 1u);
-      const uint32_t evl1 = first ? (i == end0 - 1 ? 1u : 0u) : 1u;
+      const uint32_t noev1 = first ? (i == end0 - 1 ? 0u : ev_noeval<T>()) : 0u;
       const uint32_t pos1 = first ? (uint32_t)(i - beg) : (uint32_t)(n_init_pad + (i - end0) + (bwd - beg));
-      out[pos1] = (T)(base | (on << dsh) | (evl1 << (RB + 5)));
+      out[pos1] = (T)(base | (on << dsh) | noev1);
       if (i - beg < ndrop) {
         // dropped at window position wpos[i+1], after the admits of earlier positions and before the admit of
         // that same position (FLAG_SAME_STEP), which then carries the comparison
         const uint32_t same = (rf & FLAG_SAME_STEP) ? 1u : 0u;
         const uint32_t pos2 = (uint32_t)(n_init_pad + (i - beg) + (fwd1 - (int)same - end0));
         const uint32_t off = (rf & FLAG_DEL_LINKED) ? 0u : 3u;          // -1 in the two-bit field
-        out[pos2] = (T)(base | (off << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5)));
+        out[pos2] = (T)(base | (off << dsh) | (1u << EV_DROP) | (same ? ev_noeval<T>() : 0u));
       }
     };
     // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
@@ -1288,21 +1294,124 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   }
 }
 
-// State of one lane: ST[r] = number of distinct window-only hashes of insertion rank r << 1 | (query rank r currently
-// matched).  ST is uint8 on the fast path (one byte per rank keeps 8 waves per CU resident); a count that reaches 128
-// carries out of the byte (seen in the 32-bit value before it is stored), the lane flags its locus and the uint16
-// instantiation redoes it (l_redo).  The array is shifted by one slot so that the boundary rank r*-1 needs no clamp
-// when r* = 0.  LNT = lanes per workgroup at compile time (64) or 0 for the run-time value used when a huge sketch
-// forces fewer lanes per workgroup.
+// State of one lane: ST[r] = (1 + number of distinct window-only hashes of insertion rank r) << 1 | (query rank r
+// currently matched).  ST is uint8 on the fast path (one byte per rank keeps 8 waves per CU resident); a count that
+// leaves the byte carries out of it (seen in the 32-bit value before it is stored), the lane flags its locus and the
+// uint16 instantiation redoes it (l_redo).  The array is shifted by one slot so that the boundary rank r*-1 needs no
+// clamp when r* = 0.
 //
-// The loop is VALU-issue bound (one lane per locus, ~1000 dependent events), so the state is kept in the form that
-// needs the fewest instructions: the pivot as the LDS address of its slot (rl = r* x LN + lane: comparisons against
-// the event's slot address need no conversion), F = r* + #window-only hashes below r* (the quantity both pivot tests
-// use) instead of the two terms, and pivot moves as one signed step `delta` applied with multiply-adds.
+// The slide is bound by instruction issue (one lane per locus, ~1000 dependent events; the SIMDs that carry two waves
+// set the kernel time), so the state is kept in the form that needs the fewest instructions: the pivot as the LDS
+// address of its slot (rl = r* x LNB + lane: comparisons against the event's slot address need no conversion),
+// g = r* + #window-only hashes below r* - s (the quantity both pivot tests use, against zero) instead of the terms,
+// pivot moves as one signed step `delta` applied with multiply-adds, the count stored with a bias of one because a
+// pivot move changes g by count + 1, and the comparison with the best window so far done on a copy of the shared
+// count that the event's no-eval bit makes negative.
+//
+// BASE0: the state starts at LDS address 0 (a kernel without static LDS; the kernel checks it), so that with 64
+// one-byte lanes per row the masked event word OR the lane IS the address of the event's slot.
+template <typename T, typename ST, int LNT, bool BASE0>
+struct Slide {
+  typedef __attribute__((address_space(3))) ST *lds_ptr;
+  static constexpr int STB = (int)sizeof(ST);
+  static constexpr int SBITS = 8 * STB;
+  static constexpr int RB = EvBits<T>::RANK;
+  int lbase, LNB, s;
+  int rl, g, shared, best, beg, opt_s, opt_e;
+  uint32_t overflow;
+
+  // LDS byte addresses as plain integers: `extern __shared__` has a link-time base the compiler would add on every access
+  static __device__ __forceinline__ uint32_t ld(int addr) { return (uint32_t)*(lds_ptr)(uintptr_t)(uint32_t)addr; }
+  static __device__ __forceinline__ void sto(int addr, uint32_t v) { *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)v; }
+
+  __device__ __forceinline__ void init(ST *st, int lane, int lanes, int sketch, int beg0) {
+    lbase = (int)(uint32_t)(uintptr_t)(lds_ptr)st + lane * STB;
+    LNB = (LNT ? LNT : lanes) * STB;                              // bytes between consecutive slots of one lane
+    s = sketch;
+    rl = lbase; g = 0; shared = 0; best = -1; beg = opt_s = opt_e = beg0; overflow = 0;
+  }
+  static constexpr uint32_t EMPTY = 2u;                           // count 0 (biased), not matched
+  __device__ __forceinline__ void clear() { for (int i = 0; i <= s + 1; i++) sto(i * LNB + lbase, EMPTY); }
+  // SH: position of the event inside its 32-bit word (a constant after unrolling)
+  template <int SH> __device__ __forceinline__ int slot_addr(uint32_t word) const {
+    if constexpr (LNT == 64) {
+      const uint32_t row = (SH ? word >> SH : word) & ev_slot_mask<T>();          // slot x 64
+      if constexpr (BASE0) return (int)((STB == 1 ? row : row * STB) | (uint32_t)lbase);
+      else return (int)(STB == 1 ? row : row * STB) + lbase;
+    } else {
+      return (int)__builtin_amdgcn_ubfe(word, SH + EV_SLOT, RB) * LNB + lbase;
+    }
+  }
+  // an event of the first super-window: its admit only changes the per-rank state
+  template <int SH> __device__ __forceinline__ void fill(uint32_t word) {
+    const int dM = __builtin_amdgcn_sbfe(word, SH + EV_DM, 2), dW = __builtin_amdgcn_sbfe(word, SH + EV_DW, 2);
+    const int addr = slot_addr<SH>(word);
+    const uint32_t nv = (ld(addr) + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+    overflow |= nv;
+    sto(addr, nv);
+  }
+  // pivot of the filled window: r* = min{r : r + sum_{c <= r} cnt[c] >= s} (s if there is none); the comparison after
+  // the last admit of the first window (best was -1: it always wins)
+  __device__ __forceinline__ void read_pivot() {
+    int rstar = s, F = s, acc = 0, m_acc = 0;
+    bool hit = false;
+    for (int r = 0; r < s; r++) {
+      const uint32_t v = ld((r + 1) * LNB + lbase);
+      const int c = (int)(v >> 1) - 1, mt = (int)(v & 1u);
+      const bool now = !hit && r + acc + c >= s;
+      rstar = now ? r : rstar;
+      F = now ? r + acc : F;
+      shared = now ? m_acc : shared;
+      hit = hit || now;
+      acc += c; m_acc += mt;
+    }
+    F = hit ? F : s + acc;
+    shared = hit ? shared : m_acc;
+    g = F - s;
+    rl = rstar * LNB + lbase;                                     // address of slot r* (= state of rank r*-1)
+    best = shared;
+  }
+  // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
+  template <int SH> __device__ __forceinline__ void step(uint32_t word) {
+    const int dM = __builtin_amdgcn_sbfe(word, SH + EV_DM, 2), dW = __builtin_amdgcn_sbfe(word, SH + EV_DW, 2);
+    const int drp = (int)__builtin_amdgcn_ubfe(word, SH + EV_DROP, 1);
+    // both LDS reads are issued together: the touched rank, and the rank at the boundary the pivot may move across
+    const int addr = slot_addr<SH>(word);
+    const int addrb = rl + drp * LNB;                             // slot of rank r* (drop) or r*-1 (admit)
+    const uint32_t v = ld(addr), vb0 = ld(addrb);
+    // admits of a matched rank set bit 0, drops clear it; window-only hashes count in the bits above
+    const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+    overflow |= nv;                                               // bit SBITS set = the count left its field
+    sto(addr, nv);
+    const bool below = addr <= rl;                                // rank < r*
+    const int dWb = below ? dW : 0;
+    shared += below ? dM : 0;
+    g += dWb;
+    const uint32_t vb = (addrb == addr) ? nv : vb0;
+    const int c1 = (int)(vb >> 1), mbm = __builtin_amdgcn_sbfe(vb, 0, 1);   // count + 1 of the boundary rank, -(its matched bit)
+    // a window-only hash left and query rank r* re-enters the s smallest of the union (g + count < 0 implies r* < s) ...
+    const bool up = ((dW & (g + c1 - 1)) < 0);                    // dW < 0 and g + count < 0: both sign bits set
+    // ... or one arrived below r* and f(r*-1) reached s: the largest query rank falls out
+    const bool down = dWb > 0 && g > 0;
+    const int delta = up ? 1 : (down ? -1 : 0);
+    g += __mul24(delta, c1);                                      // r* moves by delta, the count of the crossed rank changes sides
+    shared += delta & mbm;
+    rl += __mul24(delta, LNB);
+    beg += drp;
+    // the comparison of this window position, if the event carries one: otherwise its shared count reads as negative
+    const int sh_e = (int)((uint32_t)shared | ((word << ((32 - SH - 8 * (int)sizeof(T)) & 31)) & 0x80000000u));
+    const bool gt = sh_e > best, ge = sh_e >= best;
+    best = max(best, sh_e);
+    opt_s = gt ? beg : opt_s;
+    opt_e = ge ? beg : opt_e;
+  }
+};
+
+// LNT = lanes per workgroup at compile time (64) or 0 for the run-time value used when a huge sketch forces fewer lanes
+// per workgroup.
 template <typename T, typename ST, int LNT>
 __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  constexpr int SBITS = 8 * (int)sizeof(ST);
   constexpr bool REDO = sizeof(ST) > 1;
   const int LN = LNT ? LNT : a.lanes;
   ST *st = (ST *)lds;                                              // [cnt_slots + 1][LN], lane-interleaved
@@ -1318,17 +1427,13 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   const uint32_t nev = a.l_nev[l];                                  // multiple of 8
   constexpr int PER = 16 / sizeof(T);                               // events per 16-byte load
   const uint4 *ev = (const uint4 *)((const T *)a.items + a.l_ioff[l]);
-  constexpr int RB = EvBits<T>::RANK;
-  for (int i = 0; i <= s + 1; i++) st[i * LN + lane] = 0;
-  // LDS byte addresses as plain integers: `extern __shared__` has a link-time base the compiler would add on every access
-  typedef __attribute__((address_space(3))) ST *lds_ptr;
-  constexpr int STB = (int)sizeof(ST);
-  const int lbase = (int)(uint32_t)(uintptr_t)(lds_ptr)st + lane * STB;
-  const int LNB = LN * STB;                                         // bytes between consecutive slots of one lane
+  Slide<T, ST, LNT, true> sl;
+  sl.init(st, lane, LN, s, beg0);
+  sl.clear();
+  if (sl.lbase != lane * (int)sizeof(ST)) __builtin_trap();         // BASE0: this kernel has no static LDS
 
   // ---- the first super-window: its admits only change the per-rank state, so they are applied without the pivot logic
-  //      (the pivot, F and the shared count are functions of the state and are read off it afterwards) ----
-  uint32_t overflow = 0;
+  //      (the pivot, g and the shared count are functions of the state and are read off it afterwards) ----
   const uint32_t ngroups = nev / PER;
   const uint32_t fill_groups = min(ngroups, (uint32_t)((((a.l_end0[l] - beg0) + 7) & ~7) / PER));
   auto word_of = [](const uint4 &g, int q) __attribute__((always_inline)) {
@@ -1340,88 +1445,27 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
     const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < PER; q++) {
-      const uint32_t word = word_of(cur, q);
-      const int SH = (sizeof(T) == 2 && (q & 1)) ? 16 : 0;
-      const int slot = (int)__builtin_amdgcn_ubfe(word, SH, RB);
-      const int dM = __builtin_amdgcn_sbfe(word, SH + RB, 2), dW = __builtin_amdgcn_sbfe(word, SH + RB + 2, 2);
-      const int addr = slot * LNB + lbase;
-      const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
-      const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
-      overflow |= nv;
-      *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
+      if (sizeof(T) == 2 && (q & 1)) sl.template fill<16>(word_of(cur, q)); else sl.template fill<0>(word_of(cur, q));
     }
     cur = nxt;
   }
-  // pivot of the filled window: r* = min{r : r + sum_{c <= r} cnt[c] >= s} (s if there is none)
-  int rstar = s, F = s, shared = 0;
-  {
-    int acc = 0, m_acc = 0;
-    bool hit = false;
-    for (int r = 0; r < s; r++) {
-      const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)((r + 1) * LNB + lbase);
-      const int c = (int)(v >> 1), mt = (int)(v & 1u);
-      const bool now = !hit && r + acc + c >= s;
-      rstar = now ? r : rstar;
-      F = now ? r + acc : F;
-      shared = now ? m_acc : shared;
-      hit = hit || now;
-      acc += c; m_acc += mt;
-    }
-    F = hit ? F : s + acc;
-    shared = hit ? shared : m_acc;
-  }
-  int rl = rstar * LNB + lbase;                                     // address of slot r* (= state of rank r*-1)
-  int beg = beg0;
-  // the comparison after the last admit of the first window (best was -1: it always wins)
-  int best = fill_groups ? shared : -1, opt_s = beg0, opt_e = beg0;
+  sl.read_pivot();
+  if (!fill_groups) sl.best = -1;
   for (uint32_t g = fill_groups; g < ngroups; g++) {
     const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);   // prefetch: the load is off the chain
 #pragma unroll
     for (int q = 0; q < PER; q++) {
-      const uint32_t word = word_of(cur, q);
-      const int SH = (sizeof(T) == 2 && (q & 1)) ? 16 : 0;         // position of the event inside its 32-bit word (a constant after unrolling)
-      // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
-      const int slot = (int)__builtin_amdgcn_ubfe(word, SH, RB);   // query rank + 1 (0 = padding)
-      const int dM = __builtin_amdgcn_sbfe(word, SH + RB, 2), dW = __builtin_amdgcn_sbfe(word, SH + RB + 2, 2);
-      const int drp = (int)__builtin_amdgcn_ubfe(word, SH + RB + 4, 1);
-      const bool evl = ((word >> (SH + RB + 5)) & 1u) != 0;
-      // both LDS reads are issued together: the touched rank, and the rank at the boundary the pivot may move across
-      const int addr = slot * LNB + lbase;
-      const int addrb = rl + drp * LNB;                            // slot of rank r* (drop) or r*-1 (admit)
-      const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
-      const uint32_t vb0 = *(lds_ptr)(uintptr_t)(uint32_t)addrb;
-      // admits of a matched rank set bit 0, drops clear it; window-only hashes count in the bits above
-      const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
-      overflow |= nv;                                              // bit SBITS set = the count left its field
-      *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
-      const bool below = addr <= rl;                               // rank < r*
-      shared += below ? dM : 0;
-      F += below ? dW : 0;
-      const uint32_t vb = (addrb == addr) ? nv : vb0;
-      const int cb = (int)(vb >> 1), mb = (int)(vb & 1u);
-      // a window-only hash left and query rank r* re-enters the s smallest of the union (F + cb < s implies r* < s) ...
-      const bool up = ((dW & (F + cb - s)) < 0);                   // dW < 0 and F + cb < s: both sign bits set
-      // ... or one arrived below r* and f(r*-1) reached s: the largest query rank falls out
-      const bool down = dW > 0 && below && F > s;
-      const int delta = up ? 1 : (down ? -1 : 0);
-      F += __mul24(delta, cb + 1);                                 // r* moves by delta, the count of the crossed rank changes sides
-      shared += __mul24(delta, mb);
-      rl += __mul24(delta, LNB);
-      beg += drp;
-      const bool gt = evl && shared > best, ge = evl && shared >= best;
-      best = gt ? shared : best;
-      opt_s = gt ? beg : opt_s;
-      opt_e = ge ? beg : opt_e;
+      if (sizeof(T) == 2 && (q & 1)) sl.template step<16>(word_of(cur, q)); else sl.template step<0>(word_of(cur, q));
     }
     cur = nxt;
   }
-  if (overflow >> SBITS) {
+  if (sl.overflow >> Slide<T, ST, LNT, true>::SBITS) {
     if (!REDO) { a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u); return; }
   }
-  a.l_shared[l] = best < 0 ? 0 : best;
-  a.l_pos[l] = (a.ix.rec_wpos[opt_s] + a.ix.rec_wpos[opt_e]) / 2;
-  if (best >= a.pass_lut[s]) {
-    unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)(0xFFFFFFFFu - l);
+  a.l_shared[l] = sl.best < 0 ? 0 : sl.best;
+  a.l_pos[l] = (a.ix.rec_wpos[sl.opt_s] + a.ix.rec_wpos[sl.opt_e]) / 2;
+  if (sl.best >= a.pass_lut[s]) {
+    unsigned long long key = ((unsigned long long)(uint32_t)sl.best << 32) | (unsigned long long)(0xFFFFFFFFu - l);
     atomicMax(&a.group_best[a.l_group[l]], key);
   }
 }
@@ -1589,7 +1633,7 @@ __global__ __launch_bounds__(64 * (1 + NPROD), (NPROD == 2 && FU_C == 8) ? 6 : 4
         if (!REDO && rsum) { atomicAdd(a.rec_total, (unsigned long long)rsum); atomicAdd(&a.pinfo[0], (unsigned long long)esum); }
       }
     }
-    for (int i = tid; i < (s + 2) * 64; i += FU_THREADS) st[i] = (ST)0;
+    for (int i = tid; i < (s + 2) * 64; i += FU_THREADS) st[i] = (ST)Slide<T, ST, 64, false>::EMPTY;
     __syncthreads();
     const int R_fill = sh_fill_rows, R_all = sh_rows, n_steps = sh_steps;
     if (R_all == 0) continue;
@@ -1715,30 +1759,30 @@ __global__ __launch_bounds__(64 * (1 + NPROD), (NPROD == 2 && FU_C == 8) ? 6 : 4
           const int it = hf * HALF + q;
           const uint32_t y_ = phf[it].y;
           const bool found = eq[q] && x[q] < s;                        // (an equal entry at rank >= s is a sentinel)
-          const uint32_t base = (uint32_t)(x[q] + 1);
-          const int dsh = found ? RB : RB + 2;
+          const uint32_t base = (uint32_t)(x[q] + 1) << EV_SLOT;
+          const int dsh = found ? EV_DM : EV_DW;
           const uint32_t dist = (y_ >> 8) & 0xFFFFu;
           // fill: a no-op admit when the hash is already in the window (its previous occurrence lies at or after `beg`)
-          const uint32_t ev_fill = base | ((dist <= k ? 0u : 1u) << dsh);
+          const uint32_t ev_fill = base | ((dist <= k ? 0u : 1u) << dsh) | ev_noeval<T>();
           // admit: after the drops of all records before the one active at its window position; carries the comparison;
           // a no-op when linked to the previous record of the same hash
-          const uint32_t ev_admit = base | (((y_ & FLAG_INS_LINKED) ? 0u : 1u) << dsh) | (1u << (RB + 5));
+          const uint32_t ev_admit = base | (((y_ & FLAG_INS_LINKED) ? 0u : 1u) << dsh);
           // drop at window position wpos[i+1], before the admit of that same position (FLAG_SAME_STEP), which then
           // carries the comparison
           const uint32_t same = (y_ & FLAG_SAME_STEP) ? 1u : 0u;
-          const uint32_t ev_drop = base | (((y_ & FLAG_DEL_LINKED) ? 0u : 3u) << dsh) | (1u << (RB + 4)) | ((same ^ 1u) << (RB + 5));
+          const uint32_t ev_drop = base | (((y_ & FLAG_DEL_LINKED) ? 0u : 3u) << dsh) | (1u << EV_DROP) | (same ? ev_noeval<T>() : 0u);
           uint32_t ev = fill ? ev_fill : (((padmit >> it) & 1u) ? ev_admit : ev_drop);
-          ev = ((pok >> it) & 1u) ? ev : 0u;
+          ev = ((pok >> it) & 1u) ? ev : ev_noeval<T>();
           out[it * FU_UPI] = (T)ev;
         }
       }
     };
 
     // slider state (wave 0 only)
-    uint32_t overflow = 0;
-    int rl = 0, F = 0, shared = 0, best = -1, beg = 0, opt_s = 0, opt_e = 0;
+    Slide<T, ST, 64, false> sl;
+    sl.init(st, lane, 64, s, 0);
     if (wv == 0) {
-      beg = my_beg; opt_s = beg; opt_e = beg;
+      sl.beg = sl.opt_s = sl.opt_e = my_beg;
     } else {
       own_beg = owner ? u_beg[own] : -1; own_e0 = u_e0[own]; own_nmain = u_nmain[own];
       own_nfill = own_beg >= 0 ? own_e0 - 2u * (uint32_t)own_beg : 0u;  // e0 = beg + end0
@@ -1760,68 +1804,11 @@ __global__ __launch_bounds__(64 * (1 + NPROD), (NPROD == 2 && FU_C == 8) ? 6 : 4
         if (row < R_fill) {
           // the first super-window: its admits only change the per-rank state
 #pragma unroll
-          for (int q = 0; q < FU_C; q++) {
-            const int slot = (int)__builtin_amdgcn_ubfe(word[q], 0, RB);
-            const int dM = __builtin_amdgcn_sbfe(word[q], RB, 2), dW = __builtin_amdgcn_sbfe(word[q], RB + 2, 2);
-            const int addr = slot * LNB + lbase;
-            const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
-            const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
-            overflow |= nv;
-            *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
-          }
-          if (row == R_fill - 1) {
-            // pivot of the filled window: r* = min{r : r + sum_{c <= r} cnt[c] >= s} (s if there is none)
-            int rstar = s, acc = 0, m_acc = 0;
-            F = s;
-            bool hit = false;
-            for (int r = 0; r < s; r++) {
-              const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)((r + 1) * LNB + lbase);
-              const int c = (int)(v >> 1), mt = (int)(v & 1u);
-              const bool now = !hit && r + acc + c >= s;
-              rstar = now ? r : rstar;
-              F = now ? r + acc : F;
-              shared = now ? m_acc : shared;
-              hit = hit || now;
-              acc += c; m_acc += mt;
-            }
-            F = hit ? F : s + acc;
-            shared = hit ? shared : m_acc;
-            rl = rstar * LNB + lbase;
-            best = shared;                                             // the comparison after the last admit of the first window
-          }
+          for (int q = 0; q < FU_C; q++) sl.template fill<0>(word[q]);
+          if (row == R_fill - 1) sl.read_pivot();       // incl. the comparison after the last admit of the first window
         } else {
 #pragma unroll
-          for (int q = 0; q < FU_C; q++) {
-            // straight-line selects only: the 64 lanes follow 64 different loci (see k_l2_scan)
-            const uint32_t wd = word[q];
-            const int slot = (int)__builtin_amdgcn_ubfe(wd, 0, RB);
-            const int dM = __builtin_amdgcn_sbfe(wd, RB, 2), dW = __builtin_amdgcn_sbfe(wd, RB + 2, 2);
-            const int drp = (int)__builtin_amdgcn_ubfe(wd, RB + 4, 1);
-            const bool evl = ((wd >> (RB + 5)) & 1u) != 0;
-            const int addr = slot * LNB + lbase;
-            const int addrb = rl + drp * LNB;                          // slot of rank r* (drop) or r*-1 (admit)
-            const uint32_t v = *(lds_ptr)(uintptr_t)(uint32_t)addr;
-            const uint32_t vb0 = *(lds_ptr)(uintptr_t)(uint32_t)addrb;
-            const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
-            overflow |= nv;
-            *(lds_ptr)(uintptr_t)(uint32_t)addr = (ST)nv;
-            const bool below = addr <= rl;                             // rank < r*
-            shared += below ? dM : 0;
-            F += below ? dW : 0;
-            const uint32_t vb = (addrb == addr) ? nv : vb0;
-            const int cb = (int)(vb >> 1), mb = (int)(vb & 1u);
-            const bool up = ((dW & (F + cb - s)) < 0);
-            const bool down = dW > 0 && below && F > s;
-            const int delta = up ? 1 : (down ? -1 : 0);
-            F += __mul24(delta, cb + 1);
-            shared += __mul24(delta, mb);
-            rl += __mul24(delta, LNB);
-            beg += drp;
-            const bool gt = evl && shared > best, ge = evl && shared >= best;
-            best = gt ? shared : best;
-            opt_s = gt ? beg : opt_s;
-            opt_e = ge ? beg : opt_e;
-          }
+          for (int q = 0; q < FU_C; q++) sl.template step<0>(word[q]);
         }
       }
       if (stamp) t_work += __builtin_amdgcn_s_memtime() - t_in;
@@ -1831,13 +1818,13 @@ __global__ __launch_bounds__(64 * (1 + NPROD), (NPROD == 2 && FU_C == 8) ? 6 : 4
     if (wv == 0) {
       if (my_locus >= 0) {
         const int32_t l = my_locus;
-        if ((overflow >> SBITS) && !REDO) {
+        if ((sl.overflow >> SBITS) && !REDO) {
           a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u);
         } else {
-          a.l_shared[l] = best < 0 ? 0 : best;
-          a.l_pos[l] = (wpos[opt_s] + wpos[opt_e]) / 2;
-          if (best >= a.pass_lut[s]) {
-            unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)l);
+          a.l_shared[l] = sl.best < 0 ? 0 : sl.best;
+          a.l_pos[l] = (wpos[sl.opt_s] + wpos[sl.opt_e]) / 2;
+          if (sl.best >= a.pass_lut[s]) {
+            unsigned long long key = ((unsigned long long)(uint32_t)sl.best << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)l);
             atomicMax(&a.group_best[a.l_group[l]], key);
           }
         }

@@ -726,6 +726,28 @@ def test_protein_small_k_and_wide_strings(golden_dir):
         assert len(got) == 1 and got[0].matches >= 9
 
 
+@pytest.mark.parametrize("fragment_length", [513, 514, 515, 516, 520])
+def test_sketch_sizes_around_the_16_bit_event_limit(fragment_length):
+    # protein mode, k = 5, w = 1: a fragment keeps fragment_length - 4 minimizers (5-mers of random residues hardly
+    # repeat), i.e. sketches of 509 .. 516 entries: the 16-bit slide event holds slots up to 511 (sketches up to 510),
+    # beyond that the pass must switch to 32-bit events
+    g = syn.rng(1200 + fragment_length)
+    amino = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    prots = [bytes(amino[g.integers(0, 20, 9_000)]) for _ in range(3)]
+    params = dict(k=5, fragment_length=fragment_length, protein=True, minimum_fraction=0.0)
+    query = []
+    for p in prots:
+        a = np.frombuffer(p, dtype=np.uint8).copy()
+        m = g.random(len(a)) < 0.02
+        a[m] = amino[g.integers(0, 20, int(m.sum()))]
+        query.append(bytes(a))
+    mapper, hits, ohits, det = run_both(params, [prots, [prots[1], prots[0]]], query, threads=8)
+    sizes = set(det["mappings"]["sketch"].tolist())
+    assert len(det["mappings"]["rseq"]) > 20 and fragment_length - 8 <= min(sizes) and max(sizes) <= fragment_length - 4
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits and ohits
+
+
 def test_huge_sketch_with_seed_overflow():
     # protein mode (w = 1) with 12 000-residue fragments: a fragment keeps ~12 000 minimizers, far beyond what the LDS
     # tables of the chunked L1 kernel are laid out for, and four copies of the reference give it ~48 000 seed hits, more
