@@ -822,8 +822,13 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
-      a.ev_stage = 2048;                                                  // events staged per wave (longer streams go direct)
-      const size_t ev_lds = ((size_t)smax * 4 + 15) / 16 * 16 + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
+      // events of one locus staged in LDS per wave of k_l2_events (longer streams are stored directly): a stream holds
+      // the records of about 2.6 windows twice, minus the first window -- 5.3 windows' worth at the longest in the bench;
+      // the LDS this costs decides how many workgroups a CU holds (2048: 6, 1408: 7; 0.41 vs 0.38 ms for the L2 stage)
+      static const int ev_stage_env = (int)env_u64("FA_EV_STAGE", 0);
+      const int per_window = std::max(1, 2 * m.P.fragment_length / (m.P.window_size + 1));
+      a.ev_stage = ev_stage_env ? (ev_stage_env & ~7) : std::min(2048, std::max(512, (per_window * 11 / 2 + 127) & ~127));
+      const size_t ev_lds = ev_sketch_bytes(a.cnt_slots) + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
       FA_REQUIRE(ev_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS-staged event kernel");
       // fast pass: one state byte per rank; redo pass: two bytes per rank, only for loci whose counts overflowed
       auto scan_lds = [&](int ln, int bytes) { return ((size_t)(a.cnt_slots + 1) * ln * bytes + 15) / 16 * 16; };

@@ -1125,11 +1125,28 @@ template <typename T> constexpr uint32_t ev_noeval() { return 1u << (8 * sizeof(
 template <typename T> constexpr uint32_t ev_slot_mask() { return ((1u << EvBits<T>::RANK) - 1u) << EV_SLOT; }
 static_assert(EV_SLOT + EvBits<uint16_t>::RANK == 15 && EV_SLOT + EvBits<uint32_t>::RANK <= 31, "event fields overlap");
 
+// Bucket table resolution of k_l2_events: 4096 buckets over the hash range of ~250 sketch entries leave at most two
+// entries in all but a few buckets, so a rank lookup is one table read and one two-entry probe.
+#ifndef FA_EV_QT_BITS
+#define FA_EV_QT_BITS 12
+#endif
+#ifndef FA_EV_WAVES
+#define FA_EV_WAVES 8
+#endif
+constexpr int EV_QT_BITS = FA_EV_QT_BITS;
+constexpr int EV_WAVES_PER_SIMD = FA_EV_WAVES;
+constexpr int EV_PROBE = 4;                // sketch entries compared at once per rank lookup
+#ifndef FA_EV_RPL
+#define FA_EV_RPL 4
+#endif
+constexpr int EV_RPL = FA_EV_RPL;          // records per lane and trip of k_l2_events
+__host__ __device__ inline size_t ev_sketch_bytes(int cnt_slots) { return ((size_t)(cnt_slots - 1 + EV_PROBE) * 4 + 15) / 16 * 16; }   // + sentinels
+
 template <typename T, bool PACKED>
-__global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
+__global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
-  uint32_t *Q = (uint32_t *)lds;                                     // [smax], staged once per fragment
-  constexpr int QT_BITS = 10;                                        // bucket table resolution
+  uint32_t *Q = (uint32_t *)lds;                                     // [s + EV_PROBE], staged once per fragment, with sentinels
+  constexpr int QT_BITS = EV_QT_BITS;
   __shared__ uint16_t QT[(1 << QT_BITS) + 2];
   const int f = blockIdx.x;
   const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
@@ -1137,7 +1154,8 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
   const int s = a.q_size[f];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (a.counters[2] || s > a.cnt_slots - 1) return;                  // loci overflowed / sketch larger than speculated: void pass
-  for (int i = threadIdx.x; i < s; i += EV_THREADS) Q[i] = a.q_hash[(size_t)f * a.qcap + i];
+  for (int i = threadIdx.x; i < s + EV_PROBE; i += EV_THREADS) Q[i] = i < s ? a.q_hash[(size_t)f * a.qcap + i] : 0xFFFFFFFFu;
+  for (int b = threadIdx.x; b <= (1 << QT_BITS) + 1; b += EV_THREADS) QT[b] = (uint16_t)s;
   // ---- record range of every locus (the three searchIndex calls of computeL2MappedRegions) and its event count ----
   __shared__ uint32_t sh_wave[EV_THREADS / 64];
   __shared__ uint32_t sh_run, sh_base, sh_ok;
@@ -1155,9 +1173,9 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
       const int rfirst = a.l_rfirst[l], target = a.l_start[l];
       int x = max(lo, rfirst - a.frag_len), y = rfirst;
       while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+      const int last = a.ix.rec_fwd[a.l_rlast[l]];         // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
       const int beg = x;
       const int end0 = a.ix.rec_fwd[beg];                  // searchIndex(seqId, first wpos + countMinimizerWindows)
-      const int last = a.ix.rec_fwd[a.l_rlast[l]];         // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
       // the slide stops at the window position where the last record is admitted; the records dropped by then are
       // the ones before the record active at that position
       const int ndrop = last > end0 ? a.ix.rec_bwd[last - 1] - beg : 0;
@@ -1189,108 +1207,159 @@ __global__ __launch_bounds__(EV_THREADS) void k_l2_events(L2Args a) {
     sh_base = (uint32_t)base;
     atomicAdd(a.rec_total, sh_records);
   }
-  __syncthreads();
   // Bucket table over the hash range the query sketch actually spans: minimizer hashes are window minima, i.e. heavily
   // skewed towards 0, so the buckets divide [0, 2^bits) with 2^bits > the largest query hash rather than the full 32-bit
-  // range.  QT[b] = first query rank whose hash is >= b << qshift; a reference hash beyond the range ranks after all.
+  // range.  QT[b] = first query rank whose hash is >= b << qshift (rank i opens the buckets after the one of rank i-1,
+  // up to its own); a reference hash beyond the range ranks after all.
   const uint32_t hmax = s > 0 ? Q[s - 1] : 0u;
   const int qshift = max(0, (32 - __clz((int)(hmax | 1u))) - QT_BITS);   // hmax < 2^(qshift + QT_BITS)
-  for (int b = threadIdx.x; b <= (1 << QT_BITS); b += EV_THREADS) {
-    int x = 0, y = s;
-    const uint64_t key = (uint64_t)b << qshift;
-    while (x < y) { int mid = (x + y) >> 1; if ((uint64_t)Q[mid] < key) x = mid + 1; else y = mid; }
-    QT[b] = (uint16_t)x;
+  for (int i = threadIdx.x; i < s; i += EV_THREADS) {
+    const int bi = (int)(Q[i] >> qshift), bp = i ? (int)(Q[i - 1] >> qshift) : -1;
+    for (int b = bp + 1; b <= bi; b++) QT[b] = (uint16_t)i;
   }
-  if (threadIdx.x == 0) QT[(1 << QT_BITS) + 1] = (uint16_t)s;
   __syncthreads();
   if (!sh_ok) {                                                      // the event buffer is too small: void pass
     for (uint32_t i = threadIdx.x; i < l_n; i += EV_THREADS) a.l_nev[l_lo + i] = 0;
     return;
   }
-  // the waves of the workgroup take the loci of the fragment round-robin
-  for (uint32_t l = l_lo + wv; l < l_lo + l_n; l += EV_THREADS / 64) {
-    const int beg = a.l_beg[l], end0 = a.l_end0[l], last = a.l_last[l], ndrop = a.l_ndrop[l];
-    const int n_init = end0 - beg, n_init_pad = (n_init + 7) & ~7;
-    const uint32_t total = (uint32_t)(n_init_pad + (last - end0) + ndrop);
-    const uint32_t padded = (total + 7u) & ~7u;
-    const uint32_t ioff = sh_base + a.l_ioff[l];
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) a.l_ioff[l] = ioff;                               // absolute, for k_l2_scan
-    T *gout = (T *)a.items + ioff;
-    // events land at scattered 2-byte positions: build the stream of a locus in LDS and stream it out in 16-byte
-    // pieces (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
-    const bool staged = padded <= (uint32_t)a.ev_stage;
-    T *out = staged ? (T *)(lds + ((size_t)(a.cnt_slots - 1) * 4 + 15) / 16 * 16) + (size_t)wv * a.ev_stage : gout;
-    for (uint32_t i = total + lane; i < padded; i += 64) out[i] = (T)ev_noeval<T>();      // padding: slot 0, no comparison
-    if (lane < n_init_pad - n_init) out[n_init + lane] = (T)ev_noeval<T>();
-    auto emit = [&](int i, uint32_t h, uint32_t rf, bool prev_in, int32_t bwd, int32_t fwd1) __attribute__((always_inline)) {
-      const uint32_t qb = min(h >> qshift, (uint32_t)(1 << QT_BITS));     // the last bucket is [2^bits, inf): rank s
-      int x = QT[qb], y = QT[qb + 1];
-      while (x < y) { int mid = (x + y) >> 1; if (Q[mid] < h) x = mid + 1; else y = mid; }
-      const bool found = x < s && Q[x] == h;
-      // both events carry slot = rank + 1 and ONE signed delta: of the matched bit when the hash is in the query sketch,
-      // of the window-only count otherwise; branch-free apart from the store predicates
-      const uint32_t base = (uint32_t)(x + 1) << EV_SLOT;
-      const int dsh = found ? EV_DM : EV_DW;
-      const bool first = i < end0;
+  // The waves of the workgroup take the loci of the fragment round-robin; a wave goes through a locus in *trips* of
+  // 64 x EV_RPL records (EV_RPL per lane): first the records of the first super-window, then the later ones, then the
+  // stream is copied out.  (Measured and left out: issuing the reads of the next trip before working on the current one,
+  // two register sets swapping roles, and fetching the ranges of the next locus a locus ahead -- 187 -> 187..195 us; the
+  // kernel moves ~0.85 GB at 4.5 TB/s and is bound by that)
+  const uint32_t l_end = l_lo + l_n;
+  uint32_t l = l_lo + wv;
+  if (l >= l_end) return;                                            // (no workgroup barrier below this line)
+  struct Locus { int beg, end0, last, ndrop; uint32_t ioff; };
+  auto fetch_locus = [&](uint32_t lx) __attribute__((always_inline)) {        // unconditional loads from a clamped index
+    const uint32_t lc = min(lx, l_end - 1);
+    return Locus{a.l_beg[lc], a.l_end0[lc], a.l_last[lc], a.l_ndrop[lc], a.l_ioff[lc]};
+  };
+  auto uniform = [](const Locus &p) __attribute__((always_inline)) {          // the same in all lanes: keep it in scalar registers
+    return Locus{__builtin_amdgcn_readfirstlane(p.beg), __builtin_amdgcn_readfirstlane(p.end0), __builtin_amdgcn_readfirstlane(p.last),
+                 __builtin_amdgcn_readfirstlane(p.ndrop), (uint32_t)__builtin_amdgcn_readfirstlane((int)p.ioff)};
+  };
+  struct Trip { uint32_t h[EV_RPL], geo[EV_RPL], pd[EV_RPL]; int32_t pv[EV_RPL], bw[EV_RPL], fw[EV_RPL]; uint8_t rf[EV_RPL]; };
+  // the HBM reads of a trip, issued together (unconditionally, from a clamped index: a predicated load would wait for
+  // the one before it)
+  auto issue = [&](Trip &t, bool first, int t0, int hi) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) {
+      const int ic = min(t0 + lane + 64 * u, hi - 1);
+      t.h[u] = a.ix.rec_hash[ic];
+      if (PACKED) t.geo[u] = a.ix.rec_geo[ic];
+      else { t.rf[u] = a.ix.rec_flags[ic]; t.bw[u] = a.ix.rec_bwd[ic]; t.fw[u] = a.ix.rec_fwd[ic + 1]; }
+    }
+    if (first) {                                                     // (uniform)
+#pragma unroll
+      for (int u = 0; u < EV_RPL; u++) {
+        const int ic = min(t0 + lane + 64 * u, hi - 1);
+        if (PACKED) t.pd[u] = (uint32_t)a.ix.rec_prev16[ic]; else t.pv[u] = a.ix.rec_prev[ic];
+      }
+    }
+  };
+  typedef __attribute__((address_space(3))) T *lds_out_t;
+  T *const out_lds = (T *)(lds + ev_sketch_bytes(a.cnt_slots)) + (size_t)wv * a.ev_stage;
+  const uint32_t obase = (uint32_t)(uintptr_t)(lds_out_t)out_lds;
+  // the events of the records [t0, hi) of one trip; FIRST = records of the first super-window
+  auto work = [&](auto first_tag, auto store, const Trip &t, const Locus &p, int t0, int hi) __attribute__((always_inline)) {
+    constexpr bool FIRST = decltype(first_tag)::value;
+    const int beg = p.beg, end0 = p.end0, ndrop = p.ndrop;
+    const int n_init_pad = (end0 - beg + 7) & ~7;
+    // rank of a reference hash among the query hashes and whether it is one of them: the bucket's first rank, then
+    // EV_PROBE sketch entries at once; the few hashes that rank behind all of them walk on (the sentinels stop the
+    // walk).  Both the sketch and the reference hashes crowd towards 0, so two entries were not enough: nine trips out
+    // of ten still took the walk.
+    int x[EV_RPL]; uint32_t q[EV_RPL][EV_PROBE]; bool found[EV_RPL], more = false;
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) x[u] = QT[min(t.h[u] >> qshift, (uint32_t)(1 << QT_BITS))];   // the last bucket is [2^bits, inf): rank s
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) {
+#pragma unroll
+      for (int j = 0; j < EV_PROBE; j++) q[u][j] = Q[x[u] + j];
+    }
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) {
+      found[u] = false;
+      int below = 0;
+#pragma unroll
+      for (int j = 0; j < EV_PROBE; j++) { below += q[u][j] < t.h[u] ? 1 : 0; found[u] = found[u] || q[u][j] == t.h[u]; }
+      x[u] += below;
+      more = more || q[u][EV_PROBE - 1] < t.h[u];
+    }
+    if (__builtin_amdgcn_ballot_w64(more)) {
+#pragma unroll
+      for (int u = 0; u < EV_RPL; u++) if (q[u][EV_PROBE - 1] < t.h[u]) { while (Q[x[u]] < t.h[u]) x[u]++; found[u] = Q[x[u]] == t.h[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) {
+      const int i = t0 + lane + 64 * u;
+      if (i >= hi) continue;
+      uint32_t flags; bool prev_in; int32_t bwd, fwd1;
+      if (PACKED) {
+        flags = t.geo[u] >> (2 * GEO_BITS); prev_in = t.pd[u] <= (uint32_t)(i - beg);
+        bwd = i - (int32_t)((t.geo[u] >> GEO_BITS) & ((1u << GEO_BITS) - 1u)); fwd1 = i + 1 + (int32_t)(t.geo[u] & ((1u << GEO_BITS) - 1u));
+      } else { flags = t.rf[u]; prev_in = t.pv[u] >= beg; bwd = t.bw[u]; fwd1 = t.fw[u]; }
+      // both events carry slot = rank + 1 and ONE signed delta: of the matched bit when the hash is in the query
+      // sketch (a sentinel is not a match), of the window-only count otherwise
+      const uint32_t base = (uint32_t)(x[u] + 1) << EV_SLOT;
+      const int dsh = (found[u] && x[u] < s) ? EV_DM : EV_DW;
       // admit.  First super-window: inserted in record order, compared once after the last one, a no-op when the hash
       // is already in the window (prev_in).  Later: after the drops of all records before the one active at its window
       // position (rec_bwd), a no-op when linked to the previous record of the same hash.
-      const uint32_t on = first ? (prev_in ? 0u : 1u) : ((rf & FLAG_INS_LINKED) ? 0u : 1u);
-      const uint32_t noev1 = first ? (i == end0 - 1 ? 0u : ev_noeval<T>()) : 0u;
-      const uint32_t pos1 = first ? (uint32_t)(i - beg) : (uint32_t)(n_init_pad + (i - end0) + (bwd - beg));
-      out[pos1] = (T)(base | (on << dsh) | noev1);
+      if (FIRST) store((uint32_t)(i - beg), base | ((prev_in ? 0u : 1u) << dsh) | (i == end0 - 1 ? 0u : ev_noeval<T>()));
+      else store((uint32_t)(n_init_pad + (i - end0) + (bwd - beg)), base | (((flags & FLAG_INS_LINKED) ? 0u : 1u) << dsh));
       if (i - beg < ndrop) {
         // dropped at window position wpos[i+1], after the admits of earlier positions and before the admit of
         // that same position (FLAG_SAME_STEP), which then carries the comparison
-        const uint32_t same = (rf & FLAG_SAME_STEP) ? 1u : 0u;
-        const uint32_t pos2 = (uint32_t)(n_init_pad + (i - beg) + (fwd1 - (int)same - end0));
-        const uint32_t off = (rf & FLAG_DEL_LINKED) ? 0u : 3u;          // -1 in the two-bit field
-        out[pos2] = (T)(base | (off << dsh) | (1u << EV_DROP) | (same ? ev_noeval<T>() : 0u));
-      }
-    };
-    // four records per lane per trip: the HBM reads of a trip are issued together, ahead of the LDS searches
-    for (int i0 = beg + lane; i0 < last; i0 += 256) {
-      if (PACKED) {
-        uint32_t h[4], geo[4]; uint32_t pd[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + 64 * u;
-          const bool ok = i < last;
-          h[u] = ok ? a.ix.rec_hash[i] : 0u;
-          geo[u] = ok ? a.ix.rec_geo[i] : 0u;
-          pd[u] = (ok && i < end0) ? (uint32_t)a.ix.rec_prev16[i] : 65535u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + 64 * u;
-          if (i < last) emit(i, h[u], geo[u] >> (2 * GEO_BITS), pd[u] <= (uint32_t)(i - beg),
-                             i - (int32_t)((geo[u] >> GEO_BITS) & ((1u << GEO_BITS) - 1u)), i + 1 + (int32_t)(geo[u] & ((1u << GEO_BITS) - 1u)));
-        }
-      } else {
-        uint32_t h[4]; uint8_t rf[4]; int32_t pv[4], bw[4], fw[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + 64 * u;
-          const bool ok = i < last;
-          h[u] = ok ? a.ix.rec_hash[i] : 0u;
-          rf[u] = ok ? a.ix.rec_flags[i] : (uint8_t)0;
-          pv[u] = (ok && i < end0) ? a.ix.rec_prev[i] : -1;
-          bw[u] = (ok && i >= end0) ? a.ix.rec_bwd[i] : 0;
-          fw[u] = (ok && i - beg < ndrop) ? a.ix.rec_fwd[i + 1] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (i0 + 64 * u < last) emit(i0 + 64 * u, h[u], rf[u], pv[u] >= beg, bw[u], fw[u]);
+        const uint32_t same = (flags & FLAG_SAME_STEP) ? 1u : 0u;
+        const uint32_t off = (flags & FLAG_DEL_LINKED) ? 0u : 3u;         // -1 in the two-bit field
+        store((uint32_t)(n_init_pad + (i - beg) + (fwd1 - (int)same - end0)),
+              base | (off << dsh) | (1u << EV_DROP) | (same ? ev_noeval<T>() : 0u));
       }
     }
-    if (staged) {
+  };
+  // events land at scattered 2-byte positions: the stream of a locus is built in LDS and streamed out in 16-byte pieces
+  // (direct 2-byte stores doubled the HBM write traffic); very long streams fall back to direct stores
+  struct Stream { uint32_t total, padded; bool staged; T *gout; };
+  auto begin_locus = [&](const Locus &p, uint32_t lx) __attribute__((always_inline)) {
+    const int n_init = p.end0 - p.beg, n_init_pad = (n_init + 7) & ~7;
+    Stream st;
+    st.total = (uint32_t)(n_init_pad + (p.last - p.end0) + p.ndrop);
+    st.padded = (st.total + 7u) & ~7u;
+    st.staged = st.padded <= (uint32_t)a.ev_stage;
+    const uint32_t ioff = sh_base + p.ioff;
+    if (lane == 0) a.l_ioff[lx] = ioff;                              // absolute, for k_l2_scan
+    st.gout = (T *)a.items + ioff;
+    const T pad = (T)ev_noeval<T>();                                 // padding: slot 0, no comparison
+    T *o = st.staged ? out_lds : st.gout;
+    for (uint32_t i = st.total + lane; i < st.padded; i += 64) o[i] = pad;
+    if (lane < n_init_pad - n_init) o[n_init + lane] = pad;
+    return st;
+  };
+  auto end_locus = [&](const Stream &st) __attribute__((always_inline)) {
+    if (st.staged) {
       __builtin_amdgcn_wave_barrier();
-      const uint4 *src = (const uint4 *)out;
-      uint4 *dst = (uint4 *)gout;
-      const uint32_t n16 = padded * (uint32_t)sizeof(T) / 16u;
+      const uint4 *src = (const uint4 *)out_lds;
+      uint4 *dst = (uint4 *)st.gout;
+      const uint32_t n16 = st.padded * (uint32_t)sizeof(T) / 16u;
       for (uint32_t i = lane; i < n16; i += 64) dst[i] = src[i];
       __builtin_amdgcn_wave_barrier();
     }
+  };
+
+  for (; l < l_end; l += EV_THREADS / 64) {
+    const Locus cur = uniform(fetch_locus(l));
+    __builtin_amdgcn_wave_barrier();                                 // (the relative offset has been read: begin_locus overwrites it)
+    const Stream st = begin_locus(cur, l);
+    auto run = [&](auto store) __attribute__((always_inline)) {
+      Trip t;
+      for (int t0 = cur.beg; t0 < cur.end0; t0 += 64 * EV_RPL) { issue(t, true, t0, cur.end0); work(std::true_type(), store, t, cur, t0, cur.end0); }
+      for (int t0 = cur.end0; t0 < cur.last; t0 += 64 * EV_RPL) { issue(t, false, t0, cur.last); work(std::false_type(), store, t, cur, t0, cur.last); }
+    };
+    if (st.staged) run([&](uint32_t pos, uint32_t v) __attribute__((always_inline)) { *(lds_out_t)(uintptr_t)(obase + pos * (uint32_t)sizeof(T)) = (T)v; });
+    else { T *gout = st.gout; run([&](uint32_t pos, uint32_t v) __attribute__((always_inline)) { gout[pos] = (T)v; }); }
+    end_locus(st);
   }
 }
 

@@ -1145,4 +1145,4 @@ def test_device_memory_is_stable():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_leaks.py")], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     out = json.loads(res.stdout.strip().splitlines()[-1])
-    assert out["after_600_queries_mb"] <= 1.0 and out["after_50_batches_mb"] <= 1.0 and out["after_20_mappers_mb"] <= 64.0, out
+    assert out["after_600_queries_mb"] <= 1.0 and out["after_50_batches_mb"] <= 1.0 and out["after_20_mappers_mb"] <= 16.0, out
