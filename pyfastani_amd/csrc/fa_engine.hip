@@ -16,6 +16,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <deque>
 
 #include "fa_common.h"
 #include "fa_fasta.h"
@@ -321,12 +322,19 @@ struct Workspace {
   const fa_genomes *last_genomes = nullptr;
   float last_ms[16] = {0};
   hipEvent_t ev[6] = {nullptr};
+  // the parts of a pass are pipelined over this workspace and two more *lanes* (run_query_pass): sub-workspaces with their
+  // own stream and per-part buffers; `serial` tells the debug getters which lanes took part in the last call
+  std::unique_ptr<Workspace> sub[2];
+  hipEvent_t ev_bins = nullptr;
+  uint64_t serial = 0;
+  int64_t pass_f0 = 0;
   // the one-query-at-a-time call (fa_mapper_query) recycles its batch object -- no device allocation per call -- and
   // builds the upload image in pinned memory; its rows come back through a pinned block too
   std::unique_ptr<fa_genomes> query_batch;
   PinnedBuf pin_image, pin_rows;
   ~Workspace() {
     for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+    if (ev_bins) (void)hipEventDestroy(ev_bins);
     if (stream) (void)hipStreamDestroy(stream);
     if (h_status) (void)hipHostFree(h_status);
   }
@@ -660,7 +668,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ensure_luts(m, sp.smax);
     w.lut_min_hits = m.d_min_hits.p; w.lut_pass = m.d_pass.p; w.lut_ident = m.d_ident.p;
   };
-  auto publish_spec = [&] {
+  auto publish_spec = [&](const fa_mapper::Spec &sp) {
     std::lock_guard<std::mutex> lock(m.mtx);
     fa_mapper::Spec &ms = m.spec;
     ms.smax = std::max(ms.smax, sp.smax);
@@ -680,33 +688,96 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
   const size_t qs_lds = (size_t)next_pow2((uint32_t)std::max(qcap, 2)) * 4;
   FA_REQUIRE(qs_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
 
-  int64_t nrows = 0;
-  int64_t f0 = range_f0;
-  int attempt = 0;
-  while (f0 < range_f1) {
-    FA_REQUIRE(attempt < 40, FA_ERR_INTERNAL, "query pass did not converge on its buffer sizes");
-    attempt++;
-    if (attempt > 1 || f0 != range_f0) fetch_spec();
-    const int64_t f1 = std::min(range_f1, f0 + std::max<int64_t>(1, sp.part_frags));
-    const int64_t F = f1 - f0;
-    const bool first_part = f0 == range_f0, last_part = f1 == range_f1;
-    w.last_F = F; w.last_f0 = f0;
+  // ---- the parts of the pass; optionally (FA_QUERY_LANES = 2 or 3) pipelined over *lanes*: sub-workspaces with their own
+  // stream and buffers, so that part n + 1 is sketched and looked up while part n slides.  The parts share the CGI bin
+  // table (atomicMax); the rows are formed on the lane of the last part, behind the bins of all lanes.  Every part keeps
+  // its own speculation verdict: a void part is queued again (and the rows, if they were formed already, are formed
+  // again after it).  Measured: no gain (bench step 0.623 / 0.622 / 0.641 ms with 1 / 2 / 3 lanes, 16 queries per
+  // launch 237 k / 240 k pairs/s, config 3 2.59 M / 2.55 M) -- every kernel of the path runs its workgroups in one or a
+  // few resident rounds, so a third of the fragments takes nearly as long as all of them, and what the lanes add in
+  // overlap they lose in occupancy.  Hence one lane by default; DESIGN.md section 6.
+  static const int lanes_wanted = (int)std::min<uint64_t>(3, std::max<uint64_t>(1, env_u64("FA_QUERY_LANES", 1)));
+  static const int64_t lane_min_frags = (int64_t)env_u64("FA_LANE_MIN_FRAGMENTS", 256);
+  const int64_t F_total = range_f1 - range_f0;
+  int64_t auto_part = F_total;
+  if (lanes_wanted > 1 && F_total >= 2 * lane_min_frags) {
+    const int64_t parts = std::min<int64_t>(lanes_wanted, F_total / lane_min_frags);
+    auto_part = (F_total + parts - 1) / parts;
+  }
+  Workspace *lanes[3] = {&w, nullptr, nullptr};
+  int n_lanes = 1;
+  if (lanes_wanted > 1 && std::min<int64_t>(auto_part, sp.part_frags) < F_total) {
+    for (int i = 0; i + 1 < lanes_wanted; i++) {
+      if (!w.sub[i]) w.sub[i].reset(new Workspace());
+      Workspace &x = *w.sub[i];
+      if (!x.stream) FA_HIP(hipStreamCreate(&x.stream));
+      lanes[n_lanes++] = &x;
+    }
+  }
+  w.serial++;
+  w.pass_f0 = range_f0;
+  for (int i = 0; i < n_lanes; i++) for (int e = 0; e < 6; e++) if (!lanes[i]->ev[e]) FA_HIP(hipEventCreate(&lanes[i]->ev[e]));
+  if (!w.ev_bins) FA_HIP(hipEventCreate(&w.ev_bins));
+  if (npairs > 0) FA_HIP(hipMemsetAsync(w.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
+  FA_HIP(hipEventRecord(w.ev_bins, st));
+
+  struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; };
+  std::deque<std::pair<int64_t, int64_t>> todo;
+  todo.emplace_back(range_f0, range_f1);
+  std::deque<Run> flight;
+  bool busy[3] = {false, false, false}, ran[3] = {false, false, false};
+  bool rows_valid = false;
+  int rows_lane = -1;
+  int attempts = 0;
+  // the lane that forms the rows waits for the bins of the parts launched on the other lanes
+  auto join_lanes = [&](int me) {
+    for (int i = 0; i < n_lanes; i++) if (i != me && ran[i]) FA_HIP(hipStreamWaitEvent(lanes[me]->stream, lanes[i]->ev[4], 0));
+  };
+  auto launch_rows = [&](Workspace &ln) {
+    hipStream_t st = ln.stream;
+    uint32_t *const d_counters = ln.status.p->counters;
+    int32_t *const d_total_rows = &ln.status.p->total_rows;
+    RowsArgs ra;
+    ra.bins = w.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
+    ra.row_count = w.row_count.p; ra.row_ident = w.row_ident.p;
+    ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
+    ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag + g0; ra.query_id_base = g0;
+    ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = d_total_rows;
+    hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
+    if (ra.emit) {
+    } else {
+      hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, npairs, w.row_flag.p);
+      FA_HIP(hipMemsetAsync(w.row_flag.p + npairs, 0, sizeof(int32_t), st));
+      exclusive_sum_i32(ln.sk.cub_temp, w.row_flag.p, w.row_off.p, (int)npairs + 1, st);
+      FA_HIP(hipMemcpyAsync(d_total_rows, w.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+      hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, w.row_ident.p, w.row_off.p, m.G,
+                         npairs, g.d_total_frag + g0, g0, rows_dev + row_base, cap - row_base);
+    }
+  };
+  auto launch_part = [&](Run &r) {
+    Workspace &ln = *lanes[r.lane];
+    hipStream_t st = ln.stream;
+    const fa_mapper::Spec &sp = r.sp;
+    const int64_t f0 = r.f0, f1 = r.f1, F = f1 - f0;
+    ln.serial = w.serial;
+    if (&ln != &w) FA_HIP(hipStreamWaitEvent(st, w.ev_bins, 0));     // (the bin table is cleared on the first lane's stream)
+    ln.last_F = 0; ln.last_f0 = f0; ln.last_loci = 0;                 // (filled in when the part is accepted)
     const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
     const int ntiles = t1 - t0;
     // buffers whose size depends only on the geometry of the part
-    w.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
-    w.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
-    w.sk.tile_count.ensure((size_t)ntiles + 1);
-    w.q_hash.ensure((size_t)F * qcap); w.q_off.ensure((size_t)F * qcap); w.q_cnt.ensure((size_t)F * qcap);
-    w.q_size.ensure((size_t)F); w.n_seeds.ensure((size_t)F); w.ovf_off.ensure((size_t)F);
-    w.f_loci_lo.ensure((size_t)F); w.f_loci_n.ensure((size_t)F);
-    w.status.ensure(1);
-    if (!w.h_status) FA_HIP(hipHostMalloc((void **)&w.h_status, sizeof(PassStatus), hipHostMallocDefault));
-    int32_t *const d_stats = w.status.p->stats;
-    uint64_t *const d_totals = w.status.p->totals;
-    uint32_t *const d_counters = w.status.p->counters;
-    unsigned long long *const d_pinfo = w.status.p->pinfo;
-    int32_t *const d_total_rows = &w.status.p->total_rows;
+    ln.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
+    ln.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
+    ln.sk.tile_count.ensure((size_t)ntiles + 1);
+    ln.q_hash.ensure((size_t)F * qcap); ln.q_off.ensure((size_t)F * qcap); ln.q_cnt.ensure((size_t)F * qcap);
+    ln.q_size.ensure((size_t)F); ln.n_seeds.ensure((size_t)F); ln.ovf_off.ensure((size_t)F);
+    ln.f_loci_lo.ensure((size_t)F); ln.f_loci_n.ensure((size_t)F);
+    ln.status.ensure(1);
+    if (!ln.h_status) FA_HIP(hipHostMalloc((void **)&ln.h_status, sizeof(PassStatus), hipHostMallocDefault));
+    int32_t *const d_stats = ln.status.p->stats;
+    uint64_t *const d_totals = ln.status.p->totals;
+    uint32_t *const d_counters = ln.status.p->counters;
+    unsigned long long *const d_pinfo = ln.status.p->pinfo;
+    int32_t *const d_total_rows = &ln.status.p->total_rows;
     // ---- buffers and tables sized by the speculated bounds ----
     const int smax = sp.smax;
     const int64_t l_cap = sp.l_cap;
@@ -717,68 +788,67 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const int l1_threads = l1_forced ? l1_forced : (std::min(sp.seed_slots, lds_seed_cap_max(sp.smax)) <= 16 * 256 ? 256 : 512);
     const int l1_nt = l1_threads >= 1024 ? 1024 : (l1_threads >= 512 ? 512 : 256);
     const uint32_t seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * l1_nt));
-    w.l_frag.ensure((size_t)l_cap); w.l_seq.ensure((size_t)l_cap); w.l_start.ensure((size_t)l_cap); w.l_end.ensure((size_t)l_cap + 4);
-    w.l_rfirst.ensure((size_t)l_cap); w.l_rlast.ensure((size_t)l_cap + 4);
-    w.l_group.ensure((size_t)l_cap); w.l_shared.ensure((size_t)l_cap); w.l_pos.ensure((size_t)l_cap);
-    w.group_best.ensure((size_t)l_cap + 2);
-    w.l_beg.ensure((size_t)l_cap); w.l_end0.ensure((size_t)l_cap); w.l_last.ensure((size_t)l_cap); w.l_ndrop.ensure((size_t)l_cap);
-    w.l_nev.ensure((size_t)l_cap); w.l_ioff.ensure((size_t)l_cap); w.l_redo.ensure((size_t)l_cap + 4);
-    w.ovf_buf.ensure((size_t)sp.scratch_words + 4);
+    ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
+    ln.l_rfirst.ensure((size_t)l_cap); ln.l_rlast.ensure((size_t)l_cap + 4);
+    ln.l_group.ensure((size_t)l_cap); ln.l_shared.ensure((size_t)l_cap); ln.l_pos.ensure((size_t)l_cap);
+    ln.group_best.ensure((size_t)l_cap + 2);
+    ln.l_beg.ensure((size_t)l_cap); ln.l_end0.ensure((size_t)l_cap); ln.l_last.ensure((size_t)l_cap); ln.l_ndrop.ensure((size_t)l_cap);
+    ln.l_nev.ensure((size_t)l_cap); ln.l_ioff.ensure((size_t)l_cap); ln.l_redo.ensure((size_t)l_cap + 4);
+    ln.ovf_buf.ensure((size_t)sp.scratch_words + 4);
     const bool wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
-    w.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
+    ln.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
 
-    FA_HIP(hipEventRecord(w.ev[0], st));
+    FA_HIP(hipEventRecord(ln.ev[0], st));
     {
       ClearList cl;
-      cl.add(w.status.p, sizeof(PassStatus));
-      cl.add(w.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(w.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
-      cl.add(w.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
-      if (npairs > 0 && first_part) cl.add(w.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long));
+      cl.add(ln.status.p, sizeof(PassStatus));
+      cl.add(ln.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(ln.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
+      cl.add(ln.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
       cl.launch(st);
     }
     // ---- K1 + per-fragment sort/unique ----
-    launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, st);
+    launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st);
     {
       QuerySketchArgs a;
       a.frag_tile_lo = g.d_frag_tile_lo + f0;
-      a.tile_count = w.sk.tile_count.p; a.stage_hash = w.sk.stage_hash.p; a.stage_wpos = w.sk.stage_wpos.p;
+      a.tile_count = ln.sk.tile_count.p; a.stage_hash = ln.sk.stage_hash.p; a.stage_wpos = ln.sk.stage_wpos.p;
       a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
-      a.q_hash = w.q_hash.p; a.q_size = w.q_size.p; a.stats = d_stats; a.qcap = qcap;
+      a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.stats = d_stats; a.qcap = qcap;
       a.sort_cap = (int32_t)(qs_lds / 4);
       if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
       hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
     }
     debug_sync(st, "sketch");
-    FA_HIP(hipEventRecord(w.ev[1], st));
+    FA_HIP(hipEventRecord(ln.ev[1], st));
     // ---- lookup, seed totals and speculation checks ----
     {
       LookupArgs a;
-      a.ix = ix; a.q_hash = w.q_hash.p; a.q_size = w.q_size.p; a.q_off = w.q_off.p; a.q_cnt = w.q_cnt.p;
-      a.n_seeds = w.n_seeds.p; a.totals = d_totals; a.ovf_off = w.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
+      a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p;
+      a.n_seeds = ln.n_seeds.p; a.totals = d_totals; a.ovf_off = ln.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
       hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
-      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, w.n_seeds.p, F, seed_slots, d_totals, w.ovf_off.p,
+      hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, ln.n_seeds.p, F, seed_slots, d_totals, ln.ovf_off.p,
                          d_stats, smax, sp.scratch_words, d_pinfo);
     }
     debug_sync(st, "lookup");
     // ---- L1 ----
     {
       L1Args a;
-      a.ix = ix; a.q_size = w.q_size.p; a.q_off = w.q_off.p; a.q_cnt = w.q_cnt.p; a.n_seeds = w.n_seeds.p;
-      a.ovf_off = w.ovf_off.p; a.ovf_buf = w.ovf_buf.p; a.min_hits_lut = w.lut_min_hits;
-      a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p; a.l_start = w.l_start.p; a.l_end = w.l_end.p; a.l_group = w.l_group.p;
-      a.l_rfirst = w.l_rfirst.p; a.l_rlast = w.l_rlast.p;
+      a.ix = ix; a.q_size = ln.q_size.p; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p; a.n_seeds = ln.n_seeds.p;
+      a.ovf_off = ln.ovf_off.p; a.ovf_buf = ln.ovf_buf.p; a.min_hits_lut = w.lut_min_hits;
+      a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
+      a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p;
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
-      a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
+      a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
       // into LDS-sized chunks at contig boundaries by k_l1_big first; what it cannot cut stays with k_l1's HBM path
       static const bool l1_big = !(getenv("FA_L1_BIG") && atoi(getenv("FA_L1_BIG")) == 0);
       a.big_state = nullptr; a.big_enabled = 0; a.big_cap = 0;
       const int64_t big_room = (int64_t)160 * 1024 - 2048 - ((int64_t)smax + 2) * 16;   // LDS left for a chunk's seeds
       if (l1_big && sp.scratch_words > 0 && big_room >= 4 * 2048) {
-        w.big_state.ensure((size_t)F);
+        ln.big_state.ensure((size_t)F);
         a.big_cap = (uint32_t)std::min<int64_t>((int64_t)L1_BIG_E * L1_BIG_THREADS, big_room / 4 / 256 * 256);
-        a.big_state = w.big_state.p; a.big_enabled = 1;
+        a.big_state = ln.big_state.p; a.big_enabled = 1;
         const size_t lds = l1_big_lds_bytes(a.big_cap, smax);
         if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_l1_big, dim3((unsigned)F), dim3(L1_BIG_THREADS), lds, st, a);
@@ -804,22 +874,22 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       else go(std::integral_constant<int, 256>());
     }
     debug_sync(st, "l1");
-    FA_HIP(hipEventRecord(w.ev[2], st));
+    FA_HIP(hipEventRecord(ln.ev[2], st));
     // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
     {
       L2Args a;
-      a.ix = ix; a.q_hash = w.q_hash.p; a.q_size = w.q_size.p;
-      a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p; a.l_start = w.l_start.p; a.l_end = w.l_end.p; a.l_group = w.l_group.p;
-      a.l_rfirst = w.l_rfirst.p; a.l_rlast = w.l_rlast.p; a.frag_len = m.P.fragment_length;
-      a.l_beg = w.l_beg.p; a.l_end0 = w.l_end0.p; a.l_last = w.l_last.p; a.l_nev = w.l_nev.p; a.l_ioff = w.l_ioff.p; a.l_ndrop = w.l_ndrop.p;
-      a.items = w.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
-      a.l_shared = w.l_shared.p; a.l_pos = w.l_pos.p; a.pass_lut = w.lut_pass; a.group_best = w.group_best.p;
+      a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p;
+      a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
+      a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.frag_len = m.P.fragment_length;
+      a.l_beg = ln.l_beg.p; a.l_end0 = ln.l_end0.p; a.l_last = ln.l_last.p; a.l_nev = ln.l_nev.p; a.l_ioff = ln.l_ioff.p; a.l_ndrop = ln.l_ndrop.p;
+      a.items = ln.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
+      a.l_shared = ln.l_shared.p; a.l_pos = ln.l_pos.p; a.pass_lut = w.lut_pass; a.group_best = ln.group_best.p;
       a.counters = d_counters; a.qcap = qcap; a.cmw = m.cmw;
       a.cnt_slots = smax + 1;
       a.rec_total = (unsigned long long *)(d_totals + 3);
-      a.l_redo = w.l_redo.p;
+      a.l_redo = ln.l_redo.p;
       a.redo_count = d_counters + 3;
-      a.f_loci_lo = w.f_loci_lo.p; a.f_loci_n = w.f_loci_n.p;
+      a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
       // events of one locus staged in LDS per wave of k_l2_events (longer streams are stored directly): a stream holds
@@ -925,48 +995,36 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       }
     }
     debug_sync(st, "l2 scan");
-    FA_HIP(hipEventRecord(w.ev[3], st));
+    FA_HIP(hipEventRecord(ln.ev[3], st));
     // ---- core-genome identity ----
-    int32_t total_rows = 0;
     if (npairs > 0) {
       CgiArgs a;
-      a.ix = ix; a.group_best = w.group_best.p; a.counters = d_counters; a.l_frag = w.l_frag.p; a.l_seq = w.l_seq.p;
-      a.l_pos = w.l_pos.p; a.q_size = w.q_size.p; a.ident_lut = w.lut_ident;
+      a.ix = ix; a.group_best = ln.group_best.p; a.counters = d_counters; a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p;
+      a.l_pos = ln.l_pos.p; a.q_size = ln.q_size.p; a.ident_lut = w.lut_ident;
       a.frag_query = g.d_frag_query + f0; a.frag_qseq = g.d_frag_qseq + f0; a.bins = w.bins.p;
       a.bin_len = m.P.fragment_length - 20;
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
     }
-    if (npairs > 0 && last_part) {
-      RowsArgs ra;
-      ra.bins = w.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
-      ra.row_count = w.row_count.p; ra.row_ident = w.row_ident.p;
-      ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
-      ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag + g0; ra.query_id_base = g0;
-      ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = d_total_rows;
-      hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
-      if (ra.emit) {
-      } else {
-        hipLaunchKernelGGL(k_flag_nonzero, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, npairs, w.row_flag.p);
-        FA_HIP(hipMemsetAsync(w.row_flag.p + npairs, 0, sizeof(int32_t), st));
-        exclusive_sum_i32(w.sk.cub_temp, w.row_flag.p, w.row_off.p, (int)npairs + 1, st);
-        FA_HIP(hipMemcpyAsync(d_total_rows, w.row_off.p + npairs, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, w.row_ident.p, w.row_off.p, m.G,
-                           npairs, g.d_total_frag + g0, g0, rows_dev + row_base, cap - row_base);
-      }
-    }
+    if (npairs > 0 && r.with_rows) { join_lanes(r.lane); launch_rows(ln); rows_lane = r.lane; rows_valid = true; }
     FA_HIP(hipGetLastError());
     debug_sync(st, "cgi");
-    FA_HIP(hipEventRecord(w.ev[4], st));
-    // ---- the one synchronisation of the pass: results, statistics and the speculation verdict ----
-    FA_HIP(hipMemcpyAsync(w.h_status, w.status.p, sizeof(PassStatus), hipMemcpyDeviceToHost, st));
-    FA_HIP(hipEventRecord(w.ev[5], st));
-    FA_HIP(hipStreamSynchronize(st));
-    const int32_t *h_stats = w.h_status->stats;
-    const uint64_t *h_totals = w.h_status->totals;
-    const uint32_t *h_counters = w.h_status->counters;
-    const unsigned long long *h_pinfo = w.h_status->pinfo;
-    total_rows = w.h_status->total_rows;
+    FA_HIP(hipEventRecord(ln.ev[4], st));
+    // ---- the one synchronisation of the part: results, statistics and the speculation verdict ----
+    FA_HIP(hipMemcpyAsync(ln.h_status, ln.status.p, sizeof(PassStatus), hipMemcpyDeviceToHost, st));
+    FA_HIP(hipEventRecord(ln.ev[5], st));
+    ran[r.lane] = true;
+  };
+  // waits for a part and reads its verdict: true = accepted, false = void (its range has to run again)
+  auto finish_part = [&](Run &r) -> bool {
+    Workspace &ln = *lanes[r.lane];
+    fa_mapper::Spec &sp = r.sp;
+    const int64_t F = r.f1 - r.f0;
+    FA_HIP(hipStreamSynchronize(ln.stream));
+    const int32_t *h_stats = ln.h_status->stats;
+    const uint64_t *h_totals = ln.h_status->totals;
+    const uint32_t *h_counters = ln.h_status->counters;
+    const unsigned long long *h_pinfo = ln.h_status->pinfo;
     const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
     const unsigned long long flags = h_pinfo[1];
     // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
@@ -975,7 +1033,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       FA_REQUIRE(F > 1, FA_ERR_UNSUPPORTED, std::string("a single query fragment produces too many ") + what);
       sp.part_frags = std::max<int64_t>(1, std::min<int64_t>(F / 2, (int64_t)((double)F * limit / have * 0.8)));
     };
-    if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); publish_spec(); continue; }
+    if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); publish_spec(sp); return false; }
     // bounds for the next pass (or the repeat of this one)
     if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 16 + 31) / 32 * 32;
     // LDS slots for the seed sort: a quarter of headroom over the largest fragment seen, (LDS per workgroup sets how many fragments a CU works on at once)
@@ -985,34 +1043,79 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     if (flags & SPEC_LOCI) {
       const int64_t want = std::max<int64_t>(sp.l_cap * 2, (int64_t)h_counters[0] + h_counters[0] / 4);
       const int64_t l_max = (1LL << 31) - 64;
-      if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); publish_spec(); continue; }
+      if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); publish_spec(sp); return false; }
       sp.l_cap = std::min(want, l_max);
     }
     if (flags & SPEC_EVENTS) {
-      if (h_pinfo[0] > items_max) { shrink_part((double)h_pinfo[0], (double)items_max, "slide events"); publish_spec(); continue; }
+      if (h_pinfo[0] > items_max) { shrink_part((double)h_pinfo[0], (double)items_max, "slide events"); publish_spec(sp); return false; }
       sp.items_cap = std::min<uint64_t>(items_max, std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4));
     }
-    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; publish_spec(); continue; }   // void part: run it again
-    if (h_counters[3] > 0 && !sp.redo) { sp.redo = true; publish_spec(); continue; }   // loci overflowed the byte state and the wide pass was not launched
+    if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; publish_spec(sp); return false; }   // void part: run it again
+    if (h_counters[3] > 0 && !sp.redo) { sp.redo = true; publish_spec(sp); return false; }   // loci overflowed the byte state and the wide pass was not launched
     if (slots_changed) {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;
     }
-    publish_spec();
+    publish_spec(sp);
     // ---- accepted ----
     float ms;
-    for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, w.ev[i], w.ev[i + 1])); w.last_ms[i] += ms; }
-    FA_HIP(hipEventElapsedTime(&ms, w.ev[0], w.ev[5]));
-    w.last_ms[4] += ms;
-    w.last_loci = h_counters[0];
-    w.last_items = h_pinfo[0];
+    for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, ln.ev[i], ln.ev[i + 1])); w.last_ms[i] += ms; }
+    ln.last_F = F;
+    ln.last_loci = h_counters[0];
+    ln.last_items = h_pinfo[0];
     w.last_ms[5] += (float)h_totals[3];   // reference records inside the locus ranges of this call (roofline line)
     w.last_ms[6] += (float)h_counters[0];
     w.last_ms[7] += (float)h_pinfo[0];    // slide events
     w.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
-    if (last_part) nrows = total_rows;
-    f0 = f1;
-    attempt = 0;
+    return true;
+  };
+
+  while (!todo.empty() || !flight.empty()) {
+    // launch on every free lane
+    for (int i = 0; i < n_lanes && !todo.empty(); i++) {
+      if (busy[i]) continue;
+      FA_REQUIRE(attempts < 40 + 4 * (int)(F_total / std::max<int64_t>(1, std::min(auto_part, sp.part_frags)) + 1), FA_ERR_INTERNAL,
+                 "query pass did not converge on its buffer sizes");
+      attempts++;
+      fetch_spec();
+      auto range = todo.front(); todo.pop_front();
+      const int64_t f1 = std::min(range.second, range.first + std::max<int64_t>(1, std::min(auto_part, sp.part_frags)));
+      if (f1 < range.second) todo.emplace_front(f1, range.second);
+      Run r{i, range.first, f1, sp, todo.empty() && npairs > 0};
+      if (r.with_rows) rows_valid = false;
+      launch_part(r);
+      busy[i] = true;
+      flight.push_back(r);
+    }
+    // the oldest part in flight
+    Run r = flight.front(); flight.pop_front();
+    const bool ok = finish_part(r);
+    busy[r.lane] = false;
+    if (!ok) {
+      todo.emplace_front(r.f0, r.f1);
+      rows_valid = false;                     // (rows formed meanwhile lack this part)
+    }
+  }
+  int64_t nrows = 0;
+  if (npairs > 0) {
+    if (!rows_valid) {
+      // a part was repeated after the rows had been formed: form them again, behind everything
+      Workspace &ln = w;
+      join_lanes(0);
+      FA_HIP(hipMemsetAsync(&ln.status.p->counters[4], 0, sizeof(uint32_t), ln.stream));
+      FA_HIP(hipMemsetAsync(&ln.status.p->total_rows, 0, sizeof(int32_t), ln.stream));
+      launch_rows(ln);
+      FA_HIP(hipMemcpyAsync(ln.h_status, ln.status.p, sizeof(PassStatus), hipMemcpyDeviceToHost, ln.stream));
+      FA_HIP(hipStreamSynchronize(ln.stream));
+      rows_lane = 0;
+    }
+    nrows = lanes[rows_lane]->h_status->total_rows;
+  }
+  {
+    // wall time of the pass on the device: from the first launch to the end of the lane that finished last
+    float ms = 0, best = 0;
+    for (int i = 0; i < n_lanes; i++) if (ran[i] && hipEventElapsedTime(&ms, w.ev_bins, lanes[i]->ev[5]) == hipSuccess) best = std::max(best, ms);
+    w.last_ms[4] += best;
   }
   FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
   return nrows;
@@ -1639,30 +1742,41 @@ int fa_mapper_query(fa_mapper *m, const void *const *contigs, const int64_t *len
   });
 }
 
+// The parts of the last pass, in fragment order: a pass is pipelined over up to three lanes (run_query_pass), every
+// lane still holds the intermediates of the last part it ran.
+static std::vector<Workspace *> lanes_of_last_pass(Workspace &w) {
+  std::vector<Workspace *> v;
+  for (Workspace *x : {&w, w.sub[0].get(), w.sub[1].get()}) if (x && x->serial == w.serial && x->last_F > 0) v.push_back(x);
+  std::sort(v.begin(), v.end(), [](const Workspace *a, const Workspace *b) { return a->last_f0 < b->last_f0; });
+  return v;
+}
 int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t *n) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);
     bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
-    const uint32_t L = w.last_loci;
-    std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)w.last_F);
-    if (L) {
-      w.l_frag.download(lf.data(), L, w.stream); w.l_seq.download(ls.data(), L, w.stream);
-      w.l_pos.download(lp.data(), L, w.stream); w.l_shared.download(lsh.data(), L, w.stream);
-    }
-    if (w.last_F) w.q_size.download(qs.data(), (size_t)w.last_F, w.stream);
-    FA_HIP(hipStreamSynchronize(w.stream));
     ensure_luts(*m, 1);
     int64_t k = 0;
-    for (uint32_t i = 0; i < L; i++) {
-      int s = qs[lf[i]];
-      if (lsh[i] < m->stats.pass_shared[s]) continue;
-      if (k < cap) {
-        fa_mapping r;
-        r.query_seq_id = lf[i]; r.ref_seq_id = ls[i]; r.ref_start_pos = lp[i]; r.sketch_size = s; r.conserved = lsh[i]; r.query_id = 0;
-        out[k] = r;
+    for (Workspace *x : lanes_of_last_pass(w)) {
+      const uint32_t L = x->last_loci;
+      std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)x->last_F);
+      if (L) {
+        x->l_frag.download(lf.data(), L, x->stream); x->l_seq.download(ls.data(), L, x->stream);
+        x->l_pos.download(lp.data(), L, x->stream); x->l_shared.download(lsh.data(), L, x->stream);
       }
-      k++;
+      x->q_size.download(qs.data(), (size_t)x->last_F, x->stream);
+      FA_HIP(hipStreamSynchronize(x->stream));
+      for (uint32_t i = 0; i < L; i++) {
+        int s = qs[lf[i]];
+        if (lsh[i] < m->stats.pass_shared[s]) continue;
+        if (k < cap) {
+          fa_mapping r;
+          r.query_seq_id = lf[i] + (int32_t)(x->last_f0 - w.pass_f0); r.ref_seq_id = ls[i]; r.ref_start_pos = lp[i]; r.sketch_size = s;
+          r.conserved = lsh[i]; r.query_id = 0;
+          out[k] = r;
+        }
+        k++;
+      }
     }
     *n = k;
   });
@@ -1672,14 +1786,18 @@ int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *rs
     std::lock_guard<std::mutex> lock(m->mtx);
     bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
-    const uint32_t L = w.last_loci;
-    *n = L;
-    size_t c = (size_t)std::min<int64_t>(L, cap);
-    if (c) {
-      w.l_frag.download(frag, c, w.stream); w.l_seq.download(seq_id, c, w.stream);
-      w.l_start.download(rs, c, w.stream); w.l_end.download(re, c, w.stream);
-      FA_HIP(hipStreamSynchronize(w.stream));
+    int64_t k = 0;
+    for (Workspace *x : lanes_of_last_pass(w)) {
+      const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>(x->last_loci, cap - k));
+      if (c) {
+        x->l_frag.download(frag + k, c, x->stream); x->l_seq.download(seq_id + k, c, x->stream);
+        x->l_start.download(rs + k, c, x->stream); x->l_end.download(re + k, c, x->stream);
+        FA_HIP(hipStreamSynchronize(x->stream));
+        for (size_t i = 0; i < c; i++) frag[k + i] += (int32_t)(x->last_f0 - w.pass_f0);
+      }
+      k += x->last_loci;
     }
+    *n = k;
   });
 }
 int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashes, int32_t cap, int32_t *sketch_size) {
@@ -1687,12 +1805,17 @@ int fa_mapper_debug_query_sketch(fa_mapper *m, int64_t fragment, uint32_t *hashe
     std::lock_guard<std::mutex> lock(m->mtx);
     bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
-    FA_REQUIRE(fragment >= 0 && fragment < w.last_F, FA_ERR_INVALID, "fragment out of range");
-    int32_t s = 0;
-    FA_HIP(hipMemcpy(&s, w.q_size.p + fragment, 4, hipMemcpyDeviceToHost));
-    *sketch_size = s;
-    int c = std::min(s, cap);
-    if (c > 0) FA_HIP(hipMemcpy(hashes, w.q_hash.p + (size_t)fragment * m->qcap, (size_t)c * 4, hipMemcpyDeviceToHost));
+    for (Workspace *x : lanes_of_last_pass(w)) {
+      const int64_t local = fragment - (x->last_f0 - w.pass_f0);
+      if (local < 0 || local >= x->last_F) continue;
+      int32_t s = 0;
+      FA_HIP(hipMemcpy(&s, x->q_size.p + local, 4, hipMemcpyDeviceToHost));
+      *sketch_size = s;
+      int c = std::min(s, cap);
+      if (c > 0) FA_HIP(hipMemcpy(hashes, x->q_hash.p + (size_t)local * m->qcap, (size_t)c * 4, hipMemcpyDeviceToHost));
+      return;
+    }
+    throw Error(FA_ERR_INVALID, "fragment out of range");
   });
 }
 int fa_debug_sketch_sequence(const fa_params *params, const void *data, int64_t length, int char_width, uint32_t *hash,
@@ -1757,9 +1880,13 @@ int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, in
     std::lock_guard<std::mutex> lock(m->mtx);
     bind_device(m->device);
     Workspace &w = m->ws[m->last_ws];
-    *n = w.last_loci;
-    const size_t c = (size_t)std::min<int64_t>(w.last_loci, cap);
-    if (c) { w.l_nev.download(events, c, w.stream); FA_HIP(hipStreamSynchronize(w.stream)); }
+    int64_t k = 0;
+    for (Workspace *x : lanes_of_last_pass(w)) {
+      const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>(x->last_loci, cap - k));
+      if (c) { x->l_nev.download(events + k, c, x->stream); FA_HIP(hipStreamSynchronize(x->stream)); }
+      k += x->last_loci;
+    }
+    *n = k;
   });
 }
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {

@@ -1139,6 +1139,40 @@ def test_concurrent_queries_on_one_mapper():
     assert out[0] + out[1] == want
 
 
+@pytest.mark.parametrize("lanes,part", [(3, 40), (2, 0)])
+def test_parts_pipelined_over_lanes_match(lanes, part):
+    # FA_QUERY_LANES > 1 runs the parts of a pass on sub-workspaces with their own streams (run_query_pass); with tiny
+    # buffers the parts are also declared void and repeated while other parts are in flight: same rows, same mappings
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, os, json
+        sys.path.insert(0, %r)
+        sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        import test_gpu_parity as T
+        g = syn.rng(3131)
+        anc = syn.random_codes(g, 900_000)
+        refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.01, 0.05, 0.1, 0.15)]
+        q = [syn.to_ascii(syn.mutate_codes(g, anc, 0.03))]
+        mapper, hits, ohits, det = T.run_both({}, refs, q, threads=8)
+        if not os.environ.get("FA_PASS_FRAGMENTS"):      # (the stage getters keep the last part of every lane only)
+            assert T.gpu_mappings(mapper) == T.oracle_mappings(det), "mappings"
+        assert T.hit_tuples(hits) == ohits and len(ohits) == 4, "hits"
+        ms = (T.C.c_float * 16)(); T.lib.fa_mapper_last_timings(mapper._h, ms, 16)
+        print(json.dumps({"retries": ms[9], "loci": ms[6]}))
+    """) % (ROOT, ROOT)
+    env = dict(os.environ, FA_QUERY_LANES=str(lanes), FA_LANE_MIN_FRAGMENTS="64")
+    if part:
+        env.update(FA_PASS_FRAGMENTS=str(part), FA_LOCI_CAP_MIN="64", FA_EVENTS_CAP_MIN="4096")
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    out = json.loads(res.stdout.strip().splitlines()[-1])
+    assert out["loci"] > 500 and (out["retries"] > 0 if part else True), out
+
+
 def test_device_memory_is_stable():
     """Repeated queries, resident batches and mapper life cycles must not grow the device allocation (scripts/check_leaks.py)."""
     import subprocess
