@@ -16,6 +16,7 @@
 #include <string>
 #include <utility>
 #include <vector>
+#include <cstddef>
 #include <deque>
 
 #include "fa_common.h"
@@ -288,13 +289,61 @@ struct fa_genomes {
 };
 
 // Every small counter / statistic of a pass in ONE device block, mirrored into pinned host memory by one copy.
+static uint64_t env_u64(const char *name, uint64_t dflt) {
+  const char *e = getenv(name);
+  long long x = e ? atoll(e) : 0;
+  return x > 0 ? (uint64_t)x : dflt;
+}
+
 struct PassStatus {
   int32_t stats[4];                 // [0] largest query sketch
   int32_t total_rows, pad0[3];
   uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
   uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
   unsigned long long pinfo[4];      // slide events reserved, speculation flags
+  unsigned long long stamp[6];      // stage_stamp: pass start, lookup, L2, CGI, end (100 MHz ticks); not cleared with the rest
+  uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
+
+// The last kernel of a pass: copies the status block -- and, for a one-query call whose rows go to the host, the rows --
+// into pinned host memory and then releases the pass number.  The host polls that word instead of waiting for a
+// device-to-host copy and a stream synchronisation, which together return tens of microseconds after the GPU is done
+// (more on a slow host: the step time of the bench varied by 0.09 ms between boxes on that account).
+__global__ void k_publish_status(PassStatus *dev, PassStatus *host, uint32_t seq, const fa_cgi_row *rows_dev, fa_cgi_row *rows_host, int64_t cap) {
+  constexpr int W = (int)(offsetof(PassStatus, seq) / 4);
+  if (threadIdx.x == 0) {
+    dev->stamp[4] = __builtin_amdgcn_s_memrealtime();
+    if (dev->stamp[3] == 0) dev->stamp[3] = dev->stamp[4];        // (a pass without pairs has no CGI stage)
+  }
+  __syncthreads();
+  const uint32_t *s = (const uint32_t *)dev;
+  uint32_t *d = (uint32_t *)host;
+  for (int i = threadIdx.x; i < W; i += blockDim.x) d[i] = s[i];
+  if (rows_host) {
+    const int64_t n = std::min<int64_t>(dev->total_rows, cap);
+    static_assert(sizeof(fa_cgi_row) % 4 == 0, "rows are copied word by word");
+    const uint32_t *rs = (const uint32_t *)rows_dev;
+    uint32_t *rd = (uint32_t *)rows_host;
+    for (int64_t i = threadIdx.x; i < n * (int64_t)(sizeof(fa_cgi_row) / 4); i += blockDim.x) rd[i] = rs[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// host side of k_publish_status: polls for FA_SPIN_US microseconds (default 20 000), then sleeps on the stream
+static void wait_published(const PassStatus *h, uint32_t seq, hipStream_t st) {
+  static const uint64_t spin_us = env_u64("FA_SPIN_US", 20000);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint64_t it = 0; spin_us; it++) {
+    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return;
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+    if ((it & 255) == 255 && (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
+  }
+  FA_HIP(hipStreamSynchronize(st));
+  FA_REQUIRE(__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq, FA_ERR_INTERNAL, "the status of the pass was not published");
+}
 
 // Everything one query call owns: its stream, every intermediate of the pipeline, its status block and timing events.
 struct Workspace {
@@ -303,7 +352,8 @@ struct Workspace {
   SketchWork sk;
   DevBuf<uint32_t> q_hash, q_off, q_cnt, n_seeds, ovf_off, ovf_buf;
   DevBuf<PassStatus> status;
-  PassStatus *h_status = nullptr;     // pinned
+  PassStatus *h_status = nullptr;     // pinned, written by k_publish_status
+  uint32_t seq = 0;                   // passes published on this workspace
   DevBuf<int32_t> q_size, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
   DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
   DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
@@ -583,17 +633,12 @@ static uint32_t lds_seed_cap_max(int smax) {
   return (uint32_t)std::max<int64_t>(256, room / 4 / 256 * 256);
 }
 
-static uint64_t env_u64(const char *name, uint64_t dflt) {
-  const char *e = getenv(name);
-  long long x = e ? atoll(e) : 0;
-  return x > 0 ? (uint64_t)x : dflt;
-}
 
 // zero several device ranges with one launch (every DevBuf is at least 16-byte aligned; sizes are rounded up to 16 bytes,
 // which stays inside the allocation because ensure() callers below add slack)
 struct ClearList {
   ClearArgs a;
-  ClearList() { a.count = 0; }
+  ClearList() { a.count = 0; a.stamp = nullptr; }
   void add(void *p, size_t bytes) {
     if (!bytes) return;
     a.ptr[a.count] = (uint4 *)p; a.n16[a.count] = (bytes + 15) / 16; a.count++;
@@ -637,7 +682,7 @@ static int64_t pass_fragments() {
 // the 32-bit offsets of the workspace can address: the parts share the CGI bin table (step 2 of computeCGI is an
 // atomicMax, so it simply accumulates) and the rows are formed after the last part.
 static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
-                              int64_t row_base) {
+                              int64_t row_base, fa_cgi_row *host_rows = nullptr) {
   hipStream_t st = w.stream;
   const int64_t range_f0 = g.genome_frag_lo[g0], range_f1 = g.genome_frag_lo[g1];
   const int NQ = g1 - g0;
@@ -719,7 +764,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
   for (int i = 0; i < n_lanes; i++) for (int e = 0; e < 6; e++) if (!lanes[i]->ev[e]) FA_HIP(hipEventCreate(&lanes[i]->ev[e]));
   if (!w.ev_bins) FA_HIP(hipEventCreate(&w.ev_bins));
   if (npairs > 0) FA_HIP(hipMemsetAsync(w.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
-  FA_HIP(hipEventRecord(w.ev_bins, st));
+  if (n_lanes > 1) FA_HIP(hipEventRecord(w.ev_bins, st));
 
   struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; };
   std::deque<std::pair<int64_t, int64_t>> todo;
@@ -728,6 +773,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
   bool busy[3] = {false, false, false}, ran[3] = {false, false, false};
   bool rows_valid = false;
   int rows_lane = -1;
+  unsigned long long t_begin = ~0ULL, t_end = 0;
   int attempts = 0;
   // the lane that forms the rows waits for the bins of the parts launched on the other lanes
   auto join_lanes = [&](int me) {
@@ -772,7 +818,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ln.q_size.ensure((size_t)F); ln.n_seeds.ensure((size_t)F); ln.ovf_off.ensure((size_t)F);
     ln.f_loci_lo.ensure((size_t)F); ln.f_loci_n.ensure((size_t)F);
     ln.status.ensure(1);
-    if (!ln.h_status) FA_HIP(hipHostMalloc((void **)&ln.h_status, sizeof(PassStatus), hipHostMallocDefault));
+    if (!ln.h_status) {
+      FA_HIP(hipHostMalloc((void **)&ln.h_status, sizeof(PassStatus), hipHostMallocMapped | hipHostMallocCoherent));
+      memset(ln.h_status, 0, sizeof(PassStatus));
+    }
     int32_t *const d_stats = ln.status.p->stats;
     uint64_t *const d_totals = ln.status.p->totals;
     uint32_t *const d_counters = ln.status.p->counters;
@@ -798,10 +847,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const bool wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
     ln.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
 
-    FA_HIP(hipEventRecord(ln.ev[0], st));
     {
       ClearList cl;
-      cl.add(ln.status.p, sizeof(PassStatus));
+      cl.add(ln.status.p, offsetof(PassStatus, stamp));
+      cl.a.stamp = &ln.status.p->stamp[0];
       cl.add(ln.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(ln.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(ln.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
       cl.launch(st);
@@ -819,10 +868,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
     }
     debug_sync(st, "sketch");
-    FA_HIP(hipEventRecord(ln.ev[1], st));
     // ---- lookup, seed totals and speculation checks ----
     {
       LookupArgs a;
+      a.stamp = &ln.status.p->stamp[1];
       a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p;
       a.n_seeds = ln.n_seeds.p; a.totals = d_totals; a.ovf_off = ln.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
       hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
@@ -874,10 +923,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       else go(std::integral_constant<int, 256>());
     }
     debug_sync(st, "l1");
-    FA_HIP(hipEventRecord(ln.ev[2], st));
     // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
     {
       L2Args a;
+      a.stamp = &ln.status.p->stamp[2];
       a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p;
       a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
       a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.frag_len = m.P.fragment_length;
@@ -995,10 +1044,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       }
     }
     debug_sync(st, "l2 scan");
-    FA_HIP(hipEventRecord(ln.ev[3], st));
     // ---- core-genome identity ----
     if (npairs > 0) {
       CgiArgs a;
+      a.stamp = &ln.status.p->stamp[3];
       a.ix = ix; a.group_best = ln.group_best.p; a.counters = d_counters; a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p;
       a.l_pos = ln.l_pos.p; a.q_size = ln.q_size.p; a.ident_lut = w.lut_ident;
       a.frag_query = g.d_frag_query + f0; a.frag_qseq = g.d_frag_qseq + f0; a.bins = w.bins.p;
@@ -1009,10 +1058,15 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     if (npairs > 0 && r.with_rows) { join_lanes(r.lane); launch_rows(ln); rows_lane = r.lane; rows_valid = true; }
     FA_HIP(hipGetLastError());
     debug_sync(st, "cgi");
-    FA_HIP(hipEventRecord(ln.ev[4], st));
-    // ---- the one synchronisation of the part: results, statistics and the speculation verdict ----
-    FA_HIP(hipMemcpyAsync(ln.h_status, ln.status.p, sizeof(PassStatus), hipMemcpyDeviceToHost, st));
-    FA_HIP(hipEventRecord(ln.ev[5], st));
+    if (n_lanes > 1) FA_HIP(hipEventRecord(ln.ev[4], st));         // (join_lanes: the bins of this part)
+    // ---- the one hand-over of the part: results, statistics and the speculation verdict ----
+    {
+      PassStatus *h_dev = nullptr;
+      FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
+      const bool to_host = r.with_rows && host_rows != nullptr;
+      hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, st, ln.status.p, h_dev, ++ln.seq, rows_dev + row_base, to_host ? host_rows + row_base : nullptr,
+                         cap - row_base);
+    }
     ran[r.lane] = true;
   };
   // waits for a part and reads its verdict: true = accepted, false = void (its range has to run again)
@@ -1020,7 +1074,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     Workspace &ln = *lanes[r.lane];
     fa_mapper::Spec &sp = r.sp;
     const int64_t F = r.f1 - r.f0;
-    FA_HIP(hipStreamSynchronize(ln.stream));
+    wait_published(ln.h_status, ln.seq, ln.stream);
     const int32_t *h_stats = ln.h_status->stats;
     const uint64_t *h_totals = ln.h_status->totals;
     const uint32_t *h_counters = ln.h_status->counters;
@@ -1058,8 +1112,9 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     }
     publish_spec(sp);
     // ---- accepted ----
-    float ms;
-    for (int i = 0; i < 4; i++) { FA_HIP(hipEventElapsedTime(&ms, ln.ev[i], ln.ev[i + 1])); w.last_ms[i] += ms; }
+    const unsigned long long *stamp = ln.h_status->stamp;              // 100 MHz ticks
+    for (int i = 0; i < 4; i++) w.last_ms[i] += (float)((double)(stamp[i + 1] - stamp[i]) * 1e-5);
+    t_begin = std::min(t_begin, stamp[0]); t_end = std::max(t_end, stamp[4]);
     ln.last_F = F;
     ln.last_loci = h_counters[0];
     ln.last_items = h_pinfo[0];
@@ -1105,18 +1160,16 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       FA_HIP(hipMemsetAsync(&ln.status.p->counters[4], 0, sizeof(uint32_t), ln.stream));
       FA_HIP(hipMemsetAsync(&ln.status.p->total_rows, 0, sizeof(int32_t), ln.stream));
       launch_rows(ln);
-      FA_HIP(hipMemcpyAsync(ln.h_status, ln.status.p, sizeof(PassStatus), hipMemcpyDeviceToHost, ln.stream));
-      FA_HIP(hipStreamSynchronize(ln.stream));
+      PassStatus *h_dev = nullptr;
+      FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
+      hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, ln.stream, ln.status.p, h_dev, ++ln.seq, rows_dev + row_base,
+                         host_rows ? host_rows + row_base : nullptr, cap - row_base);
+      wait_published(ln.h_status, ln.seq, ln.stream);
       rows_lane = 0;
     }
     nrows = lanes[rows_lane]->h_status->total_rows;
   }
-  {
-    // wall time of the pass on the device: from the first launch to the end of the lane that finished last
-    float ms = 0, best = 0;
-    for (int i = 0; i < n_lanes; i++) if (ran[i] && hipEventElapsedTime(&ms, w.ev_bins, lanes[i]->ev[5]) == hipSuccess) best = std::max(best, ms);
-    w.last_ms[4] += best;
-  }
+  if (t_end > t_begin) w.last_ms[4] += (float)((double)(t_end - t_begin) * 1e-5);   // device wall time of the pass
   FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
   return nrows;
 }
@@ -1127,21 +1180,31 @@ static int64_t run_query(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_
   for (float &x : w.last_ms) x = 0;
   fa_cgi_row *dst = rows;
   if (!rows_device) { w.rows_dev.ensure((size_t)std::max<int64_t>(cap, 1)); dst = w.rows_dev.p; }
+  // a call that is ONE pass and returns a modest number of rows to the host gets them written into pinned memory by the
+  // pass's last kernel (k_publish_status): no device-to-host copy, no second synchronisation
+  const bool one_pass = count > 0 && g.genome_frag_lo[first + count] - g.genome_frag_lo[first] <= pass_fragments();
+  fa_cgi_row *host_rows = nullptr;
+  if (!rows_device && one_pass && cap <= 65536) {
+    w.pin_rows.ensure(std::max<size_t>((size_t)cap * sizeof(fa_cgi_row), 4096));
+    FA_HIP(hipHostGetDevicePointer((void **)&host_rows, w.pin_rows.p, 0));
+  }
   int64_t nrows = 0;
   int32_t g0 = first;
   while (g0 < first + count) {
     int32_t g1 = g0 + 1;
     while (g1 < first + count && g.genome_frag_lo[g1 + 1] - g.genome_frag_lo[g0] <= pass_fragments()) g1++;
     // frag_query is batch-wide: the bins of a pass are indexed by (genome - g0), handled through the pointer offset below
-    nrows += run_query_pass(m, w, g, g0, g1, dst, cap, nrows);
+    nrows += run_query_pass(m, w, g, g0, g1, dst, cap, nrows, host_rows);
     g0 = g1;
   }
   if (!rows_device && nrows) {
-    // through pinned memory: a device-to-pageable copy of a few KB costs more in staging than the copy itself
     const size_t bytes = (size_t)nrows * sizeof(fa_cgi_row);
-    w.pin_rows.ensure(std::max<size_t>(bytes, 4096));
-    FA_HIP(hipMemcpyAsync(w.pin_rows.p, w.rows_dev.p, bytes, hipMemcpyDeviceToHost, w.stream));
-    FA_HIP(hipStreamSynchronize(w.stream));
+    if (!host_rows) {
+      // through pinned memory: a device-to-pageable copy of a few KB costs more in staging than the copy itself
+      w.pin_rows.ensure(std::max<size_t>(bytes, 4096));
+      FA_HIP(hipMemcpyAsync(w.pin_rows.p, w.rows_dev.p, bytes, hipMemcpyDeviceToHost, w.stream));
+      FA_HIP(hipStreamSynchronize(w.stream));
+    }
     memcpy(rows, w.pin_rows.p, bytes);
   }
   return nrows;

@@ -25,6 +25,14 @@
 
 namespace fa {
 
+// Stage timings of a query pass without host-side events: the first thread of the first kernel of every stage leaves
+// the chip-wide 100 MHz counter in the pass's status block (the kernels of a pass run one after the other on a stream,
+// so the difference of two stamps is the time of everything in between).
+__device__ __forceinline__ void stage_stamp(unsigned long long *stamp) {
+  if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
+}
+
+
 constexpr int MAP_THREADS = 256;
 constexpr int L1_STAGE = 256;     // loci of one fragment merged in LDS by k_l1 (more fall back to a second pass)
 constexpr uint32_t SEED_PAD = 0xFFFFFFFFu;
@@ -375,9 +383,11 @@ struct LookupArgs {
   uint32_t *ovf_off;     // [F] offset into the overflow scratch for fragments whose seeds do not fit LDS
   int32_t qcap;
   uint32_t lds_seed_cap;
+  unsigned long long *stamp;       // stage_stamp: start of the lookup + L1 stage
 };
 
 __global__ __launch_bounds__(MAP_THREADS) void k_lookup(LookupArgs a) {
+  stage_stamp(a.stamp);
   const int f = blockIdx.x, tid = threadIdx.x;
   const int s = a.q_size[f];
   __shared__ uint32_t red[MAP_THREADS / 64];
@@ -1104,6 +1114,7 @@ struct L2Args {
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
   const uint32_t *f_loci_lo, *f_loci_n;   // [F] loci of each fragment
+  unsigned long long *stamp;         // stage_stamp: start of the L2 stage
   int32_t dbg;                       // FA_FUSED_DEBUG (timing experiments only, results are void): 1 = slider idles,
                                      // 2 = producer composes no events, 4 = producer issues no loads
 };
@@ -1145,6 +1156,7 @@ __host__ __device__ inline size_t ev_sketch_bytes(int cnt_slots) { return ((size
 template <typename T, bool PACKED>
 __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
+  stage_stamp(a.stamp);
   uint32_t *Q = (uint32_t *)lds;                                     // [s + EV_PROBE], staged once per fragment, with sentinels
   constexpr int QT_BITS = EV_QT_BITS;
   __shared__ uint16_t QT[(1 << QT_BITS) + 2];
@@ -1597,6 +1609,7 @@ __device__ __forceinline__ void lds_barrier() {
 template <typename T, typename ST, bool REDO, int FU_C, int NPROD>
 __global__ __launch_bounds__(64 * (1 + NPROD), (NPROD == 2 && FU_C == 8) ? 6 : 4) void k_l2_fused(L2Args a, int64_t n_frag) {
   extern __shared__ __align__(16) unsigned char lds[];
+  if (REDO == false) stage_stamp(a.stamp);
   constexpr int FU_THREADS = 64 * (1 + NPROD);
   constexpr int FU_UPI = 64 / FU_C;                    // loci per producer iteration (of one wave)
   constexpr int FU_ITERS = 64 / NPROD / FU_UPI;        // producer iterations per row (of one wave)
@@ -1922,9 +1935,11 @@ struct CgiArgs {
   unsigned long long *bins;     // [NQ * total_bins]
   int32_t bin_len;              // fragment_length - 20
   int32_t query_base;           // first query genome of this pass (frag_query is batch-wide)
+  unsigned long long *stamp;    // stage_stamp: start of the CGI stage
 };
 
 __global__ void k_cgi_bins(CgiArgs a) {
+  stage_stamp(a.stamp);
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
   if (a.counters[2] || g >= a.counters[1]) return;
   unsigned long long best = a.group_best[g];
@@ -2059,8 +2074,10 @@ struct ClearArgs {
   uint4 *ptr[8];
   uint64_t n16[8];
   int count;
+  unsigned long long *stamp;       // the stamps of the pass: [0] = its start (see stage_stamp)
 };
 __global__ __launch_bounds__(256) void k_clear(ClearArgs a) {
+  if (a.stamp && blockIdx.x == 0 && threadIdx.x == 0) { a.stamp[0] = __builtin_amdgcn_s_memrealtime(); a.stamp[3] = 0; }   // [3]: CGI stage, if any
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (int r = 0; r < a.count; r++)
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n16[r]; i += stride) a.ptr[r][i] = make_uint4(0, 0, 0, 0);
