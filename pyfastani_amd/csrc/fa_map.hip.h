@@ -1986,20 +1986,32 @@ __global__ __launch_bounds__(256) void k_cgi_rows(RowsArgs a) {
     const int x0 = a.genome_bin[g], x1 = a.genome_bin[g + 1];
     int cnt = 0;
     float sum = 0.0f;
-    for (int x = x0; x < x1; x += 512) {
-      unsigned long long v[8];
+    // the loads of up to 2048 bins are issued together (one round trip to HBM for a 5 Mb genome); only the upper word
+    // of a bin -- the identity as float bits, never zero for a mapped bin -- is kept
+    constexpr int CGI_BATCH = 32;
+    for (int x = x0; x < x1; x += 64 * CGI_BATCH) {
+      uint32_t bits[CGI_BATCH];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = (x + 64 * u + lane < x1) ? b[x + 64 * u + lane] : 0ULL;
+      for (int u = 0; u < CGI_BATCH; u++) bits[u] = (x + 64 * u + lane < x1) ? (uint32_t)(b[x + 64 * u + lane] >> 32) : 0u;
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const uint64_t any = __ballot(v[u] != 0ULL);
+      for (int u = 0; u < CGI_BATCH; u++) {
+        const uint64_t any = __ballot(bits[u] != 0u);
         if (any == 0) continue;                                    // wave-uniform
         cnt += __popcll(any);
         // empty bins hold +0.0f and x + 0.0f == x exactly, so adding all 64 lanes in lane order IS the reference's
         // sequential sum over the non-empty bins; constant lane indices keep the chain at one v_readlane + v_add each
-        const int bits = (int)(uint32_t)(v[u] >> 32);
+        // (sixteen lanes are read into scalar registers before their sixteen dependent additions: back to back, a
+        // v_readlane and the v_add that consumes it wait on each other's scalar operand)
 #pragma unroll
-        for (int src = 0; src < 64; src++) sum += __uint_as_float((uint32_t)__builtin_amdgcn_readlane(bits, src));
+        for (int base = 0; base < 64; base += 16) {
+          float part[16];
+#pragma unroll
+          for (int k = 0; k < 16; k++) part[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)bits[u], base + k));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int k = 0; k < 16; k++) sum += part[k];
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     if (lane == 0) {
