@@ -300,7 +300,8 @@ struct PassStatus {
   int32_t total_rows, pad0[3];
   uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
   uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
-  unsigned long long pinfo[4];      // slide events reserved, speculation flags
+  unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
+  unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
   unsigned long long stamp[6];      // stage_stamp: pass start, lookup, L2, CGI, end (100 MHz ticks); not cleared with the rest
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
@@ -331,6 +332,12 @@ __global__ void k_publish_status(PassStatus *dev, PassStatus *host, uint32_t seq
   if (threadIdx.x == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // host side of k_publish_status: polls for FA_SPIN_US microseconds (default 20 000), then sleeps on the stream
+// regions of the event arena used by a part of F fragments (L2Args::n_regions): a power of two, one per eight fragments
+static uint32_t ev_regions_for(int64_t F) {
+  uint32_t n = 1;
+  while (n < (uint32_t)EV_REGIONS && (int64_t)n * 16 <= F) n <<= 1;
+  return n;
+}
 static void wait_published(const PassStatus *h, uint32_t seq, hipStream_t st) {
   static const uint64_t spin_us = env_u64("FA_SPIN_US", 20000);
   const auto t0 = std::chrono::steady_clock::now();
@@ -936,6 +943,9 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.counters = d_counters; a.qcap = qcap; a.cmw = m.cmw;
       a.cnt_slots = smax + 1;
       a.rec_total = (unsigned long long *)(d_totals + 3);
+      a.ev_region = ln.status.p->ev_region; a.rec_region = ln.status.p->rec_region;
+      a.n_regions = ev_regions_for(F);
+      a.region_cap = (sp.items_cap / a.n_regions) & ~7ULL;
       a.l_redo = ln.l_redo.p;
       a.redo_count = d_counters + 3;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
@@ -1080,6 +1090,11 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const uint32_t *h_counters = ln.h_status->counters;
     const unsigned long long *h_pinfo = ln.h_status->pinfo;
     const uint64_t total_seeds = h_totals[0], max_seeds = h_totals[1];
+    uint64_t events_total = h_pinfo[0], records_total = h_totals[3], ev_region_max = 0;
+    for (int i = 0; i < EV_REGIONS; i++) {
+      events_total += ln.h_status->ev_region[i]; records_total += ln.h_status->rec_region[i];
+      ev_region_max = std::max<uint64_t>(ev_region_max, ln.h_status->ev_region[i]);
+    }
     const unsigned long long flags = h_pinfo[1];
     // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
     if (flags || (h_counters[3] > 0 && !sp.redo)) w.last_ms[9] += 1.0f;   // repeated attempts of this call (speculation misses)
@@ -1101,8 +1116,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       sp.l_cap = std::min(want, l_max);
     }
     if (flags & SPEC_EVENTS) {
-      if (h_pinfo[0] > items_max) { shrink_part((double)h_pinfo[0], (double)items_max, "slide events"); publish_spec(sp); return false; }
-      sp.items_cap = std::min<uint64_t>(items_max, std::max<uint64_t>(sp.items_cap * 2, h_pinfo[0] + h_pinfo[0] / 4));
+      // every region has to hold its share: size the arena for the fullest one (the fused form reserves from one counter)
+      const uint64_t need = std::max<uint64_t>(h_pinfo[0], ev_region_max * ev_regions_for(F));
+      if (need > items_max) { shrink_part((double)need, (double)items_max, "slide events"); publish_spec(sp); return false; }
+      sp.items_cap = std::min<uint64_t>(items_max, std::max<uint64_t>(sp.items_cap * 2, need + need / 4));
     }
     if (flags) { if (slots_changed && (flags & SPEC_SCRATCH)) sp.seed_slots = want_slots; publish_spec(sp); return false; }   // void part: run it again
     if (h_counters[3] > 0 && !sp.redo) { sp.redo = true; publish_spec(sp); return false; }   // loci overflowed the byte state and the wide pass was not launched
@@ -1117,10 +1134,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     t_begin = std::min(t_begin, stamp[0]); t_end = std::max(t_end, stamp[4]);
     ln.last_F = F;
     ln.last_loci = h_counters[0];
-    ln.last_items = h_pinfo[0];
-    w.last_ms[5] += (float)h_totals[3];   // reference records inside the locus ranges of this call (roofline line)
+    ln.last_items = events_total;
+    w.last_ms[5] += (float)records_total;   // reference records inside the locus ranges of this call (roofline line)
     w.last_ms[6] += (float)h_counters[0];
-    w.last_ms[7] += (float)h_pinfo[0];    // slide events
+    w.last_ms[7] += (float)events_total;  // slide events
     w.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
     return true;
   };

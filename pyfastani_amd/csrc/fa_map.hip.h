@@ -1111,6 +1111,12 @@ struct L2Args {
   int32_t lanes;                     // loci per workgroup of k_l2_scan (power of two <= 64)
   int32_t ev_stage;                  // events of one locus staged in LDS per wave of k_l2_events
   unsigned long long *rec_total;     // sum over loci of the records in their range (for the roofline line)
+  // k_l2_events reserves the events of a fragment with ONE atomic that returns its offset; thousands of workgroups doing
+  // that on one address within a few microseconds queue up for ~12 ns each (14 us of a 190 us kernel), so the arena is
+  // cut into up to EV_REGIONS equal regions with a counter each and a fragment uses region (fragment mod n_regions)
+  unsigned long long *ev_region, *rec_region;   // [EV_REGIONS] events reserved / records read per region
+  uint64_t region_cap;               // events per region (items_cap / n_regions, a multiple of 8)
+  uint32_t n_regions;                // regions in use: a power of two <= EV_REGIONS, about one per eight fragments
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
   const uint32_t *f_loci_lo, *f_loci_n;   // [F] loci of each fragment
@@ -1121,6 +1127,7 @@ struct L2Args {
 
 constexpr int L2_THREADS = 64;
 constexpr int EV_THREADS = 256;
+constexpr int EV_REGIONS = 64;
 
 // Event word, from the low end: dM:2 | dW:2 | spare | drop | slot (= query rank + 1; 0 is the padding no-op) | no-eval
 // (the top bit), where dM / dW are two's complement -1 / 0 / +1: the change of the matched bit of that rank, resp. of
@@ -1213,11 +1220,12 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const unsigned long long base = atomicAdd(&a.pinfo[0], (unsigned long long)sh_run);   // order of fragments is irrelevant
-    sh_ok = base + sh_run <= a.items_cap;
+    const uint32_t region = (uint32_t)f & (a.n_regions - 1);
+    const unsigned long long base = atomicAdd(&a.ev_region[region], (unsigned long long)sh_run);   // order of fragments is irrelevant
+    sh_ok = base + sh_run <= a.region_cap;
     if (!sh_ok) atomicOr(&a.pinfo[1], (unsigned long long)SPEC_EVENTS);
-    sh_base = (uint32_t)base;
-    atomicAdd(a.rec_total, sh_records);
+    sh_base = (uint32_t)(region * a.region_cap + base);
+    atomicAdd(&a.rec_region[region], sh_records);
   }
   // Bucket table over the hash range the query sketch actually spans: minimizer hashes are window minima, i.e. heavily
   // skewed towards 0, so the buckets divide [0, 2^bits) with 2^bits > the largest query hash rather than the full 32-bit
