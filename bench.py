@@ -212,7 +212,7 @@ def weak_scaling(ctx):
     for i in range(args.steps):
         n_last = step(i)
         ms = (C.c_float * 8)()
-        lib.fa_mapper_last_timings(mapper._h, ms, 8)     # HIP-event timings of this step, on the library's stream
+        lib.fa_mapper_last_timings(mapper._h, ms, 8)     # stage times of this step: device stamps on the library's stream
         phase_ms += np.array(list(ms)[:5])
     gathered = exchange(args.steps)
     fence(ctx)
@@ -224,7 +224,8 @@ def weak_scaling(ctx):
         return None
 
     value = world * n_pairs_step * args.steps / elapsed
-    # ---- roofline of the dominant kernel, from the HIP-event timings taken inside the timed region ----
+    # ---- roofline of the dominant kernel, from the stage times taken inside the timed region (device stamps of the
+    #      100 MHz counter at the stage boundaries; cross-checked below with HIP events on the library's stream) ----
     phase = dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase_ms]))
     # K1 alone, repeated, for the minimizer-extraction roofline the north star asks for
     k1_ms, bases, mins = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
@@ -234,6 +235,17 @@ def weak_scaling(ctx):
     ms = (C.c_float * 8)()
     lib.fa_mapper_last_timings(mapper._h, ms, 8)
     l2_records, n_loci = float(ms[5]), float(ms[6])
+    # the same stage bracketed by two HIP events on the library's stream, in extra (untimed) steps: an event record
+    # costs the stream about as much as a small kernel, so the timed steps run without them
+    check(lib.fa_mapper_set_stage_events(mapper._h, 1))
+    ev_ms, ev_steps = 0.0, min(max(args.steps, 1), 20)
+    for i in range(ev_steps):
+        step(i % table.shape[0])
+        ms24 = (C.c_float * 24)()
+        lib.fa_mapper_last_timings(mapper._h, ms24, 24)
+        ev_ms += float(ms24[16])
+    check(lib.fa_mapper_set_stage_events(mapper._h, 0))
+    ev_ms /= ev_steps
     # every reference record inside a locus range is one 12-byte MinimizerInfo of the reference's layout
     l2_bytes = l2_records * 12.0
     l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
@@ -261,6 +273,8 @@ def weak_scaling(ctx):
                    "index_minimizers": n_min, "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack, "head": git_head()},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": roof[1],
+                     "kernel_ms_source": "device stamps (100 MHz counter) at the stage boundaries of every timed step, on the library's stream",
+                     "kernel_ms_hip_events": ev_ms if dominant == l2_name else None,
                      "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes},
         "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_tiles", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,

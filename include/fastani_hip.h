@@ -209,12 +209,17 @@ int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes);
 /* slide events per L2 locus of the last call (two-kernel form), in locus order -- development aid */
 int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, int64_t *n);
 /* last-call statistics: [0] sketch ms (K1 + fragment sort/unique), [1] lookup + L1 ms, [2] L2 ms, [3] CGI ms,
- * [4] total ms -- measured with HIP events on the library's stream -- then counters of the call:
- * [5] reference records inside L2 locus ranges, [6] L2 loci, [7] L2 slide events, [8] loci redone with the wide
- * L2 state, [9] passes repeated because a speculated buffer size was too small; after fa_mapper_query also the
- * host-side wall-clock split of that call: [10] packing ms, [11] fragment / tile tables ms, [12] uploads ms,
- * [13] device pass + row download ms.  n <= 16. */
+ * [4] total ms -- device time between stamps of the chip-wide 100 MHz counter that the first kernel of every stage
+ * leaves in the pass's status block (the kernels of a pass run back to back on the library's stream) -- then counters
+ * of the call: [5] reference records inside L2 locus ranges, [6] L2 loci, [7] L2 slide events, [8] loci redone with
+ * the wide L2 state, [9] passes repeated because a speculated buffer size was too small; after fa_mapper_query also
+ * the host-side wall-clock split of that call: [10] packing ms, [11] fragment / tile tables ms, [12] uploads ms,
+ * [13] device pass + rows ms; [14], [15] development (fused L2 form); [16] the L2 stage once more, bracketed by HIP
+ * events on the library's stream, when fa_mapper_set_stage_events is on (0 otherwise).  n <= 24. */
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n);
+/* on != 0: also bracket the L2 stage of every pass with two HIP events (slot [16] above).  Off by default: an event
+ * record costs the stream about as much as a small kernel. */
+int fa_mapper_set_stage_events(fa_mapper *m, int on);
 /* the HIP stream the library launches on (so callers can bracket it with their own events) */
 int fa_mapper_stream(fa_mapper *m, void **stream);
 /* run only the minimizer-extraction kernel (K1) over a resident batch `repeat` times and report the mean

@@ -377,7 +377,7 @@ struct Workspace {
   uint32_t last_loci = 0;
   uint64_t last_items = 0;
   const fa_genomes *last_genomes = nullptr;
-  float last_ms[16] = {0};
+  float last_ms[24] = {0};
   hipEvent_t ev[6] = {nullptr};
   // the parts of a pass are pipelined over this workspace and two more *lanes* (run_query_pass): sub-workspaces with their
   // own stream and per-part buffers; `serial` tells the debug getters which lanes took part in the last call
@@ -443,6 +443,7 @@ struct fa_mapper {
   Workspace ws[NWS];
   std::condition_variable ws_free;
   int last_ws = 0;                    // workspace of the most recent call (stage getters, timings)
+  bool stage_events = false;          // fa_mapper_set_stage_events
   std::vector<DevBuf<int32_t>> retired_i32;   // LUT generations still referenced by calls in flight
   std::vector<DevBuf<float>> retired_f32;
 
@@ -932,6 +933,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     debug_sync(st, "l1");
     // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
     {
+      if (m.stage_events) FA_HIP(hipEventRecord(ln.ev[2], st));
       L2Args a;
       a.stamp = &ln.status.p->stamp[2];
       a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p;
@@ -1054,6 +1056,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       }
     }
     debug_sync(st, "l2 scan");
+    if (m.stage_events) FA_HIP(hipEventRecord(ln.ev[3], st));
     // ---- core-genome identity ----
     if (npairs > 0) {
       CgiArgs a;
@@ -1129,6 +1132,12 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     }
     publish_spec(sp);
     // ---- accepted ----
+    if (m.stage_events) {
+      float ev_ms = 0;
+      FA_HIP(hipEventSynchronize(ln.ev[3]));
+      FA_HIP(hipEventElapsedTime(&ev_ms, ln.ev[2], ln.ev[3]));
+      w.last_ms[16] += ev_ms;
+    }
     const unsigned long long *stamp = ln.h_status->stamp;              // 100 MHz ticks
     for (int i = 0; i < 4; i++) w.last_ms[i] += (float)((double)(stamp[i + 1] - stamp[i]) * 1e-5);
     t_begin = std::min(t_begin, stamp[0]); t_end = std::max(t_end, stamp[4]);
@@ -1969,9 +1978,14 @@ int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, in
     *n = k;
   });
 }
+int fa_mapper_set_stage_events(fa_mapper *m, int on) {
+  std::lock_guard<std::mutex> lock(m->mtx);
+  m->stage_events = on != 0;
+  return FA_OK;
+}
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n) {
   std::lock_guard<std::mutex> lock(m->mtx);
-  for (int i = 0; i < n && i < 16; i++) ms[i] = m->ws[m->last_ws].last_ms[i];
+  for (int i = 0; i < n && i < 24; i++) ms[i] = m->ws[m->last_ws].last_ms[i];
   return FA_OK;
 }
 int fa_mapper_stream(fa_mapper *m, void **stream) { *stream = (void *)m->stream; return FA_OK; }
