@@ -327,7 +327,7 @@ def boundary_call(args, mapper, query, timed_rows):
             "slowest_call_index": int(np.argmax(per_call)),
             "hits": len(hits), "hits_match_timed_rows": bool(same),
             "split_ms": {"host_pack": float(split[10]), "fragment_tile_tables": float(split[11]), "h2d_upload": float(split[12]),
-                         "device_pass_and_rows_d2h": float(split[13]), "device_pass_events": float(split[4]),
+                         "device_pass_and_rows_d2h": float(split[13]), "device_pass": float(split[4]),
                          "python_binding_and_hits": dt * 1e3 - native}}
 
 
