@@ -522,7 +522,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   // thread 0 can publish the next trip's values while slower waves still read this trip's
   __shared__ uint32_t sh_heads[2];
   __shared__ int sh_prev_seq[2], sh_prev_wa[2], sh_has_prev[2];
-  __shared__ uint32_t sh_base, sh_gbase;
+  __shared__ uint32_t sh_base, sh_gbase, sh_grp;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
   const uint32_t n = a.n_seeds[f];
@@ -745,8 +745,46 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     }
     __syncthreads();
     if (pass == 0) {
+      const uint32_t cnt0 = sh_heads[par];
+      if (cnt0 > 0 && cnt0 <= (uint32_t)L1_STAGE) {
+        // The common case: the loci are in LDS.  Their groups (consecutive loci on the same reference genome) are
+        // counted from the staged copy first, so that loci and groups are reserved with ONE returning atomic on the
+        // adjacent counters -- thousands of workgroups queue up on that address for ~12 ns each, and two reservations
+        // per workgroup cost k_l1 11 of its 96 us.
+        uint32_t *st_grp = (uint32_t *)(lds + l1_off_offset(a.lds_seed_cap));   // (the list offsets are no longer needed)
+        if (wv == 0) {
+          uint32_t run = 0;
+          for (uint32_t i0 = 0; i0 < cnt0; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            bool gh = false;
+            if (i < cnt0) gh = (i == 0) || a.ix.contig_genome[st_seq[i]] != a.ix.contig_genome[st_seq[i - 1]];
+            const uint64_t gb = __ballot(gh);
+            if (i < cnt0) st_grp[i] = run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1;
+            run += __popcll(gb);
+          }
+          if (lane == 0) {
+            const unsigned long long old = atomicAdd((unsigned long long *)&a.counters[0], (unsigned long long)cnt0 | ((unsigned long long)run << 32));
+            uint32_t base = (uint32_t)old, cnt = cnt0;
+            if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+            sh_base = base;
+            sh_gbase = cnt;
+            sh_grp = (uint32_t)(old >> 32);
+            a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
+          }
+        }
+        __syncthreads();
+        if (sh_gbase == 0) return;
+        for (uint32_t q = tid; q < sh_gbase; q += NT) {
+          const uint32_t li = sh_base + q;
+          a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
+          a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q];
+          a.l_group[li] = (int32_t)(sh_grp + st_grp[q]);
+        }
+        return;
+      }
+      // more loci than the stage holds (or none): reserve, then a second pass writes them straight to HBM
       if (tid == 0) {
-        uint32_t cnt = sh_heads[par];
+        uint32_t cnt = cnt0;
         uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
         if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
@@ -755,16 +793,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       }
       __syncthreads();
       if (sh_gbase == 0) return;
-      staged = sh_gbase <= (uint32_t)L1_STAGE;
-      if (staged) {
-        // the common case: copy the loci from LDS to their reserved place
-        for (uint32_t q = tid; q < sh_gbase; q += NT) {
-          const uint32_t li = sh_base + q;
-          a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
-          a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q];
-        }
-        break;
-      }
+      staged = false;
     }
   }
   // ---- groups: consecutive loci of this fragment on the same reference genome ----
