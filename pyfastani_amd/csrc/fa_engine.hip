@@ -771,8 +771,14 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
   w.pass_f0 = range_f0;
   for (int i = 0; i < n_lanes; i++) for (int e = 0; e < 6; e++) if (!lanes[i]->ev[e]) FA_HIP(hipEventCreate(&lanes[i]->ev[e]));
   if (!w.ev_bins) FA_HIP(hipEventCreate(&w.ev_bins));
-  if (npairs > 0) FA_HIP(hipMemsetAsync(w.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
-  if (n_lanes > 1) FA_HIP(hipEventRecord(w.ev_bins, st));
+  // the CGI bin table is cleared once per pass: with one lane by the k_clear of the first part launched (a void first
+  // part cleared it all the same), with several lanes up front on the first lane's stream, which the others wait for
+  bool bins_cleared = npairs == 0;
+  if (n_lanes > 1) {
+    if (npairs > 0) FA_HIP(hipMemsetAsync(w.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
+    bins_cleared = true;
+    FA_HIP(hipEventRecord(w.ev_bins, st));
+  }
 
   struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; };
   std::deque<std::pair<int64_t, int64_t>> todo;
@@ -861,6 +867,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       cl.a.stamp = &ln.status.p->stamp[0];
       cl.add(ln.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(ln.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(ln.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
+      if (!bins_cleared) { cl.add(w.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long)); bins_cleared = true; }
       cl.launch(st);
     }
     // ---- K1 + per-fragment sort/unique ----
