@@ -362,7 +362,7 @@ struct Workspace {
   PassStatus *h_status = nullptr;     // pinned, written by k_publish_status
   uint32_t seq = 0;                   // passes published on this workspace
   DevBuf<int32_t> q_size, l_frag, l_seq, l_start, l_end, l_group, l_shared, l_pos, row_count, row_flag, row_off;
-  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast;
+  DevBuf<int32_t> l_beg, l_end0, l_last, l_ndrop, l_rfirst, l_rlast, l_rpart;
   DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo, big_state;
@@ -852,7 +852,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const int l1_nt = l1_threads >= 1024 ? 1024 : (l1_threads >= 512 ? 512 : 256);
     const uint32_t seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * l1_nt));
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
-    ln.l_rfirst.ensure((size_t)l_cap); ln.l_rlast.ensure((size_t)l_cap + 4);
+    ln.l_rfirst.ensure((size_t)l_cap); ln.l_rlast.ensure((size_t)l_cap + 4); ln.l_rpart.ensure((size_t)l_cap);
     ln.l_group.ensure((size_t)l_cap); ln.l_shared.ensure((size_t)l_cap); ln.l_pos.ensure((size_t)l_cap);
     ln.group_best.ensure((size_t)l_cap + 2);
     ln.l_beg.ensure((size_t)l_cap); ln.l_end0.ensure((size_t)l_cap); ln.l_last.ensure((size_t)l_cap); ln.l_ndrop.ensure((size_t)l_cap);
@@ -900,7 +900,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.ix = ix; a.q_size = ln.q_size.p; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p; a.n_seeds = ln.n_seeds.p;
       a.ovf_off = ln.ovf_off.p; a.ovf_buf = ln.ovf_buf.p; a.min_hits_lut = w.lut_min_hits;
       a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
-      a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p;
+      a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.l_rpart = ln.l_rpart.p;
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
@@ -945,7 +945,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.stamp = &ln.status.p->stamp[2];
       a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p;
       a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
-      a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.frag_len = m.P.fragment_length;
+      a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.l_rpart = ln.l_rpart.p; a.frag_len = m.P.fragment_length;
       a.l_beg = ln.l_beg.p; a.l_end0 = ln.l_end0.p; a.l_last = ln.l_last.p; a.l_nev = ln.l_nev.p; a.l_ioff = ln.l_ioff.p; a.l_ndrop = ln.l_ndrop.p;
       a.items = ln.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
       a.l_shared = ln.l_shared.p; a.l_pos = ln.l_pos.p; a.pass_lut = w.lut_pass; a.group_best = ln.group_best.p;

@@ -488,6 +488,7 @@ struct L1Args {
   const int32_t *min_hits_lut;   // [smax+1]
   int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
   int32_t *l_rfirst, *l_rlast;   // record index of the first / last seed of the locus
+  int32_t *l_rpart;              // record index of the seed that fixed the locus start (the partner of its first seed); -1 = unknown
   uint32_t *counters;            // [0] loci, [1] groups, [2] loci overflow flag
   uint32_t *f_loci_lo, *f_loci_n; // [F] loci of each fragment (contiguous)
   unsigned long long *pinfo;     // [1] speculation flags
@@ -500,7 +501,7 @@ struct L1Args {
   uint32_t big_cap;              // seed hits per chunk of k_l1_big (<= L1_BIG_E x L1_BIG_THREADS)
 };
 
-// dynamic LDS of k_l1: the seed hits [cap], the list offsets and sources [lut_smax + 2 each], the staged loci (5 arrays
+// dynamic LDS of k_l1: the seed hits [cap], the list offsets and sources [lut_smax + 2 each], the staged loci (6 arrays
 // of L1_STAGE)
 constexpr int L1_INPLACE_MAX = 32;  // most seeds per thread the in-place merge keeps in registers (template parameter E: 16 or 32)
 __host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 4 + 15) / 16 * 16; }
@@ -508,7 +509,7 @@ __host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_sma
   return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 8 + 15) / 16 * 16;   // list offsets + list sources
 }
 __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax) {
-  return l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 5 * 4;
+  return l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 6 * 4;
 }
 
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
@@ -670,6 +671,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   //      is normally the only one; if a fragment has more loci, pass 0 only counted and pass 1 writes them to HBM. ----
   int32_t *st_seq = (int32_t *)(lds + l1_stage_offset(a.lds_seed_cap, a.lut_smax));   // [L1_STAGE] each
   int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
+  int32_t *st_rpart = st_rlast + L1_STAGE;
   for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
   bool staged = true;
   for (int pass = 0; pass < 2; pass++) {
@@ -692,7 +694,8 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         sw_n = in < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
       }
       int seqb = __shfl(seq, (lane + m - 1) & 63), wb = __shfl(wa, (lane + m - 1) & 63);
-      if (lane + m - 1 >= 64 && i < ncand) { const int2 swb = a.ix.rec_sw[seeds[i + m - 1]]; seqb = swb.x; wb = swb.y; }
+      int rb = __shfl((int)ra, (lane + m - 1) & 63);                     // record of the partner seed: it fixes the locus start
+      if (lane + m - 1 >= 64 && i < ncand) { rb = (int)seeds[i + m - 1]; const int2 swb = a.ix.rec_sw[rb]; seqb = swb.x; wb = swb.y; }
       if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
@@ -723,12 +726,12 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
         if (pass == 0) {
           if (slot <= (uint32_t)L1_STAGE) {
-            if (head) { st_seq[slot - 1] = seq; st_start[slot - 1] = start; st_rfirst[slot - 1] = (int32_t)ra; }
+            if (head) { st_seq[slot - 1] = seq; st_start[slot - 1] = start; st_rfirst[slot - 1] = (int32_t)ra; st_rpart[slot - 1] = rb; }
             if (last_here) { atomicMax(&st_end[slot - 1], wa); atomicMax(&st_rlast[slot - 1], (int32_t)ra); }
           }
         } else {
           uint32_t li = sh_base + slot - 1;
-          if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; a.l_rfirst[li] = (int32_t)ra; }
+          if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; a.l_rfirst[li] = (int32_t)ra; a.l_rpart[li] = rb; }
           if (last_here) { atomicMax(&a.l_end[li], wa); atomicMax(&a.l_rlast[li], (int32_t)ra); }
         }
       }
@@ -777,7 +780,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         for (uint32_t q = tid; q < sh_gbase; q += NT) {
           const uint32_t li = sh_base + q;
           a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
-          a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q];
+          a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q]; a.l_rpart[li] = st_rpart[q];
           a.l_group[li] = (int32_t)(sh_grp + st_grp[q]);
         }
         return;
@@ -1062,7 +1065,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   const uint32_t nl = sh_cnt, base = sh_base;
   for (uint32_t q = tid; q < nl; q += NT) {
     const uint32_t li = base + q;
-    a.l_frag[li] = f; a.l_seq[li] = S_seq[q]; a.l_start[li] = S_start[q]; a.l_rfirst[li] = S_rfirst[q];
+    a.l_frag[li] = f; a.l_seq[li] = S_seq[q]; a.l_start[li] = S_start[q]; a.l_rfirst[li] = S_rfirst[q]; a.l_rpart[li] = -1;
     a.l_end[li] = S_end[q]; a.l_rlast[li] = S_rlast[q];
   }
   __threadfence_block();
@@ -1121,7 +1124,7 @@ struct L2Args {
   IndexView ix;
   const uint32_t *q_hash;
   const int32_t *q_size;
-  const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group, *l_rfirst, *l_rlast;
+  const int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group, *l_rfirst, *l_rlast, *l_rpart;
   int32_t frag_len;
   int32_t *l_beg, *l_end0, *l_last;  // record range of the locus, end of the first super-window
   int32_t *l_ndrop;                  // records dropped before the slide ends
@@ -1218,10 +1221,19 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
       const int lo = a.ix.contig_rec[a.l_seq[l]];
       // searchIndex(seqId, rangeStartPos): rangeStartPos <= wpos of the first seed and wpos is strictly increasing, so
       // the answer lies within fragment_length records before that seed
-      const int rfirst = a.l_rfirst[l], target = a.l_start[l];
-      int x = max(lo, rfirst - a.frag_len), y = rfirst;
-      while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+      const int rfirst = a.l_rfirst[l], target = a.l_start[l], rpart = a.l_rpart[l];
       const int last = a.ix.rec_fwd[a.l_rlast[l]];         // searchIndex(seqId, rangeEndPos + countMinimizerWindows)
+      int x = max(lo, rfirst - a.frag_len), y = rfirst;
+      if (rpart >= 0) {
+        // ... and far closer: the range starts fragment_length - 1 bases before the partner seed p that k_l1 paired with
+        // the first one, and rec_bwd[p] is the last record at or before wpos[p] - cmw + 1, which is only
+        // fragment_length - cmw bases further on -- that many records at most, wpos being strictly increasing.  Six
+        // probes inside two or three cache lines instead of twelve spread over the contig (scattered probes were a tenth
+        // of this kernel's HBM traffic).
+        y = min(rfirst, a.ix.rec_bwd[rpart] + 1);
+        x = max(x, y - (a.frag_len - a.cmw + 1));
+      }
+      while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
       const int beg = x;
       const int end0 = a.ix.rec_fwd[beg];                  // searchIndex(seqId, first wpos + countMinimizerWindows)
       // the slide stops at the window position where the last record is admitted; the records dropped by then are
