@@ -1387,9 +1387,13 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   g->d_frag_qseq = (const int32_t *)(g->blob.p + o_fs);
   g->d_total_frag = (const int32_t *)(g->blob.p + o_tf);
   // the staging image must stay untouched until the copy has left it (pageable copies return after staging, pinned ones
-  // are asynchronous): one synchronisation per upload
-  FA_HIP(hipStreamSynchronize(st));
-  if (!pin) { std::vector<unsigned char>().swap(g->host_image); }
+  // are asynchronous).  An image in the caller's pinned block (the one-query call: the block belongs to the workspace and
+  // is not touched again before the call returns, and the pass runs on this same stream, behind the copy) needs no
+  // synchronisation; otherwise one per upload
+  if (!pin) {
+    FA_HIP(hipStreamSynchronize(st));
+    std::vector<unsigned char>().swap(g->host_image);
+  }
   tr.mark("uploads", st);
   lap(2);
   return g;
