@@ -878,20 +878,16 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.tile_count = ln.sk.tile_count.p; a.stage_hash = ln.sk.stage_hash.p; a.stage_wpos = ln.sk.stage_wpos.p;
       a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
       a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.stats = d_stats; a.qcap = qcap;
+      a.ix = ix; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p; a.n_seeds = ln.n_seeds.p;
       a.sort_cap = (int32_t)(qs_lds / 4);
       if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
       hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
     }
     debug_sync(st, "sketch");
-    // ---- lookup, seed totals and speculation checks ----
+    // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch) ----
     {
-      LookupArgs a;
-      a.stamp = &ln.status.p->stamp[1];
-      a.ix = ix; a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p;
-      a.n_seeds = ln.n_seeds.p; a.totals = d_totals; a.ovf_off = ln.ovf_off.p; a.qcap = qcap; a.lds_seed_cap = seed_slots;
-      hipLaunchKernelGGL(k_lookup, dim3((unsigned)F), dim3(MAP_THREADS), 0, st, a);
       hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, ln.n_seeds.p, F, seed_slots, d_totals, ln.ovf_off.p,
-                         d_stats, smax, sp.scratch_words, d_pinfo);
+                         d_stats, smax, sp.scratch_words, d_pinfo, &ln.status.p->stamp[1]);
     }
     debug_sync(st, "lookup");
     // ---- L1 ----

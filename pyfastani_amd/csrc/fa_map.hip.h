@@ -57,128 +57,6 @@ __device__ inline void block_bitonic_sort(uint32_t *a, uint32_t n32) {
 }
 
 // ----------------------------------------------------------------------------------------------------------
-// query fragments: gather the staged records of a fragment's tiles, apply the leading-run rule, sort by hash,
-// drop duplicates (std::sort + std::unique of _fastani.pyx:929-936).  One workgroup per fragment.
-// ----------------------------------------------------------------------------------------------------------
-struct QuerySketchArgs {
-  const int32_t *frag_tile_lo;  // [F+1]
-  const int32_t *tile_count;
-  const uint32_t *stage_hash;
-  const int32_t *stage_wpos;
-  uint32_t *q_hash;             // [F * qcap]
-  int32_t *q_size;              // [F]
-  int32_t *stats;               // [0] max sketch size
-  int32_t qcap;
-  int32_t sort_cap;             // power of two >= max records of a fragment
-  int32_t tile_base;            // first tile of this pass (staging is indexed pass-locally)
-};
-
-constexpr int QS_TILES = 16;      // tiles of a fragment whose counts k_query_sketch fetches in one go
-__global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
-  extern __shared__ __align__(16) unsigned char lds[];
-  uint32_t *buf = (uint32_t *)lds;                 // [sort_cap]
-  __shared__ int sh_drop, sh_total;
-  __shared__ uint32_t sh_h0;
-  __shared__ int sh_wpos0;
-  const int f = blockIdx.x, tid = threadIdx.x;
-  const int t0 = a.frag_tile_lo[f] - a.tile_base, t1 = a.frag_tile_lo[f + 1] - a.tile_base;
-  // gather in order.  The counts of the (few) tiles of a fragment are fetched together, then all staged records: two
-  // dependent round trips to HBM per fragment instead of two per tile
-  __shared__ int sh_cnt[QS_TILES + 1];
-  const int ntile = t1 - t0;
-  int n = 0;
-  if (ntile <= QS_TILES) {
-    if (tid < ntile) sh_cnt[tid] = a.tile_count[t0 + tid];
-    __syncthreads();
-    int first = -1;
-    for (int q = 0; q < ntile; q++) { if (first < 0 && sh_cnt[q] > 0) first = q; n += sh_cnt[q]; }
-    for (int i = tid; i < n; i += blockDim.x) {
-      int q = 0, o = i;
-      while (o >= sh_cnt[q]) { o -= sh_cnt[q]; q++; }
-      buf[i] = a.stage_hash[(size_t)(t0 + q) * TILE + o];
-    }
-    if (tid == 0 && first >= 0) { sh_h0 = a.stage_hash[(size_t)(t0 + first) * TILE]; sh_wpos0 = a.stage_wpos[(size_t)(t0 + first) * TILE]; }
-  } else {
-    for (int t = t0; t < t1; t++) {
-      int c = a.tile_count[t];
-      for (int i = tid; i < c; i += blockDim.x) buf[n + i] = a.stage_hash[(size_t)t * TILE + i];
-      if (n == 0 && c > 0 && tid == 0) { sh_h0 = a.stage_hash[(size_t)t * TILE]; sh_wpos0 = a.stage_wpos[(size_t)t * TILE]; }
-      n += c;
-    }
-  }
-  if (tid == 0) { sh_drop = n; }
-  __syncthreads();
-  // leading run: records 1..d equal to record 0's hash are dropped when record 0 sits at window 0
-  if (n > 1 && sh_wpos0 == 0) {
-    uint32_t h0 = sh_h0;
-    int first_diff = n;
-    for (int i = 1 + tid; i < n; i += blockDim.x) if (buf[i] != h0) { first_diff = i; break; }
-    atomicMin(&sh_drop, first_diff);
-    __syncthreads();
-    int d = sh_drop - 1;
-    __syncthreads();
-    if (d > 0) {
-      // overwrite the dropped records with copies of record 0 (duplicates vanish in the unique step)
-      for (int i = 1 + tid; i <= d; i += blockDim.x) buf[i] = h0;
-    }
-  }
-  __syncthreads();
-  if (n <= (int)blockDim.x) {
-    // the usual case (a 3 kb fragment holds ~240 minimizers): one record per thread, ranked by counting -- every thread
-    // reads the same LDS words (broadcast, four at a time), two barriers instead of the 36 of a bitonic network
-    const int n4 = (n + 3) & ~3;
-    for (int i = n + tid; i < n4; i += blockDim.x) buf[i] = SEED_PAD;
-    __syncthreads();
-    const uint32_t x = tid < n ? buf[tid] : 0u;
-    int rank = 0;
-    const uint4 *b4 = (const uint4 *)buf;
-    for (int j = 0; j < n4; j += 4) {
-      const uint4 v = b4[j >> 2];
-      rank += (v.x < x || (v.x == x && j < tid)) ? 1 : 0;
-      rank += (v.y < x || (v.y == x && j + 1 < tid)) ? 1 : 0;
-      rank += (v.z < x || (v.z == x && j + 2 < tid)) ? 1 : 0;
-      rank += (v.w < x || (v.w == x && j + 3 < tid)) ? 1 : 0;
-    }
-    __syncthreads();
-    if (tid < n) buf[rank] = x;
-    __syncthreads();
-  } else {
-    uint32_t n32 = 1;
-    while (n32 < (uint32_t)n) n32 <<= 1;
-    if (n32 < 2) n32 = 2;
-    for (uint32_t i = n + tid; i < n32; i += blockDim.x) buf[i] = SEED_PAD;
-    __syncthreads();
-    // a real hash may equal SEED_PAD (protein mode): harmless, the first n sorted entries are then the same multiset
-    block_bitonic_sort(buf, n32);
-  }
-  // unique: keep buf[i] if i == 0 or differs from predecessor, among the first n sorted entries
-  if (tid == 0) sh_total = 0;
-  __syncthreads();
-  uint32_t *out = a.q_hash + (size_t)f * a.qcap;
-  for (int base = 0; base < n; base += blockDim.x) {
-    int i = base + tid;
-    bool keep = i < n && (i == 0 || buf[i] != buf[i - 1]);
-    uint64_t bal = __ballot(keep);
-    __shared__ int wave_cnt[MAP_THREADS / 64];
-    int lane = tid & 63, wv = tid >> 6;
-    if (lane == 0) wave_cnt[wv] = __popcll(bal);
-    __syncthreads();
-    int off = sh_total;
-    for (int q = 0; q < wv; q++) off += wave_cnt[q];
-    if (keep) out[off + __popcll(bal & ((1ULL << lane) - 1ULL))] = buf[i];
-    __syncthreads();
-    if (tid == 0) { int tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += wave_cnt[q]; sh_total += tot; }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    a.q_size[f] = sh_total;
-    // ~1700 workgroups updating one address serialise in L2 (that alone was most of this kernel's time): the maximum
-    // only ever grows, so a plain read filters out nearly all of them
-    if (sh_total > *(volatile int32_t *)&a.stats[0]) atomicMax(&a.stats[0], sh_total);
-  }
-}
-
-// ----------------------------------------------------------------------------------------------------------
 // index construction helpers (the radix sort / run-length / scan primitives come from hipCUB)
 // ----------------------------------------------------------------------------------------------------------
 __global__ void k_iota(uint32_t *a, int64_t n) {
@@ -372,28 +250,138 @@ __device__ __forceinline__ bool index_find(const IndexView &ix, uint32_t h, uint
 // ----------------------------------------------------------------------------------------------------------
 // lookup: for every query minimizer its position list in the index, frequency-filtered (_fastani.pyx:941-948)
 // ----------------------------------------------------------------------------------------------------------
-struct LookupArgs {
-  IndexView ix;
-  const uint32_t *q_hash;
-  const int32_t *q_size;
-  uint32_t *q_off;       // [F*qcap] start of the list in pos_ridx
-  uint32_t *q_cnt;       // [F*qcap] list length (0 when absent or too frequent)
-  uint32_t *n_seeds;     // [F]
-  uint64_t *totals;      // [0] sum of seeds, [1] max seeds of a fragment, [2] overflow scratch words
-  uint32_t *ovf_off;     // [F] offset into the overflow scratch for fragments whose seeds do not fit LDS
+// ----------------------------------------------------------------------------------------------------------
+// query fragments: gather the staged records of a fragment's tiles, apply the leading-run rule, sort by hash,
+// drop duplicates (std::sort + std::unique of _fastani.pyx:929-936).  One workgroup per fragment.
+// ----------------------------------------------------------------------------------------------------------
+struct QuerySketchArgs {
+  const int32_t *frag_tile_lo;  // [F+1]
+  const int32_t *tile_count;
+  const uint32_t *stage_hash;
+  const int32_t *stage_wpos;
+  uint32_t *q_hash;             // [F * qcap]
+  int32_t *q_size;              // [F]
+  int32_t *stats;               // [0] max sketch size
   int32_t qcap;
-  uint32_t lds_seed_cap;
-  unsigned long long *stamp;       // stage_stamp: start of the lookup + L1 stage
+  int32_t sort_cap;             // power of two >= max records of a fragment
+  int32_t tile_base;            // first tile of this pass (staging is indexed pass-locally)
+  // the index lookup of the fragment's minimizers follows in the same workgroup (it was a kernel of its own: k_lookup)
+  IndexView ix;
+  uint32_t *q_off;              // [F*qcap] start of the list in pos_ridx
+  uint32_t *q_cnt;              // [F*qcap] list length (0 when absent or too frequent)
+  uint32_t *n_seeds;            // [F]
 };
 
-__global__ __launch_bounds__(MAP_THREADS) void k_lookup(LookupArgs a) {
-  stage_stamp(a.stamp);
+constexpr int QS_TILES = 16;      // tiles of a fragment whose counts k_query_sketch fetches in one go
+__global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  uint32_t *buf = (uint32_t *)lds;                 // [sort_cap]
+  __shared__ int sh_drop, sh_total;
+  __shared__ uint32_t sh_h0;
+  __shared__ int sh_wpos0;
   const int f = blockIdx.x, tid = threadIdx.x;
-  const int s = a.q_size[f];
+  const int t0 = a.frag_tile_lo[f] - a.tile_base, t1 = a.frag_tile_lo[f + 1] - a.tile_base;
+  // gather in order.  The counts of the (few) tiles of a fragment are fetched together, then all staged records: two
+  // dependent round trips to HBM per fragment instead of two per tile
+  __shared__ int sh_cnt[QS_TILES + 1];
+  const int ntile = t1 - t0;
+  int n = 0;
+  if (ntile <= QS_TILES) {
+    if (tid < ntile) sh_cnt[tid] = a.tile_count[t0 + tid];
+    __syncthreads();
+    int first = -1;
+    for (int q = 0; q < ntile; q++) { if (first < 0 && sh_cnt[q] > 0) first = q; n += sh_cnt[q]; }
+    for (int i = tid; i < n; i += blockDim.x) {
+      int q = 0, o = i;
+      while (o >= sh_cnt[q]) { o -= sh_cnt[q]; q++; }
+      buf[i] = a.stage_hash[(size_t)(t0 + q) * TILE + o];
+    }
+    if (tid == 0 && first >= 0) { sh_h0 = a.stage_hash[(size_t)(t0 + first) * TILE]; sh_wpos0 = a.stage_wpos[(size_t)(t0 + first) * TILE]; }
+  } else {
+    for (int t = t0; t < t1; t++) {
+      int c = a.tile_count[t];
+      for (int i = tid; i < c; i += blockDim.x) buf[n + i] = a.stage_hash[(size_t)t * TILE + i];
+      if (n == 0 && c > 0 && tid == 0) { sh_h0 = a.stage_hash[(size_t)t * TILE]; sh_wpos0 = a.stage_wpos[(size_t)t * TILE]; }
+      n += c;
+    }
+  }
+  if (tid == 0) { sh_drop = n; }
+  __syncthreads();
+  // leading run: records 1..d equal to record 0's hash are dropped when record 0 sits at window 0
+  if (n > 1 && sh_wpos0 == 0) {
+    uint32_t h0 = sh_h0;
+    int first_diff = n;
+    for (int i = 1 + tid; i < n; i += blockDim.x) if (buf[i] != h0) { first_diff = i; break; }
+    atomicMin(&sh_drop, first_diff);
+    __syncthreads();
+    int d = sh_drop - 1;
+    __syncthreads();
+    if (d > 0) {
+      // overwrite the dropped records with copies of record 0 (duplicates vanish in the unique step)
+      for (int i = 1 + tid; i <= d; i += blockDim.x) buf[i] = h0;
+    }
+  }
+  __syncthreads();
+  if (n <= (int)blockDim.x) {
+    // the usual case (a 3 kb fragment holds ~240 minimizers): one record per thread, ranked by counting -- every thread
+    // reads the same LDS words (broadcast, four at a time), two barriers instead of the 36 of a bitonic network
+    const int n4 = (n + 3) & ~3;
+    for (int i = n + tid; i < n4; i += blockDim.x) buf[i] = SEED_PAD;
+    __syncthreads();
+    const uint32_t x = tid < n ? buf[tid] : 0u;
+    int rank = 0;
+    const uint4 *b4 = (const uint4 *)buf;
+    for (int j = 0; j < n4; j += 4) {
+      const uint4 v = b4[j >> 2];
+      rank += (v.x < x || (v.x == x && j < tid)) ? 1 : 0;
+      rank += (v.y < x || (v.y == x && j + 1 < tid)) ? 1 : 0;
+      rank += (v.z < x || (v.z == x && j + 2 < tid)) ? 1 : 0;
+      rank += (v.w < x || (v.w == x && j + 3 < tid)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (tid < n) buf[rank] = x;
+    __syncthreads();
+  } else {
+    uint32_t n32 = 1;
+    while (n32 < (uint32_t)n) n32 <<= 1;
+    if (n32 < 2) n32 = 2;
+    for (uint32_t i = n + tid; i < n32; i += blockDim.x) buf[i] = SEED_PAD;
+    __syncthreads();
+    // a real hash may equal SEED_PAD (protein mode): harmless, the first n sorted entries are then the same multiset
+    block_bitonic_sort(buf, n32);
+  }
+  // unique: keep buf[i] if i == 0 or differs from predecessor, among the first n sorted entries
+  if (tid == 0) sh_total = 0;
+  __syncthreads();
+  uint32_t *out = a.q_hash + (size_t)f * a.qcap;
+  for (int base = 0; base < n; base += blockDim.x) {
+    int i = base + tid;
+    bool keep = i < n && (i == 0 || buf[i] != buf[i - 1]);
+    uint64_t bal = __ballot(keep);
+    __shared__ int wave_cnt[MAP_THREADS / 64];
+    int lane = tid & 63, wv = tid >> 6;
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int off = sh_total;
+    for (int q = 0; q < wv; q++) off += wave_cnt[q];
+    if (keep) out[off + __popcll(bal & ((1ULL << lane) - 1ULL))] = buf[i];
+    __syncthreads();
+    if (tid == 0) { int tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += wave_cnt[q]; sh_total += tot; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.q_size[f] = sh_total;
+    // ~1700 workgroups updating one address serialise in L2 (that alone was most of this kernel's time): the maximum
+    // only ever grows, so a plain read filters out nearly all of them
+    if (sh_total > *(volatile int32_t *)&a.stats[0]) atomicMax(&a.stats[0], sh_total);
+  }
+  // ---- lookup: one 16-byte table probe per distinct minimizer (unordered_map::find), strict `< freqThreshold` ----
+  __syncthreads();                                                  // (the hashes this workgroup wrote to `out`)
+  const int s = sh_total;
   __shared__ uint32_t red[MAP_THREADS / 64];
   uint32_t mine = 0;
   for (int j = tid; j < s; j += blockDim.x) {
-    uint32_t h = a.q_hash[(size_t)f * a.qcap + j];
+    const uint32_t h = out[j];
     uint32_t off = 0, cnt = 0;
     if (index_find(a.ix, h, off, cnt)) {
       if ((int64_t)cnt >= (int64_t)a.ix.freq_threshold) cnt = 0;   // strict `size < threshold` keeps the list
@@ -423,7 +411,8 @@ constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS =
 // more than this.  Also checks the speculated sketch-size and scratch bounds.
 __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
                                                       uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
-                                                      uint64_t spec_scratch_words, unsigned long long *pinfo) {
+                                                      uint64_t spec_scratch_words, unsigned long long *pinfo, unsigned long long *stamp) {
+  stage_stamp(stamp);                                                // start of the L1 stage
   __shared__ unsigned long long sh_sum;
   __shared__ unsigned int sh_max, sh_any;
   if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; }
