@@ -306,30 +306,17 @@ struct PassStatus {
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
 
-// The last kernel of a pass: copies the status block -- and, for a one-query call whose rows go to the host, the rows --
+// The hand-over of a pass (publish_pass, fa_map.hip.h): copies the status block -- and, for a one-query call whose rows go to the host, the rows --
 // into pinned host memory and then releases the pass number.  The host polls that word instead of waiting for a
 // device-to-host copy and a stream synchronisation, which together return tens of microseconds after the GPU is done
 // (more on a slow host: the step time of the bench varied by 0.09 ms between boxes on that account).
-__global__ void k_publish_status(PassStatus *dev, PassStatus *host, uint32_t seq, const fa_cgi_row *rows_dev, fa_cgi_row *rows_host, int64_t cap) {
-  constexpr int W = (int)(offsetof(PassStatus, seq) / 4);
-  if (threadIdx.x == 0) {
-    dev->stamp[4] = __builtin_amdgcn_s_memrealtime();
-    if (dev->stamp[3] == 0) dev->stamp[3] = dev->stamp[4];        // (a pass without pairs has no CGI stage)
-  }
-  __syncthreads();
-  const uint32_t *s = (const uint32_t *)dev;
-  uint32_t *d = (uint32_t *)host;
-  for (int i = threadIdx.x; i < W; i += blockDim.x) d[i] = s[i];
-  if (rows_host) {
-    const int64_t n = std::min<int64_t>(dev->total_rows, cap);
-    static_assert(sizeof(fa_cgi_row) % 4 == 0, "rows are copied word by word");
-    const uint32_t *rs = (const uint32_t *)rows_dev;
-    uint32_t *rd = (uint32_t *)rows_host;
-    for (int64_t i = threadIdx.x; i < n * (int64_t)(sizeof(fa_cgi_row) / 4); i += blockDim.x) rd[i] = rs[i];
-  }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(&host->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+static PublishArgs publish_args(PassStatus *dev, PassStatus *host_mapped, uint32_t seq, const fa_cgi_row *rows_dev, fa_cgi_row *rows_host, int64_t cap) {
+  PublishArgs p;
+  p.status_dev = (uint32_t *)dev; p.status_host = (uint32_t *)host_mapped;
+  p.words = (int32_t)(offsetof(PassStatus, seq) / 4); p.seq_word = p.words; p.seq = seq;
+  p.stamp = dev->stamp; p.total_rows = &dev->total_rows;
+  p.rows_dev = rows_dev; p.rows_host = rows_host; p.cap = cap;
+  return p;
 }
 // host side of k_publish_status: polls for FA_SPIN_US microseconds (default 20 000), then sleeps on the stream
 // regions of the event arena used by a part of F fragments (L2Args::n_regions): a power of two, one per eight fragments
@@ -793,7 +780,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
   auto join_lanes = [&](int me) {
     for (int i = 0; i < n_lanes; i++) if (i != me && ran[i]) FA_HIP(hipStreamWaitEvent(lanes[me]->stream, lanes[i]->ev[4], 0));
   };
-  auto launch_rows = [&](Workspace &ln) {
+  // forms the rows; returns true if the kernel also hands the pass over to the host (small passes: its last workgroup does)
+  auto launch_rows = [&](Workspace &ln, const PublishArgs &pub) -> bool {
     hipStream_t st = ln.stream;
     uint32_t *const d_counters = ln.status.p->counters;
     int32_t *const d_total_rows = &ln.status.p->total_rows;
@@ -801,6 +789,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ra.bins = w.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
     ra.row_count = w.row_count.p; ra.row_ident = w.row_ident.p;
     ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
+    ra.pub = pub;
+    if (!ra.emit) ra.pub.seq = 0;
     ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag + g0; ra.query_id_base = g0;
     ra.rows = rows_dev + row_base; ra.cap = cap - row_base; ra.total_rows = d_total_rows;
     hipLaunchKernelGGL(k_cgi_rows, dim3(ceil_div(npairs, 4)), dim3(256), 0, st, ra);
@@ -813,6 +803,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       hipLaunchKernelGGL(k_emit_rows, dim3(ceil_div(npairs, 256)), dim3(256), 0, st, w.row_count.p, w.row_ident.p, w.row_off.p, m.G,
                          npairs, g.d_total_frag + g0, g0, rows_dev + row_base, cap - row_base);
     }
+    return ra.emit != 0;
   };
   auto launch_part = [&](Run &r) {
     Workspace &ln = *lanes[r.lane];
@@ -1071,18 +1062,17 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
     }
-    if (npairs > 0 && r.with_rows) { join_lanes(r.lane); launch_rows(ln); rows_lane = r.lane; rows_valid = true; }
+    // ---- the one hand-over of the part: results, statistics and the speculation verdict (publish_pass) ----
+    PassStatus *h_dev = nullptr;
+    FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
+    const bool to_host = r.with_rows && host_rows != nullptr;
+    const PublishArgs pub = publish_args(ln.status.p, h_dev, ++ln.seq, rows_dev + row_base, to_host ? host_rows + row_base : nullptr, cap - row_base);
+    bool published = false;
+    if (npairs > 0 && r.with_rows) { join_lanes(r.lane); published = launch_rows(ln, pub); rows_lane = r.lane; rows_valid = true; }
     FA_HIP(hipGetLastError());
     debug_sync(st, "cgi");
     if (n_lanes > 1) FA_HIP(hipEventRecord(ln.ev[4], st));         // (join_lanes: the bins of this part)
-    // ---- the one hand-over of the part: results, statistics and the speculation verdict ----
-    {
-      PassStatus *h_dev = nullptr;
-      FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
-      const bool to_host = r.with_rows && host_rows != nullptr;
-      hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, st, ln.status.p, h_dev, ++ln.seq, rows_dev + row_base, to_host ? host_rows + row_base : nullptr,
-                         cap - row_base);
-    }
+    if (!published) hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, st, pub);
     ran[r.lane] = true;
   };
   // waits for a part and reads its verdict: true = accepted, false = void (its range has to run again)
@@ -1188,11 +1178,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       join_lanes(0);
       FA_HIP(hipMemsetAsync(&ln.status.p->counters[4], 0, sizeof(uint32_t), ln.stream));
       FA_HIP(hipMemsetAsync(&ln.status.p->total_rows, 0, sizeof(int32_t), ln.stream));
-      launch_rows(ln);
       PassStatus *h_dev = nullptr;
       FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
-      hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, ln.stream, ln.status.p, h_dev, ++ln.seq, rows_dev + row_base,
-                         host_rows ? host_rows + row_base : nullptr, cap - row_base);
+      const PublishArgs pub = publish_args(ln.status.p, h_dev, ++ln.seq, rows_dev + row_base, host_rows ? host_rows + row_base : nullptr, cap - row_base);
+      if (!launch_rows(ln, pub)) hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, ln.stream, pub);
       wait_published(ln.h_status, ln.seq, ln.stream);
       rows_lane = 0;
     }

@@ -1999,6 +1999,41 @@ __global__ void k_cgi_bins(CgiArgs a) {
 // of eight 64-bin chunks are fetched together so that the sequential chain waits for HBM once per 512 bins, and
 // chunks without any mapping are skipped (x + 0.0f == x).  When `emit` is set (small passes) the last workgroup to
 // finish also forms the rows -- flag the non-empty pairs, scan, write in (query, genome) order -- which saves a launch.
+// Hand-over of a pass to the host (fa_engine.hip, k_publish_status): the status block and, for a one-query call, the hit
+// rows are copied into pinned host memory, then the pass number is released for the host that polls it.  Run by one
+// workgroup: the last one of k_cgi_rows when that kernel also forms the rows, else a kernel of its own.
+struct PublishArgs {
+  uint32_t *status_dev;              // the device status block, as words
+  uint32_t *status_host;             // its pinned mirror
+  int32_t words;                     // words to copy (everything before the pass number)
+  int32_t seq_word;                  // index of the pass number in the host block
+  uint32_t seq;                      // 0 = nothing to publish here
+  unsigned long long *stamp;         // the stamps of the pass inside the device block ([3] CGI start, [4] end)
+  const int32_t *total_rows;         // in the device block
+  const fa_cgi_row *rows_dev;
+  fa_cgi_row *rows_host;             // nullptr: the rows stay on the device
+  int64_t cap;
+};
+__device__ __forceinline__ void publish_pass(const PublishArgs &p) {
+  if (threadIdx.x == 0) {
+    p.stamp[4] = __builtin_amdgcn_s_memrealtime();
+    if (p.stamp[3] == 0) p.stamp[3] = p.stamp[4];                  // (a pass without pairs has no CGI stage)
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < p.words; i += blockDim.x) p.status_host[i] = p.status_dev[i];
+  if (p.rows_host) {
+    const int64_t n = min((int64_t)*p.total_rows, p.cap);
+    static_assert(sizeof(fa_cgi_row) % 4 == 0, "rows are copied word by word");
+    const uint32_t *rs = (const uint32_t *)p.rows_dev;
+    uint32_t *rd = (uint32_t *)p.rows_host;
+    for (int64_t i = threadIdx.x; i < n * (int64_t)(sizeof(fa_cgi_row) / 4); i += blockDim.x) rd[i] = rs[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(&p.status_host[p.seq_word], p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_publish_status(PublishArgs p) { publish_pass(p); }
+
 struct RowsArgs {
   const unsigned long long *bins;
   const int32_t *genome_bin;
@@ -2012,6 +2047,7 @@ struct RowsArgs {
   fa_cgi_row *rows;
   int64_t cap;
   int32_t *total_rows;
+  PublishArgs pub;                 // emit only: the last workgroup also hands the pass over to the host (seq != 0)
 };
 
 __global__ __launch_bounds__(256) void k_cgi_rows(RowsArgs a) {
@@ -2094,6 +2130,11 @@ __global__ __launch_bounds__(256) void k_cgi_rows(RowsArgs a) {
     __syncthreads();
   }
   if (threadIdx.x == 0) *a.total_rows = sh_run;
+  if (a.pub.seq) {
+    __threadfence();
+    __syncthreads();                                                 // the rows and their count are written
+    publish_pass(a.pub);
+  }
 }
 
 // ordered compaction of the non-empty (query, genome) pairs into fa_cgi_row records
