@@ -118,10 +118,23 @@ struct StageTrace {
   }
 };
 
+// `clear` (a query pass): ranges zeroed by extra workgroups of the first launch, beside the hashing
 static void launch_sketch_tiles(const fa_params &P, const StoreView &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
-                                int32_t *stage_wpos, int32_t *tile_count, hipStream_t st) {
-  if (ntiles <= 0) return;
+                                int32_t *stage_wpos, int32_t *tile_count, hipStream_t st, const ClearArgs *clear = nullptr) {
+  if (ntiles <= 0) {
+    if (clear && clear->count) hipLaunchKernelGGL(k_clear, dim3(256), dim3(256), 0, st, *clear);
+    return;
+  }
   SketchArgs a;
+  a.ntiles = ntiles;
+  a.clear.count = 0; a.clear.stamp = nullptr;
+  int extra = 0;
+  if (clear && clear->count) {
+    a.clear = *clear;
+    uint64_t most = 0;
+    for (int i = 0; i < clear->count; i++) most = std::max(most, clear->n16[i]);
+    extra = (int)std::min<uint64_t>(512, std::max<uint64_t>(1, (most + SK_THREADS * 8 - 1) / (SK_THREADS * 8)));
+  }
   a.tiles = d_tiles;
   a.packed = store.packed; a.bytes = store.bytes; a.exc_pos = store.exc_pos; a.exc_val = store.exc_val;
   a.stage_hash = stage_hash; a.stage_wpos = stage_wpos; a.tile_count = tile_count;
@@ -133,7 +146,8 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   a.code_words = (int32_t)(image / 4);
   auto launch = [&](auto kernel) {
     if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(ntiles), dim3(SK_THREADS), lds, st, a);
+    hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), lds, st, a);
+    extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;          // (only the first launch zeroes)
   };
   // plain-ACGT tiles from the 2-bit image; protein tiles and tiles with other bytes through the byte image
   if (!a.protein) { if (P.kmer_size == 16) launch(k_sketch_tiles<16, false>); else launch(k_sketch_tiles<0, false>); }
@@ -859,10 +873,9 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       cl.add(ln.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(ln.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(ln.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
       if (!bins_cleared) { cl.add(w.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long)); bins_cleared = true; }
-      cl.launch(st);
+      // ---- K1 (its extra workgroups zero the ranges above beside the hashing) + per-fragment sort/unique ----
+      launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st, &cl.a);
     }
-    // ---- K1 + per-fragment sort/unique ----
-    launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st);
     {
       QuerySketchArgs a;
       a.frag_tile_lo = g.d_frag_tile_lo + f0;

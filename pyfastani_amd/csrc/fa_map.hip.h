@@ -25,12 +25,6 @@
 
 namespace fa {
 
-// Stage timings of a query pass without host-side events: the first thread of the first kernel of every stage leaves
-// the chip-wide 100 MHz counter in the pass's status block (the kernels of a pass run one after the other on a stream,
-// so the difference of two stamps is the time of everything in between).
-__device__ __forceinline__ void stage_stamp(unsigned long long *stamp) {
-  if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
-}
 
 
 constexpr int MAP_THREADS = 256;
@@ -2161,17 +2155,4 @@ __global__ void k_flag_nonzero(const int32_t *row_count, int64_t n, int32_t *fla
 
 
 // One launch instead of a dozen hipMemsetAsync calls: zero up to 8 device ranges (sizes in 16-byte units).
-struct ClearArgs {
-  uint4 *ptr[8];
-  uint64_t n16[8];
-  int count;
-  unsigned long long *stamp;       // the stamps of the pass: [0] = its start (see stage_stamp)
-};
-__global__ __launch_bounds__(256) void k_clear(ClearArgs a) {
-  if (a.stamp && blockIdx.x == 0 && threadIdx.x == 0) { a.stamp[0] = __builtin_amdgcn_s_memrealtime(); a.stamp[3] = 0; }   // [3]: CGI stage, if any
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (int r = 0; r < a.count; r++)
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n16[r]; i += stride) a.ptr[r][i] = make_uint4(0, 0, 0, 0);
-}
-
 }  // namespace fa

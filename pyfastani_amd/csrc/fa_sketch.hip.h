@@ -546,6 +546,31 @@ __device__ __forceinline__ bool hash_bytes(const uint8_t *bytes, int b, int k, b
   return hf != hb;
 }
 
+// Stage timings of a query pass without host-side events: the first thread of the first kernel of every stage leaves
+// the chip-wide 100 MHz counter in the pass's status block (the kernels of a pass run one after the other on a stream,
+// so the difference of two stamps is the time of everything in between).
+__device__ __forceinline__ void stage_stamp(unsigned long long *stamp) {
+  if (stamp && blockIdx.x == 0 && threadIdx.x == 0) *stamp = __builtin_amdgcn_s_memrealtime();
+}
+
+// Zeroing several device ranges in one go (every counter and table of a query pass).  As a kernel of its own (k_clear) or
+// as extra workgroups behind the tiles of k_sketch_tiles, where the memory-bound zeroing runs beside the hashing.
+struct ClearArgs {
+  uint4 *ptr[8];
+  uint64_t n16[8];
+  int count;
+  unsigned long long *stamp;       // the stamps of the pass: [0] = its start (see stage_stamp)
+};
+__device__ __forceinline__ void clear_ranges(const ClearArgs &a, uint32_t block, uint32_t blocks) {
+  const uint64_t stride = (uint64_t)blocks * blockDim.x;
+  for (int r = 0; r < a.count; r++)
+    for (uint64_t i = (uint64_t)block * blockDim.x + threadIdx.x; i < a.n16[r]; i += stride) a.ptr[r][i] = make_uint4(0, 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void k_clear(ClearArgs a) {
+  if (a.stamp && blockIdx.x == 0 && threadIdx.x == 0) { a.stamp[0] = __builtin_amdgcn_s_memrealtime(); a.stamp[3] = 0; }   // [3]: CGI stage, if any
+  clear_ranges(a, blockIdx.x, gridDim.x);
+}
+
 struct SketchArgs {
   const Tile *tiles;
   const uint32_t *packed;
@@ -559,6 +584,8 @@ struct SketchArgs {
   int32_t protein;
   int32_t code_words;     // LDS words reserved for the 2-bit image / byte image
   int32_t npos_cap;       // LDS key slots: TILE + 2w - 2
+  int32_t ntiles;         // workgroups beyond the tiles zero the ranges of `clear` (a query pass)
+  ClearArgs clear;
 };
 
 // LDS carve-up (dynamic): [image: code_words*4 B][keyA: npos_cap*8][keyB: npos_cap*8][valid: (npos_cap/64+1)*8]
@@ -578,6 +605,12 @@ template <int KT, bool BYTES>
 __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(SketchArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= a.ntiles) {                                // not a tile: one of the zeroing workgroups of a query pass
+    if (a.clear.stamp && blockIdx.x == (uint32_t)a.ntiles && tid == 0) a.clear.stamp[3] = 0;   // [3]: CGI stage, if any
+    clear_ranges(a.clear, blockIdx.x - (uint32_t)a.ntiles, gridDim.x - (uint32_t)a.ntiles);
+    return;
+  }
+  if (a.clear.stamp && blockIdx.x == 0 && tid == 0) a.clear.stamp[0] = __builtin_amdgcn_s_memrealtime();   // start of the pass
   const Tile t = a.tiles[blockIdx.x];
   if (BYTES ? (!a.protein && t.exc_n == 0) : (t.exc_n > 0)) return;
   const int k = KT ? KT : a.k, w = a.w;
