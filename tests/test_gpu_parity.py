@@ -1173,6 +1173,36 @@ def test_parts_pipelined_over_lanes_match(lanes, part):
     assert out["loci"] > 500 and (out["retries"] > 0 if part else True), out
 
 
+def test_stage_times_by_stamps_agree_with_hip_events():
+    # the stage times of a pass come from device stamps of the 100 MHz counter (fa_mapper_last_timings [0..4]); on request
+    # the L2 stage is bracketed by two HIP events on the library's stream as well ([16]): the two clocks must agree
+    g = syn.rng(4242)
+    anc = syn.random_codes(g, 1_500_000)
+    sk = pf.Sketch()
+    for i, d in enumerate((0.01, 0.04, 0.08, 0.12)):
+        sk.add_genome(i, syn.to_ascii(syn.mutate_codes(g, anc, d)))
+    mapper = sk.index()
+    q = syn.to_ascii(syn.mutate_codes(g, anc, 0.03))
+    mapper.query_genome(q)
+    check(lib.fa_mapper_set_stage_events(mapper._h, 1))
+    try:
+        l2, ev, total, parts = [], [], [], []
+        for _ in range(5):
+            assert len(mapper.query_genome(q)) == 4
+            ms = (C.c_float * 24)()
+            check(lib.fa_mapper_last_timings(mapper._h, ms, 24))
+            l2.append(ms[2]); ev.append(ms[16]); total.append(ms[4]); parts.append(sum(ms[0:4]))
+    finally:
+        check(lib.fa_mapper_set_stage_events(mapper._h, 0))
+    assert min(l2) > 0.01 and min(ev) > 0.01, (l2, ev)
+    assert abs(np.median(l2) - np.median(ev)) <= 0.15 * np.median(l2) + 0.01, (l2, ev)       # ms
+    assert abs(np.median(total) - np.median(parts)) <= 0.02 * np.median(total) + 0.005, (total, parts)
+    ms = (C.c_float * 24)()
+    mapper.query_genome(q)
+    check(lib.fa_mapper_last_timings(mapper._h, ms, 24))
+    assert ms[16] == 0.0                                                                       # off again
+
+
 def test_device_memory_is_stable():
     """Repeated queries, resident batches and mapper life cycles must not grow the device allocation (scripts/check_leaks.py)."""
     import subprocess
