@@ -385,7 +385,7 @@ struct Workspace {
   std::unique_ptr<Workspace> sub[2];
   hipEvent_t ev_bins = nullptr;
   uint64_t serial = 0;
-  int64_t pass_f0 = 0;
+  int64_t pass_f0 = 0, pass_F = 0;    // first fragment and number of fragments of the last pass
   // the one-query-at-a-time call (fa_mapper_query) recycles its batch object -- no device allocation per call -- and
   // builds the upload image in pinned memory; its rows come back through a pinned block too
   std::unique_ptr<fa_genomes> query_batch;
@@ -769,7 +769,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     }
   }
   w.serial++;
-  w.pass_f0 = range_f0;
+  w.pass_f0 = range_f0; w.pass_F = range_f1 - range_f0;
   for (int i = 0; i < n_lanes; i++) for (int e = 0; e < 6; e++) if (!lanes[i]->ev[e]) FA_HIP(hipEventCreate(&lanes[i]->ev[e]));
   if (!w.ev_bins) FA_HIP(hipEventCreate(&w.ev_bins));
   // the CGI bin table is cleared once per pass: with one lane by the k_clear of the first part launched (a void first
@@ -1846,6 +1846,12 @@ static std::vector<Workspace *> lanes_of_last_pass(Workspace &w) {
   std::vector<Workspace *> v;
   for (Workspace *x : {&w, w.sub[0].get(), w.sub[1].get()}) if (x && x->serial == w.serial && x->last_F > 0) v.push_back(x);
   std::sort(v.begin(), v.end(), [](const Workspace *a, const Workspace *b) { return a->last_f0 < b->last_f0; });
+  // a pass that ran in more parts than there are lanes (several passes of one genome, or parts that were repeated) has
+  // left only its last parts behind: say so instead of handing out a fraction of the pass as if it were all of it
+  int64_t covered = 0;
+  for (const Workspace *x : v) covered += x->last_F;
+  FA_REQUIRE(covered == w.pass_F, FA_ERR_UNSUPPORTED,
+             "the stage getters hold the last part of every lane only, and the last pass ran in more parts than that");
   return v;
 }
 int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t *n) {
