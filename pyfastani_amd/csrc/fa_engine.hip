@@ -888,15 +888,18 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
     }
     debug_sync(st, "sketch");
-    // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch) ----
-    {
+    // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch).  A kernel of its own
+    //      only where k_l1 / k_l1_big need the scratch offsets it produces; else workgroup F of k_l1's launch ----
+    const bool fold_totals = sp.scratch_words == 0;
+    if (!fold_totals)
       hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, ln.n_seeds.p, F, seed_slots, d_totals, ln.ovf_off.p,
                          d_stats, smax, sp.scratch_words, d_pinfo, &ln.status.p->stamp[1]);
-    }
     debug_sync(st, "lookup");
     // ---- L1 ----
     {
       L1Args a;
+      a.fold_totals = fold_totals ? 1 : 0; a.spec_smax = smax; a.F = F; a.totals = d_totals; a.stats = d_stats;
+      a.spec_scratch_words = sp.scratch_words; a.stamp = &ln.status.p->stamp[1];
       a.ix = ix; a.q_size = ln.q_size.p; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p; a.n_seeds = ln.n_seeds.p;
       a.ovf_off = ln.ovf_off.p; a.ovf_buf = ln.ovf_buf.p; a.min_hits_lut = w.lut_min_hits;
       a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
@@ -927,10 +930,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);
         if (seed_slots <= 16 * (uint32_t)NTT) {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3((unsigned)F), dim3(NTT), lds, st, a);
+          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3((unsigned)(F + (fold_totals ? 1 : 0))), dim3(NTT), lds, st, a);
         } else {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3((unsigned)F), dim3(NTT), lds, st, a);
+          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3((unsigned)(F + (fold_totals ? 1 : 0))), dim3(NTT), lds, st, a);
         }
       };
       if (l1_threads >= 1024) go(std::integral_constant<int, 1024>());

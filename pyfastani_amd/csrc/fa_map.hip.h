@@ -403,10 +403,10 @@ constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS =
 // totals[0] = sum of seeds, [1] = largest fragment, [2] = HBM scratch words for fragments whose seeds do not fit the
 // LDS slots of k_l1 (their offsets go to ovf_off).  One workgroup: thousands of same-address atomics from k_lookup cost
 // more than this.  Also checks the speculated sketch-size and scratch bounds.
-__global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
-                                                      uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
-                                                      uint64_t spec_scratch_words, unsigned long long *pinfo, unsigned long long *stamp) {
-  stage_stamp(stamp);                                                // start of the L1 stage
+// (one workgroup of any size: a kernel of its own when k_l1 needs the scratch offsets, else an extra workgroup of k_l1)
+__device__ __forceinline__ void seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
+                                            uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
+                                            uint64_t spec_scratch_words, unsigned long long *pinfo) {
   __shared__ unsigned long long sh_sum;
   __shared__ unsigned int sh_max, sh_any;
   if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; }
@@ -454,6 +454,12 @@ __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, i
     if (flags) atomicOr(&pinfo[1], flags);
   }
 }
+__global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
+                                                      uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
+                                                      uint64_t spec_scratch_words, unsigned long long *pinfo, unsigned long long *stamp) {
+  stage_stamp(stamp);                                                // start of the L1 stage
+  seed_totals(n_seeds, F, lds_seed_cap, totals, ovf_off, stats, spec_smax, spec_scratch_words, pinfo);
+}
 
 // ----------------------------------------------------------------------------------------------------------
 // L1: gather + sort the seed hits of a fragment, scan for >= minHits hits inside one fragment length, merge
@@ -461,12 +467,20 @@ __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, i
 // arrays in (fragment-local) order, and consecutive loci on the same reference genome share a `group`.
 // ----------------------------------------------------------------------------------------------------------
 struct L1Args {
+  // the seed totals of the pass (seed_totals) as workgroup number F of this launch, when nothing in the pass needs the
+  // scratch offsets they produce (no fragment has outgrown the LDS seed slots on this mapper yet)
+  int32_t fold_totals, spec_smax;
+  int64_t F;
+  uint64_t *totals;
+  const int32_t *stats;
+  uint64_t spec_scratch_words;
+  unsigned long long *stamp;     // stage_stamp: start of the L1 stage (when the totals are folded in)
   IndexView ix;
   const int32_t *q_size;
   const uint32_t *q_off;
   const uint32_t *q_cnt;
   const uint32_t *n_seeds;
-  const uint32_t *ovf_off;
+  uint32_t *ovf_off;
   uint32_t *ovf_buf;
   const int32_t *min_hits_lut;   // [smax+1]
   int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
@@ -500,6 +514,13 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax) 
 template <int NT, int E>
 __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
+  if (a.fold_totals) {
+    stage_stamp(a.stamp);
+    if ((int64_t)blockIdx.x == a.F) {
+      seed_totals(a.n_seeds, a.F, a.lds_seed_cap, a.totals, a.ovf_off, a.stats, a.spec_smax, a.spec_scratch_words, a.pinfo);
+      return;
+    }
+  }
   __shared__ uint32_t sh_scan[NT / 64];
   __shared__ uint32_t sh_run;       // running offset (gather)
   // candidate pass: running head count and the last flagged candidate so far, double-buffered by trip parity so that
