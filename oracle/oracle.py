@@ -18,6 +18,7 @@ def build(force=False):
     stale = lambda: not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in src)  # noqa: E731
     if force or stale():
         import fcntl
+        os.makedirs(os.path.dirname(_SO), exist_ok=True)       # a fresh checkout has no _build/ yet
         with open(_SO + ".lock", "w") as lock:                 # several processes may ask at once: one runs make
             fcntl.flock(lock, fcntl.LOCK_EX)
             if force or stale():
