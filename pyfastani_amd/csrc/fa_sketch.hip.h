@@ -399,9 +399,25 @@ inline void make_tiles(std::vector<Tile> &tiles, const HostStore &hs, int64_t of
 // ----------------------------------------------------------------------------------------------------------
 // device: MurmurHash3_x64_128, seed 42, low 32 bits (getHash)
 // ----------------------------------------------------------------------------------------------------------
+// h * 5 + c as a shift-and-add (v_lshl_add_u64) plus an add: the compiler's own choice for a 64-bit multiply by five is
+// two v_mad_u64_u32, which issue at a quarter of the rate (the hashing loop is bound by exactly those)
+__device__ __forceinline__ uint64_t mul5_add(uint64_t h, uint32_t c) {
+  uint64_t t = h;
+  asm("" : "+v"(t));                                   // (an opaque copy, or (h << 2) + h is folded back into h * 5)
+  return (h << 2) + t + c;
+}
+
 struct Murmur {
   uint64_t h1, h2;
-  __device__ __forceinline__ static uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+  // a 64-bit rotation by a constant is two v_alignbit_b32 on the halves (the generic form compiles to 64-bit shifts and
+  // ORs, twice the instructions; there are eight rotations per k-mer position)
+  __device__ __forceinline__ static uint64_t rotl(uint64_t x, int r) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (r >= 32) { const uint32_t t = lo; lo = hi; hi = t; r -= 32; }
+    if (r == 0) return ((uint64_t)hi << 32) | lo;
+    const uint32_t nh = __builtin_amdgcn_alignbit(hi, lo, 32 - r), nl = __builtin_amdgcn_alignbit(lo, hi, 32 - r);
+    return ((uint64_t)nh << 32) | nl;
+  }
   __device__ __forceinline__ static uint64_t fmix(uint64_t k) {
     k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
     return k;
@@ -415,9 +431,9 @@ struct Murmur {
   }
   __device__ __forceinline__ void block(uint64_t k1, uint64_t k2) {
     mix1(k1);
-    h1 = rotl(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    h1 = rotl(h1, 27); h1 += h2; h1 = mul5_add(h1, 0x52dce729u);
     mix2(k2);
-    h2 = rotl(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    h2 = rotl(h2, 31); h2 += h1; h2 = mul5_add(h2, 0x38495ab5u);
   }
   __device__ __forceinline__ void tail(uint64_t k1, uint64_t k2, int rem) {
     if (rem > 8) mix2(k2);
@@ -493,10 +509,10 @@ __device__ __forceinline__ uint32_t murmur16_premixed(uint64_t k1c1, uint64_t k2
   m.init();
   uint64_t k1 = Murmur::rotl(k1c1, 31) * 0x4cf5ad432745937fULL;
   m.h1 ^= k1;
-  m.h1 = Murmur::rotl(m.h1, 27); m.h1 += m.h2; m.h1 = m.h1 * 5 + 0x52dce729;
+  m.h1 = Murmur::rotl(m.h1, 27); m.h1 += m.h2; m.h1 = mul5_add(m.h1, 0x52dce729u);
   uint64_t k2 = Murmur::rotl(k2c2, 33) * 0x87c37b91114253d5ULL;
   m.h2 ^= k2;
-  m.h2 = Murmur::rotl(m.h2, 31); m.h2 += m.h1; m.h2 = m.h2 * 5 + 0x38495ab5;
+  m.h2 = Murmur::rotl(m.h2, 31); m.h2 += m.h1; m.h2 = mul5_add(m.h2, 0x38495ab5u);
   return m.finish(16);
 }
 __device__ __forceinline__ bool hash_codes16(const uint32_t *codes, int b, const uint64_t *tc1, const uint64_t *tc2, uint32_t &out) {
@@ -585,6 +601,7 @@ struct SketchArgs {
   int32_t code_words;     // LDS words reserved for the 2-bit image / byte image
   int32_t npos_cap;       // LDS key slots: TILE + 2w - 2
   int32_t ntiles;         // workgroups beyond the tiles zero the ranges of `clear` (a query pass)
+  int32_t fast;           // the 32-bit window minimum may be used (3 <= w <= 1022 and not switched off)
   ClearArgs clear;
 };
 
@@ -622,7 +639,10 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
   uint64_t *valid = keyB + a.npos_cap;
   uint64_t *emit = valid + (a.npos_cap / 64 + 1);
   uint32_t *prefix = (uint32_t *)(emit + TILE / 64);
-  uint64_t *tc1 = (uint64_t *)(((uintptr_t)(prefix + TILE / 64 + 1) + 15) & ~(uintptr_t)15), *tc2 = tc1 + 256;
+  // (an offset from `lds`, not a rounded-up pointer value: a pointer that went through an integer is a generic one to
+  // the compiler, and the eight table reads per position became flat loads instead of LDS reads)
+  const size_t tc_off = ((size_t)((unsigned char *)(prefix + TILE / 64 + 1) - lds) + 15) & ~(size_t)15;
+  uint64_t *tc1 = (uint64_t *)(lds + tc_off), *tc2 = tc1 + 256;
 
   const int hb = min(t.pos0, 2 * w - 2);          // halo of k-mer positions in front of the tile
   const int jlo = t.pos0 - hb;                    // first k-mer position computed (sequence-local)
@@ -664,6 +684,12 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
   __syncthreads();
 
   // ---- 2. hash both strands, canonical minimum, validity ----
+  // The 16 B per position behind the image are one pool of 32-bit words.  Hs[j] = canonical hash of position j.
+  uint32_t *const pool = (uint32_t *)keyA;
+  uint32_t *const Hs = pool;
+  __shared__ int tile_plain;                        // every position valid and no hash equal to the "none" value
+  if (tid == 0) tile_plain = 1;
+  __syncthreads();
   for (int j0 = 0; j0 < npt; j0 += SK_THREADS) {
     int j = j0 + tid;
     bool ok = false;
@@ -673,57 +699,123 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
       else if (KT == 16) ok = hash_codes16(codes, shift + j, tc1, tc2, h);
       else ok = hash_codes<KT>(codes, shift + j, k, h);
     }
-    uint64_t key = ok ? (((uint64_t)h << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)j)) : ~0ULL;
     uint64_t bal = __ballot(ok);
-    if (j < a.npos_cap) keyA[j] = key;
+    if (j < a.npos_cap) Hs[j] = ok ? h : 0xFFFFFFFFu;
+    if (__ballot(j < npt && (!ok || h == 0xFFFFFFFFu)) && lane == 0) tile_plain = 0;
     if (lane == 0 && (j0 / 64 + wave) <= a.npos_cap / 64) valid[j0 / 64 + wave] = bal;
   }
   __syncthreads();
-
-  // ---- 3. sparse table: after `levels` doubling passes X[j] = min key over [j, j + 2^levels) ----
-  uint64_t *X = keyA, *Y = keyB;
-  for (int lv = 0; lv < a.levels; lv++) {
-    const int step = 1 << lv;
-    for (int j = tid; j < npt; j += SK_THREADS) {
-      uint64_t v = X[j];
-      if (j + step < npt) { uint64_t u = X[j + step]; v = u < v ? u : v; }
-      Y[j] = v;
-    }
-    __syncthreads();
-    uint64_t *tmp = X; X = Y; Y = tmp;
-  }
-  const int span = 1 << a.levels;                 // span <= w < 2*span
-
-  // ---- 4. emission: the window argmin changed since the previous valid position ----
   const int first_check = (w - 1) - jlo;          // tile-local index of sequence position w-1
   uint32_t rec_hash[SK_ITERS];
   bool rec_emit[SK_ITERS];
-#pragma unroll
-  for (int it = 0; it < SK_ITERS; it++) {
-    const int tt = it * SK_THREADS + tid;         // tile position
-    const int il = hb + tt;                       // tile-local index incl. halo
-    bool em = false;
-    uint32_t hsh = 0;
-    if (tt < t.npos && il >= first_check && ((valid[il >> 6] >> (il & 63)) & 1ULL)) {
-      uint64_t a1 = X[il - w + 1], a2 = X[il - span + 1];
-      uint64_t cur = a1 < a2 ? a1 : a2;
-      hsh = (uint32_t)(cur >> 32);
-      // previous valid position that was itself checked, within the last w-1 positions
-      int lo = max(first_check, il - w + 1), prev = -1;
-      for (int q = il - 1; q >= lo; q--) {
-        if ((valid[q >> 6] >> (q & 63)) & 1ULL) { prev = q; break; }
+
+  if (a.fast && tile_plain) {
+    // ---- 3a / 4a. all positions valid (all but one tile in 10^4: a k-mer equal to its reverse complement is rare):
+    // the window minimum and the emission test need the hashes only.  With m(i), p(i) the minimum of the window that
+    // ends at i and its rightmost position: p(i) != p(i-1) iff the newcomer is a minimum of the old window as well
+    // (rightmost wins: H[i] <= m(i-1)) or the old one stood at the position that leaves, alone (H[i-w] < M2, the minimum
+    // of the w-1 positions in between).  M2 comes from a table of minima over sp = 2^floor(log2(w-1)) positions, built
+    // in 32-bit passes that multiply the span by four (two passes for w = 24), then by two.
+    const int stride = a.npos_cap + w;            // Hs | P0 | P1, with room for the reads past the tile's end
+    int levels32 = 0;
+    while ((2 << levels32) <= w - 1) levels32++;
+    const int sp = 1 << levels32;
+    int src = 0, dst = stride, cur = 1;             // Hs is never written: the passes alternate between P0 and P1
+    while (cur * 4 <= sp) {
+      for (int j = tid; j < npt; j += SK_THREADS) {
+        const uint32_t x0 = pool[src + j], x1 = pool[src + j + cur], x2 = pool[src + j + 2 * cur], x3 = pool[src + j + 3 * cur];
+        pool[dst + j] = min(min(x0, x1), min(x2, x3));
       }
-      if (prev < 0) em = true;
-      else {
-        uint64_t b1 = X[prev - w + 1], b2 = X[prev - span + 1];
-        uint64_t old = b1 < b2 ? b1 : b2;
-        em = (uint32_t)old != (uint32_t)cur;      // low words hold ~position of the argmin
+      __syncthreads();
+      src = dst; dst = src == stride ? 2 * stride : stride; cur *= 4;
+    }
+    while (cur * 2 <= sp) {
+      for (int j = tid; j < npt; j += SK_THREADS) pool[dst + j] = min(pool[src + j], pool[src + j + cur]);
+      __syncthreads();
+      src = dst; dst = src == stride ? 2 * stride : stride; cur *= 2;
+    }
+    const uint32_t *X = pool + src;
+#pragma unroll
+    for (int it = 0; it < SK_ITERS; it++) {
+      const int tt = it * SK_THREADS + tid;         // tile position
+      const int il = hb + tt;                       // tile-local index incl. halo
+      bool em = false;
+      uint32_t hsh = 0;
+      if (tt < t.npos && il >= first_check) {
+        const uint32_t H = Hs[il], Hw = Hs[max(il - w, 0)];
+        const uint32_t M2 = min(X[il - w + 1], X[il - sp]);
+        hsh = min(M2, H);
+        em = il == first_check || H <= min(Hw, M2) || Hw < M2;
+      }
+      rec_hash[it] = hsh;
+      rec_emit[it] = em;
+      uint64_t bal = __ballot(em);
+      if (lane == 0) emit[it * (SK_THREADS / 64) + wave] = bal;
+    }
+  } else {
+    // ---- 3b. general form: 64-bit keys (hash, ~position; all ones for a position without a k-mer), sparse table: after
+    //      `levels` doubling passes X[j] = min key over [j, j + 2^levels) ----
+    {
+      uint32_t hreg[(TILE + 2048) / SK_THREADS + 1];
+      const int nreg = (int)(sizeof(hreg) / sizeof(hreg[0]));
+      // (npos_cap can exceed what the registers hold only for w > 1024: go through in rounds, back to front, so that
+      // no key overwrites a hash that is still to be read -- key j occupies the words 2j and 2j+1 >= j)
+      for (int r0 = (a.npos_cap - 1) / (SK_THREADS * nreg) * (SK_THREADS * nreg); r0 >= 0; r0 -= SK_THREADS * nreg) {
+#pragma unroll
+        for (int q = 0; q < nreg; q++) { const int j = r0 + q * SK_THREADS + tid; hreg[q] = j < a.npos_cap ? Hs[j] : 0u; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < nreg; q++) {
+          const int j = r0 + q * SK_THREADS + tid;
+          if (j < a.npos_cap) {
+            const bool ok = j < npt && ((valid[j >> 6] >> (j & 63)) & 1ULL);
+            keyA[j] = ok ? (((uint64_t)hreg[q] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)j)) : ~0ULL;
+          }
+        }
+        __syncthreads();
       }
     }
-    rec_hash[it] = hsh;
-    rec_emit[it] = em;
-    uint64_t bal = __ballot(em);
-    if (lane == 0) emit[it * (SK_THREADS / 64) + wave] = bal;
+    uint64_t *X = keyA, *Y = keyB;
+    for (int lv = 0; lv < a.levels; lv++) {
+      const int step = 1 << lv;
+      for (int j = tid; j < npt; j += SK_THREADS) {
+        uint64_t v = X[j];
+        if (j + step < npt) { uint64_t u = X[j + step]; v = u < v ? u : v; }
+        Y[j] = v;
+      }
+      __syncthreads();
+      uint64_t *tmp = X; X = Y; Y = tmp;
+    }
+    const int span = 1 << a.levels;                 // span <= w < 2*span
+
+    // ---- 4b. emission: the window argmin changed since the previous valid position ----
+#pragma unroll
+    for (int it = 0; it < SK_ITERS; it++) {
+      const int tt = it * SK_THREADS + tid;         // tile position
+      const int il = hb + tt;                       // tile-local index incl. halo
+      bool em = false;
+      uint32_t hsh = 0;
+      if (tt < t.npos && il >= first_check && ((valid[il >> 6] >> (il & 63)) & 1ULL)) {
+        uint64_t a1 = X[il - w + 1], a2 = X[il - span + 1];
+        uint64_t cur = a1 < a2 ? a1 : a2;
+        hsh = (uint32_t)(cur >> 32);
+        // previous valid position that was itself checked, within the last w-1 positions
+        int lo = max(first_check, il - w + 1), prev = -1;
+        for (int q = il - 1; q >= lo; q--) {
+          if ((valid[q >> 6] >> (q & 63)) & 1ULL) { prev = q; break; }
+        }
+        if (prev < 0) em = true;
+        else {
+          uint64_t b1 = X[prev - w + 1], b2 = X[prev - span + 1];
+          uint64_t old = b1 < b2 ? b1 : b2;
+          em = (uint32_t)old != (uint32_t)cur;      // low words hold ~position of the argmin
+        }
+      }
+      rec_hash[it] = hsh;
+      rec_emit[it] = em;
+      uint64_t bal = __ballot(em);
+      if (lane == 0) emit[it * (SK_THREADS / 64) + wave] = bal;
+    }
   }
   __syncthreads();
 
