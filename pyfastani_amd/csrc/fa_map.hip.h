@@ -316,24 +316,30 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
     }
   }
   __syncthreads();
-  if (n <= (int)blockDim.x) {
+  __shared__ uint8_t occ[MAP_THREADS];              // counted form: slot i of the sorted array holds a (distinct) hash
+  const bool counted = n <= (int)blockDim.x;
+  if (counted) {
     // the usual case (a 3 kb fragment holds ~240 minimizers): one record per thread, ranked by counting -- every thread
-    // reads the same LDS words (broadcast, four at a time), two barriers instead of the 36 of a bitonic network
+    // reads the same LDS words (broadcast, four at a time), two barriers instead of the 36 of a bitonic network.  The
+    // rank is the number of SMALLER hashes only (a compare and an add-with-carry per entry; breaking ties by position
+    // took twice the instructions, and this loop is a third of the kernel): equal hashes then land on one slot, the
+    // slots behind it stay empty, and the occupied slots are exactly what std::unique would keep.
     const int n4 = (n + 3) & ~3;
     for (int i = n + tid; i < n4; i += blockDim.x) buf[i] = SEED_PAD;
+    occ[tid] = 0;
     __syncthreads();
     const uint32_t x = tid < n ? buf[tid] : 0u;
     int rank = 0;
     const uint4 *b4 = (const uint4 *)buf;
     for (int j = 0; j < n4; j += 4) {
       const uint4 v = b4[j >> 2];
-      rank += (v.x < x || (v.x == x && j < tid)) ? 1 : 0;
-      rank += (v.y < x || (v.y == x && j + 1 < tid)) ? 1 : 0;
-      rank += (v.z < x || (v.z == x && j + 2 < tid)) ? 1 : 0;
-      rank += (v.w < x || (v.w == x && j + 3 < tid)) ? 1 : 0;
+      rank += v.x < x ? 1 : 0;
+      rank += v.y < x ? 1 : 0;
+      rank += v.z < x ? 1 : 0;
+      rank += v.w < x ? 1 : 0;
     }
     __syncthreads();
-    if (tid < n) buf[rank] = x;
+    if (tid < n) { buf[rank] = x; occ[rank] = 1; }
     __syncthreads();
   } else {
     uint32_t n32 = 1;
@@ -350,7 +356,8 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   uint32_t *out = a.q_hash + (size_t)f * a.qcap;
   for (int base = 0; base < n; base += blockDim.x) {
     int i = base + tid;
-    bool keep = i < n && (i == 0 || buf[i] != buf[i - 1]);
+    bool keep = i < n && (counted ? occ[i] != 0 : (i == 0 || buf[i] != buf[i - 1]));
+    const uint32_t val = i < n ? buf[i] : 0u;
     uint64_t bal = __ballot(keep);
     __shared__ int wave_cnt[MAP_THREADS / 64];
     int lane = tid & 63, wv = tid >> 6;
@@ -358,7 +365,10 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
     __syncthreads();
     int off = sh_total;
     for (int q = 0; q < wv; q++) off += wave_cnt[q];
-    if (keep) out[off + __popcll(bal & ((1ULL << lane) - 1ULL))] = buf[i];
+    // (also kept in LDS, compacted in place -- every read of this round is behind the barrier above, and a slot that a
+    // later round still reads is only ever written with its own value -- so that the lookup below need not read the
+    // hashes back from global memory)
+    if (keep) { const int pos = off + __popcll(bal & ((1ULL << lane) - 1ULL)); out[pos] = val; buf[pos] = val; }
     __syncthreads();
     if (tid == 0) { int tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += wave_cnt[q]; sh_total += tot; }
     __syncthreads();
@@ -375,7 +385,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
   __shared__ uint32_t red[MAP_THREADS / 64];
   uint32_t mine = 0;
   for (int j = tid; j < s; j += blockDim.x) {
-    const uint32_t h = out[j];
+    const uint32_t h = buf[j];
     uint32_t off = 0, cnt = 0;
     if (index_find(a.ix, h, off, cnt)) {
       if ((int64_t)cnt >= (int64_t)a.ix.freq_threshold) cnt = 0;   // strict `size < threshold` keeps the list
