@@ -96,6 +96,17 @@ def test_minimizer_streams(k, frag):
         assert np.array_equal(gh, oh) and np.array_equal(gw, ow), f"{name}: gpu {len(gh)} records, oracle {len(oh)}"
 
 
+def test_minimizer_streams_through_the_general_window_minimum():
+    # k_sketch_tiles takes the 32-bit form of the window minimum for every tile whose positions are all valid and falls
+    # back to 64-bit (hash, ~position) keys for the others (a k-mer equal to its reverse complement, w < 3 or > 1022).
+    # FA_K1_GENERAL=1 sends every tile through the fallback: the same streams, edge cases and parameter cells must hold.
+    import subprocess
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                          "-k", "test_minimizer_streams and not general or test_edge_cases or test_degenerate_and_unusual_parameter_cells"],
+                         env=dict(os.environ, FA_K1_GENERAL="1"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and " passed" in res.stdout, res.stdout[-3000:] + res.stderr[-2000:]
+
+
 def test_reference_sketch_multi_contig_and_index():
     g = syn.rng(11)
     anc, members, _ = syn.family(11, 4, 200_000)
