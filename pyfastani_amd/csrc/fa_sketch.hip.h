@@ -504,6 +504,21 @@ __device__ __forceinline__ uint64_t premix(const uint64_t *tab, uint32_t codes16
   const uint32_t hi = (uint32_t)tab[(codes16 >> 8) & 0xFFu];
   return lo + ((uint64_t)hi << 32);
 }
+// the two tables as constants of the code object (every workgroup used to compute its copy: 31 vector instructions per
+// thread and tile, two 64-bit multiplies among them; now one 16-byte read per thread)
+struct PremixTables {
+  uint64_t v[512];
+  constexpr PremixTables() : v() {
+    for (uint32_t g = 0; g < 256; g++) {
+      uint64_t A = 0;
+      for (int j = 0; j < 4; j++) A |= (uint64_t)("ACGT"[(g >> (2 * j)) & 3u]) << (8 * j);
+      v[g] = A * 0x87c37b91114253d5ULL;
+      v[256 + g] = A * 0x4cf5ad432745937fULL;
+    }
+  }
+};
+__device__ const PremixTables d_premix = PremixTables();
+
 __device__ __forceinline__ uint32_t murmur16_premixed(uint64_t k1c1, uint64_t k2c2) {
   Murmur m;
   m.init();
@@ -601,7 +616,7 @@ struct SketchArgs {
   int32_t code_words;     // LDS words reserved for the 2-bit image / byte image
   int32_t npos_cap;       // LDS key slots: TILE + 2w - 2
   int32_t ntiles;         // workgroups beyond the tiles zero the ranges of `clear` (a query pass)
-  int32_t fast;           // the 32-bit window minimum may be used (3 <= w <= 1022 and not switched off)
+  int32_t fast;           // the 32-bit window minimum may be used (3 <= w <= 1000 and not switched off)
   ClearArgs clear;
 };
 
@@ -651,11 +666,7 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
   const int64_t base0 = t.base + jlo;             // store offset of the first staged base
   const bool byte_mode = BYTES;
   int shift = 0;
-  if (!BYTES && KT == 16 && tid < 256) {
-    const uint64_t A = expand4((uint32_t)tid);
-    tc1[tid] = A * 0x87c37b91114253d5ULL;
-    tc2[tid] = A * 0x4cf5ad432745937fULL;
-  }
+  if (!BYTES && KT == 16 && tid < 256) { tc1[tid] = d_premix.v[tid]; tc2[tid] = d_premix.v[256 + tid]; }
 
   // ---- 1. stage the sequence image ----
   if (BYTES && a.protein) {
@@ -716,20 +727,49 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
     // (rightmost wins: H[i] <= m(i-1)) or the old one stood at the position that leaves, alone (H[i-w] < M2, the minimum
     // of the w-1 positions in between).  M2 comes from a table of minima over sp = 2^floor(log2(w-1)) positions, built
     // in 32-bit passes that multiply the span by four (two passes for w = 24), then by two.
-    const int stride = a.npos_cap + w;            // Hs | P0 | P1, with room for the reads past the tile's end
+    // Hs | P0 | P1, each with room for the reads past the tile's end, 16-byte aligned: a thread takes FOUR consecutive
+    // positions per trip, reads whole 16-byte words and shares the loads and the partial minima between its outputs
+    // (the one-position-per-thread form spent 28 instructions per position on the two passes of w = 24, this one 10)
+    const int stride = ((a.npos_cap + w + 3) & ~3) + 4;
     int levels32 = 0;
     while ((2 << levels32) <= w - 1) levels32++;
     const int sp = 1 << levels32;
     int src = 0, dst = stride, cur = 1;             // Hs is never written: the passes alternate between P0 and P1
-    while (cur * 4 <= sp) {
-      for (int j = tid; j < npt; j += SK_THREADS) {
-        const uint32_t x0 = pool[src + j], x1 = pool[src + j + cur], x2 = pool[src + j + 2 * cur], x3 = pool[src + j + 3 * cur];
-        pool[dst + j] = min(min(x0, x1), min(x2, x3));
+    if (sp >= 4) {
+      // span 1 -> 4: out[i] = min(h[i .. i+3]) for i = 0..3 from h[0 .. 6], with the minima of (h2,h3) and (h4,h5) shared
+      for (int b = 4 * tid; b < npt; b += 4 * SK_THREADS) {
+        const uint4 lo = *(const uint4 *)(pool + src + b), hi = *(const uint4 *)(pool + src + b + 4);
+        const uint32_t m23 = min(lo.z, lo.w), m45 = min(hi.x, hi.y);
+        uint4 o;
+        o.x = min(min(lo.x, lo.y), m23); o.y = min(min(lo.y, m23), hi.x); o.z = min(m23, m45); o.w = min(min(lo.w, m45), hi.z);
+        *(uint4 *)(pool + dst + b) = o;
+      }
+      __syncthreads();
+      src = dst; dst = src == stride ? 2 * stride : stride; cur = 4;
+    }
+    while (cur >= 4 && cur * 4 <= sp) {
+      for (int b = 4 * tid; b < npt; b += 4 * SK_THREADS) {
+        const uint4 q0 = *(const uint4 *)(pool + src + b), q1 = *(const uint4 *)(pool + src + b + cur);
+        const uint4 q2 = *(const uint4 *)(pool + src + b + 2 * cur), q3 = *(const uint4 *)(pool + src + b + 3 * cur);
+        uint4 o;
+        o.x = min(min(q0.x, q1.x), min(q2.x, q3.x)); o.y = min(min(q0.y, q1.y), min(q2.y, q3.y));
+        o.z = min(min(q0.z, q1.z), min(q2.z, q3.z)); o.w = min(min(q0.w, q1.w), min(q2.w, q3.w));
+        *(uint4 *)(pool + dst + b) = o;
       }
       __syncthreads();
       src = dst; dst = src == stride ? 2 * stride : stride; cur *= 4;
     }
-    while (cur * 2 <= sp) {
+    if (cur >= 4 && cur * 2 <= sp) {
+      for (int b = 4 * tid; b < npt; b += 4 * SK_THREADS) {
+        const uint4 q0 = *(const uint4 *)(pool + src + b), q1 = *(const uint4 *)(pool + src + b + cur);
+        uint4 o;
+        o.x = min(q0.x, q1.x); o.y = min(q0.y, q1.y); o.z = min(q0.z, q1.z); o.w = min(q0.w, q1.w);
+        *(uint4 *)(pool + dst + b) = o;
+      }
+      __syncthreads();
+      src = dst; dst = src == stride ? 2 * stride : stride; cur *= 2;
+    }
+    if (cur * 2 <= sp) {                             // (sp = 2: w = 3 or 4)
       for (int j = tid; j < npt; j += SK_THREADS) pool[dst + j] = min(pool[src + j], pool[src + j + cur]);
       __syncthreads();
       src = dst; dst = src == stride ? 2 * stride : stride; cur *= 2;

@@ -98,7 +98,7 @@ def test_minimizer_streams(k, frag):
 
 def test_minimizer_streams_through_the_general_window_minimum():
     # k_sketch_tiles takes the 32-bit form of the window minimum for every tile whose positions are all valid and falls
-    # back to 64-bit (hash, ~position) keys for the others (a k-mer equal to its reverse complement, w < 3 or > 1022).
+    # back to 64-bit (hash, ~position) keys for the others (a k-mer equal to its reverse complement, w < 3 or > 1000).
     # FA_K1_GENERAL=1 sends every tile through the fallback: the same streams, edge cases and parameter cells must hold.
     import subprocess
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
