@@ -145,7 +145,7 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   static const bool k1_general = getenv("FA_K1_GENERAL") && atoi(getenv("FA_K1_GENERAL")) != 0;
   a.fast = (!k1_general && P.window_size >= 3 && P.window_size <= 1000) ? 1 : 0;   // (three padded arrays in the LDS of two key arrays)
   size_t lds = sketch_lds_bytes(P.kmer_size, P.window_size);
-  size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 2 * 256 * 8);
+  size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 4 * 256 * 8);
   a.code_words = (int32_t)(image / 4);
   auto launch = [&](auto kernel) {
     if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

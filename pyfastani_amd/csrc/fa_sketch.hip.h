@@ -497,23 +497,24 @@ __device__ __forceinline__ bool hash_codes(const uint32_t *codes, int b, int k_r
 
 // k = 16 fast path.  The first multiply of each 8-byte half of the MurmurHash3 block is linear in the key bytes:
 // with A(g) the four ASCII bytes of the 8-bit code group g,  key*c = A(g0)*c + (A(g1)*c mod 2^32) << 32.
-// TC1[g] = A(g) * c1 and TC2[g] = A(g) * c2 (mod 2^64) sit in LDS (2 x 2 KiB, built once per workgroup), so the ASCII
-// bytes are never materialised and 4 of the 16 64-bit multiplies per base become two LDS reads and an add each.
-__device__ __forceinline__ uint64_t premix(const uint64_t *tab, uint32_t codes16) {
-  const uint64_t lo = tab[codes16 & 0xFFu];
-  const uint32_t hi = (uint32_t)tab[(codes16 >> 8) & 0xFFu];
-  return lo + ((uint64_t)hi << 32);
-}
-// the two tables as constants of the code object (every workgroup used to compute its copy: 31 vector instructions per
-// thread and tile, two 64-bit multiplies among them; now one 16-byte read per thread)
+// TC1[g] = A(g) * c1 and TC2[g] = A(g) * c2 (mod 2^64) sit in LDS, so the ASCII bytes are never materialised and 4 of the
+// 16 64-bit multiplies per base become two LDS reads and an add each.  The tables are constants of the code object,
+// copied into LDS by every workgroup (each used to compute its copy: 31 vector instructions per thread and tile, two
+// 64-bit multiplies among them).
 struct PremixTables {
-  uint64_t v[512];
+  uint64_t v[1024];                                 // TC1 | TC2 | TR1 | TR2, with TRx[g] = TCx[reverse complement of group g]
   constexpr PremixTables() : v() {
     for (uint32_t g = 0; g < 256; g++) {
       uint64_t A = 0;
       for (int j = 0; j < 4; j++) A |= (uint64_t)("ACGT"[(g >> (2 * j)) & 3u]) << (8 * j);
       v[g] = A * 0x87c37b91114253d5ULL;
       v[256 + g] = A * 0x4cf5ad432745937fULL;
+    }
+    for (uint32_t g = 0; g < 256; g++) {
+      uint32_t rc = 0;
+      for (int j = 0; j < 4; j++) rc |= (3u - ((g >> (2 * (3 - j))) & 3u)) << (2 * j);   // code j of the reverse complement = 3 - code (3-j)
+      v[512 + g] = v[rc];
+      v[768 + g] = v[256 + rc];
     }
   }
 };
@@ -530,11 +531,17 @@ __device__ __forceinline__ uint32_t murmur16_premixed(uint64_t k1c1, uint64_t k2
   m.h2 = Murmur::rotl(m.h2, 31); m.h2 += m.h1; m.h2 = mul5_add(m.h2, 0x38495ab5u);
   return m.finish(16);
 }
-__device__ __forceinline__ bool hash_codes16(const uint32_t *codes, int b, const uint64_t *tc1, const uint64_t *tc2, uint32_t &out) {
+// Both strands from the four 8-bit groups g0..g3 of the forward k-mer: the reverse complement's groups are rc(g3), rc(g2),
+// rc(g1), rc(g0), and TR1 / TR2 are the tables pre-composed with rc -- the reverse-complement word is never formed, and a
+// group's two table reads share one address.
+__device__ __forceinline__ bool hash_codes16(const uint32_t *codes, int b, const uint64_t *tc, uint32_t &out) {
   const uint32_t cf = get16(codes, b);
-  const uint32_t cr = revcomp16(cf);
-  const uint32_t hf = murmur16_premixed(premix(tc1, cf & 0xFFFFu), premix(tc2, cf >> 16));
-  const uint32_t hb = murmur16_premixed(premix(tc1, cr & 0xFFFFu), premix(tc2, cr >> 16));
+  const uint32_t g0 = cf & 0xFFu, g1 = (cf >> 8) & 0xFFu, g2 = (cf >> 16) & 0xFFu, g3 = cf >> 24;
+  const uint64_t *tc1 = tc, *tc2 = tc + 256, *tr1 = tc + 512, *tr2 = tc + 768;
+  const uint64_t f1 = tc1[g0] + ((uint64_t)(uint32_t)tc1[g1] << 32), f2 = tc2[g2] + ((uint64_t)(uint32_t)tc2[g3] << 32);
+  const uint64_t r1 = tr1[g3] + ((uint64_t)(uint32_t)tr1[g2] << 32), r2 = tr2[g1] + ((uint64_t)(uint32_t)tr2[g0] << 32);
+  const uint32_t hf = murmur16_premixed(f1, f2);
+  const uint32_t hb = murmur16_premixed(r1, r2);
   out = hf < hb ? hf : hb;
   return hf != hb;
 }
@@ -627,7 +634,7 @@ inline size_t sketch_lds_bytes(int k, int w) {
   size_t span = npos_cap + (size_t)k - 1 + 64;            // bases (or bytes) staged, with slack for get16 over-read
   size_t image = ((span + 3) / 4 + 4) * 4;                // byte image is the larger of the two
   image = (image + 15) / 16 * 16;
-  return image + npos_cap * 16 + (npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 2 * 256 * 8;
+  return image + npos_cap * 16 + (npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 4 * 256 * 8;
 }
 
 // BYTES = false: tiles of plain ACGT, hashed from the 2-bit image (the hot kernel, kept free of the byte path so that it
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
   // (an offset from `lds`, not a rounded-up pointer value: a pointer that went through an integer is a generic one to
   // the compiler, and the eight table reads per position became flat loads instead of LDS reads)
   const size_t tc_off = ((size_t)((unsigned char *)(prefix + TILE / 64 + 1) - lds) + 15) & ~(size_t)15;
-  uint64_t *tc1 = (uint64_t *)(lds + tc_off), *tc2 = tc1 + 256;
+  uint64_t *tc1 = (uint64_t *)(lds + tc_off);                        // TC1 | TC2 | TR1 | TR2 (PremixTables)
 
   const int hb = min(t.pos0, 2 * w - 2);          // halo of k-mer positions in front of the tile
   const int jlo = t.pos0 - hb;                    // first k-mer position computed (sequence-local)
@@ -666,7 +673,7 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
   const int64_t base0 = t.base + jlo;             // store offset of the first staged base
   const bool byte_mode = BYTES;
   int shift = 0;
-  if (!BYTES && KT == 16 && tid < 256) { tc1[tid] = d_premix.v[tid]; tc2[tid] = d_premix.v[256 + tid]; }
+  if (!BYTES && KT == 16) for (int i = tid; i < 1024; i += SK_THREADS) tc1[i] = d_premix.v[i];
 
   // ---- 1. stage the sequence image ----
   if (BYTES && a.protein) {
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(SK_THREADS, BYTES ? 2 : 4) void k_sketch_tiles(Sket
     uint32_t h = 0xFFFFFFFFu;
     if (j < npt) {
       if (BYTES) ok = hash_bytes(img, j, k, a.protein != 0, h);
-      else if (KT == 16) ok = hash_codes16(codes, shift + j, tc1, tc2, h);
+      else if (KT == 16) ok = hash_codes16(codes, shift + j, tc1, h);
       else ok = hash_codes<KT>(codes, shift + j, k, h);
     }
     uint64_t bal = __ballot(ok);
