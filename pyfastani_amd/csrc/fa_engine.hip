@@ -119,6 +119,7 @@ struct StageTrace {
 };
 
 // `clear` (a query pass): ranges zeroed by extra workgroups of the first launch, beside the hashing
+static uint64_t env_u64(const char *name, uint64_t dflt);
 static void launch_sketch_tiles(const fa_params &P, const StoreView &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
                                 int32_t *stage_wpos, int32_t *tile_count, hipStream_t st, const ClearArgs *clear = nullptr) {
   if (ntiles <= 0) {
@@ -147,9 +148,10 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   size_t lds = sketch_lds_bytes(P.kmer_size, P.window_size);
   size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 4 * 256 * 8);
   a.code_words = (int32_t)(image / 4);
+  static const size_t lds_pad = (size_t)env_u64("FA_K1_LDS_PAD", 0);     // experiment: unused LDS, i.e. fewer workgroups per CU
   auto launch = [&](auto kernel) {
-    if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), lds, st, a);
+    if (lds + lds_pad > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
+    hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), lds + lds_pad, st, a);
     extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;          // (only the first launch zeroes)
   };
   // plain-ACGT tiles from the 2-bit image; protein tiles and tiles with other bytes through the byte image
