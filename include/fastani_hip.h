@@ -132,6 +132,10 @@ void fa_mapper_free(fa_mapper *m);
 int fa_mapper_freq_threshold(fa_mapper *m, int *threshold);
 /* len(Mapper.lookup_index) = minimizerPosLookupIndex.size(), _fastani.pyx:1454-1456 */
 int fa_mapper_lookup_size(fa_mapper *m, int64_t *n);
+/* The HIP device the mapper's index lives on (fa_set_device at the time Sketch.index() ran; -1: the calling thread's
+ * current device).  No reference counterpart (the reference has no device); used by the multi-GPU layer to allocate the
+ * tensors it hands to fa_mapper_lookup_export_device / fa_mapper_set_global_frequency on the right GPU. */
+int fa_mapper_device(fa_mapper *m, int *device);
 /* Reference-sharded index ("when the index does not fit"): every rank indexes its own share of
  * the reference genomes, and the frequency threshold of Sketch_t::computeFreqHist / the `size < threshold` filter of
  * _fastani.pyx:946 must then be taken over the position lists of ALL shards.  fa_mapper_lookup_export_device copies

@@ -705,9 +705,10 @@ cdef class Sketch(_Parameterized):
 
     cpdef Sketch clear(self):
         """Reset the `Sketch`, removing any reference genome it may contain (_fastani.pyx:746-767)."""
-        self._names.clear()
-        _check(hip.fa_sketch_clear(self._hs))
-        self._version += 1
+        with self._lock:                       # (add_draft / add_genome / add_fasta hold it while they append contigs)
+            self._names.clear()
+            _check(hip.fa_sketch_clear(self._hs))
+            self._version += 1
         return self
 
     cpdef Mapper index(self):
@@ -716,14 +717,17 @@ cdef class Sketch(_Parameterized):
         Ownership of the data moves to the returned `Mapper`; this `Sketch` is cleared but stays usable."""
         cdef Mapper mapper = Mapper.__new__(Mapper)
         cdef int code
-        with nogil:
-            code = hip.fa_sketch_index(self._hs, &mapper._hm)                # Sketch_t::index + computeFreqHist, :790-791
-        _check(code)
-        mapper._p = self._p
-        mapper._threads = self._threads
-        mapper._names = self._names.copy()
-        self._names.clear()
-        self._version += 1
+        # under the lock of the add_* calls: a genome that another thread is half-way through adding must not be split
+        # between the mapper and the emptied sketch, and the names move in the same critical section as the records
+        with self._lock:
+            with nogil:
+                code = hip.fa_sketch_index(self._hs, &mapper._hm)            # Sketch_t::index + computeFreqHist, :790-791
+            _check(code)
+            mapper._p = self._p
+            mapper._threads = self._threads
+            mapper._names = self._names.copy()
+            self._names.clear()
+            self._version += 1
         return mapper
 
 
@@ -740,12 +744,14 @@ cdef class Mapper(_Parameterized):
     cdef list _names
     cdef vector[uint64_t] _lengths
     cdef bint _have_lengths
+    cdef int64_t _version                  # bumped by __setstate__: the `Minimizers` view caches per (object, version)
     cdef readonly object minimizers
 
     def __cinit__(self):
         self._hm = NULL
         self._names = []
         self._have_lengths = False
+        self._version = 0
         self.minimizers = Minimizers(self)
 
     def __init__(self, *args, **kwargs):
@@ -762,7 +768,7 @@ cdef class Mapper(_Parameterized):
         return <uintptr_t> self._hm
 
     def _state_token(self):
-        return ("mapper", id(self))
+        return ("mapper", id(self), self._version)
 
     def _num_minimizers(self):
         cdef int64_t n = 0
@@ -837,6 +843,7 @@ cdef class Mapper(_Parameterized):
         self._threads = other._threads
         self._names = other._names
         self._have_lengths = False
+        self._version += 1
 
     def __reduce__(self):
         return (_unpickle_mapper, (self.__getstate__(),))
@@ -847,6 +854,12 @@ cdef class Mapper(_Parameterized):
         """`MinimizerIndex`: the table of minimizer positions in the reference genomes (_fastani.pyx:869-881)."""
         return MinimizerIndex(self)
 
+    def _torch_device(self):
+        import torch
+        cdef int d = -1
+        _check(hip.fa_mapper_device(self._hm, &d))
+        return torch.device("cuda", d if d >= 0 else torch.cuda.current_device())
+
     def _export_lookup(self, device="cuda"):
         """Distinct hashes of this index (ascending, ``int32`` bit patterns) and the lengths of their position lists, as
         two torch tensors on ``device``: what a rank contributes to the global frequency threshold of a
@@ -856,9 +869,10 @@ cdef class Mapper(_Parameterized):
         cdef uintptr_t pk, pc
         _check(hip.fa_mapper_lookup_size(self._hm, &n))
         dev = torch.device(device)
-        keys = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
-        counts = torch.empty(max(n, 1), dtype=torch.int32, device="cuda")
-        torch.cuda.synchronize()
+        own = self._torch_device()                                           # the GPU this mapper is bound to, not torch's current one
+        keys = torch.empty(max(n, 1), dtype=torch.int32, device=own)
+        counts = torch.empty(max(n, 1), dtype=torch.int32, device=own)
+        torch.cuda.synchronize(own)
         pk, pc = keys.data_ptr(), counts.data_ptr()
         _check(hip.fa_mapper_lookup_export_device(self._hm, keys.shape[0], <uint32_t*> pk, <int32_t*> pc))
         return keys[:n].to(dev), counts[:n].to(dev)
@@ -867,8 +881,9 @@ cdef class Mapper(_Parameterized):
         """Install the frequency threshold taken over all shards of a reference-sharded index and the hashes (torch
         ``int32`` bit patterns) whose summed list length reaches it."""
         import torch
-        drop = drop_keys.to(device="cuda", dtype=torch.int32).contiguous()
-        torch.cuda.synchronize()
+        own = self._torch_device()
+        drop = drop_keys.to(device=own, dtype=torch.int32).contiguous()
+        torch.cuda.synchronize(own)
         cdef uintptr_t p = drop.data_ptr() if drop.numel() else 0
         _check(hip.fa_mapper_set_global_frequency(self._hm, int(threshold), int(drop.numel()), <const uint32_t*> p))
 

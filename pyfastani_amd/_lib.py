@@ -81,6 +81,7 @@ SIGNATURES = {
     "fa_mapper_lookup_export_device": (_i32, [_vp, _i64, _vp, _vp]),
     "fa_mapper_set_global_frequency": (_i32, [_vp, _i32, _i64, _vp]),
     "fa_mapper_lookup_size": (_i32, [_vp, _P(_i64)]),
+    "fa_mapper_device": (_i32, [_vp, _P(_i32)]),
     "fa_mapper_lookup_keys": (_i32, [_vp, _vp]),
     "fa_mapper_lookup_count": (_i32, [_vp, _u32, _P(_i64)]),
     "fa_mapper_lookup_get": (_i32, [_vp, _u32, _vp, _vp, _i64]),

@@ -120,6 +120,7 @@ struct StageTrace {
 
 // `clear` (a query pass): ranges zeroed by extra workgroups of the first launch, beside the hashing
 static uint64_t env_u64(const char *name, uint64_t dflt);
+static uint64_t exp_u64(const char *name, uint64_t dflt);     // the same in builds with -DFA_EXPERIMENTS, else `dflt`
 static void launch_sketch_tiles(const fa_params &P, const StoreView &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
                                 int32_t *stage_wpos, int32_t *tile_count, hipStream_t st, const ClearArgs *clear = nullptr) {
   if (ntiles <= 0) {
@@ -148,7 +149,7 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   size_t lds = sketch_lds_bytes(P.kmer_size, P.window_size);
   size_t image = lds - ((size_t)a.npos_cap * 16 + ((size_t)a.npos_cap / 64 + 1) * 8 + (TILE / 64) * 8 + (TILE / 64 + 1) * 4 + 16 + 4 * 256 * 8);
   a.code_words = (int32_t)(image / 4);
-  static const size_t lds_pad = (size_t)env_u64("FA_K1_LDS_PAD", 0);     // experiment: unused LDS, i.e. fewer workgroups per CU
+  static const size_t lds_pad = (size_t)exp_u64("FA_K1_LDS_PAD", 0);     // experiment: unused LDS, i.e. fewer workgroups per CU
   auto launch = [&](auto kernel) {
     if (lds + lds_pad > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds + lds_pad)));
     hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), lds + lds_pad, st, a);
@@ -325,6 +326,8 @@ struct PassStatus {
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
 
+static_assert(offsetof(PassStatus, stamp) % 16 == 0, "k_clear zeroes whole 16-byte words: the cleared prefix of the status block must end on one");
+
 // The hand-over of a pass (publish_pass, fa_map.hip.h): copies the status block -- and, for a one-query call whose rows go to the host, the rows --
 // into pinned host memory and then releases the pass number.  The host polls that word instead of waiting for a
 // device-to-host copy and a stream synchronisation, which together return tens of microseconds after the GPU is done
@@ -337,13 +340,13 @@ static PublishArgs publish_args(PassStatus *dev, PassStatus *host_mapped, uint32
   p.rows_dev = rows_dev; p.rows_host = rows_host; p.cap = cap;
   return p;
 }
-// host side of k_publish_status: polls for FA_SPIN_US microseconds (default 20 000), then sleeps on the stream
-// regions of the event arena used by a part of F fragments (L2Args::n_regions): a power of two, one per eight fragments
+// regions of the event arena used by a part of F fragments (L2Args::n_regions): a power of two, one per sixteen fragments
 static uint32_t ev_regions_for(int64_t F) {
   uint32_t n = 1;
   while (n < (uint32_t)EV_REGIONS && (int64_t)n * 16 <= F) n <<= 1;
   return n;
 }
+// host side of k_publish_status: polls for FA_SPIN_US microseconds (default 20 000), then sleeps on the stream
 static void wait_published(const PassStatus *h, uint32_t seq, hipStream_t st) {
   static const uint64_t spin_us = env_u64("FA_SPIN_US", 20000);
   const auto t0 = std::chrono::steady_clock::now();
@@ -419,8 +422,10 @@ struct fa_mapper {
   DevBuf<uint32_t> rec_geo;       // packed window geometry + flags for k_l2_events (empty when cmw >= 8191)
   DevBuf<uint16_t> rec_prev16;
   DevBuf<int2> rec_sw;            // (rec_seq, rec_wpos) interleaved for k_l1
+#ifdef FA_EXPERIMENTS
   DevBuf<uint32_t> ev_bits;       // merged admit / drop order of the slide (k_event_bits), 2 bits per record
   DevBuf<uint2> rec_hf;           // hash + flags + distance to the previous record of the hash (k_pack_hf), for k_l2_fused
+#endif
   bool packed_geo = false;
   int64_t N = 0, U = 0;
   int32_t C = 0, G = 0, table_bits = 4, freq_threshold = INT_MAX, total_bins = 0;
@@ -457,7 +462,9 @@ struct fa_mapper {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
     v.rec_geo = packed_geo ? rec_geo.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_sw = rec_sw.p;
+#ifdef FA_EXPERIMENTS
     v.ev_bits = ev_bits.p; v.rec_hf = rec_hf.p;
+#endif
     v.uniq_hash = uniq_hash.p; v.uniq_off = uniq_off.p; v.pos_ridx = pos_ridx.p; v.table = table.p;
     v.contig_rec = contig_rec.p; v.contig_genome = contig_genome.p; v.contig_bin = contig_bin.p; v.genome_bin = genome_bin.p;
     v.N = N; v.U = U; v.C = C; v.G = G; v.table_bits = table_bits; v.freq_threshold = freq_threshold; v.total_bins = total_bins;
@@ -476,11 +483,18 @@ __global__ void k_contig_bins(const int32_t *contig_rec, const int32_t *rec_wpos
   nbins[c] = n;
 }
 
+// Knobs that only ever served A/B measurements (LDS padding, forced workgroup shapes, the fused L2 kernel) exist in builds
+// with -DFA_EXPERIMENTS only (scripts/experiments/README.md); the product library ignores them.
+#ifdef FA_EXPERIMENTS
+static uint64_t exp_u64(const char *name, uint64_t dflt) { return env_u64(name, dflt); }
 // FA_L2_FUSED=1: build the extra index arrays of the fused L2 kernel and use it (see run_query_pass)
 static bool fused_l2_enabled() {
   static const bool on = getenv("FA_L2_FUSED") && atoi(getenv("FA_L2_FUSED")) != 0;
   return on;
 }
+#else
+static uint64_t exp_u64(const char *, uint64_t dflt) { return dflt; }
+#endif
 
 // Sketch_t::index() + computeFreqHist() on the device
 static void build_index(fa_mapper &m) {
@@ -596,6 +610,7 @@ static void build_index(fa_mapper &m) {
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
     m.rec_sw.ensure((size_t)N + 4);
     hipLaunchKernelGGL(k_interleave_seq_wpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, N, m.rec_sw.p);
+#ifdef FA_EXPERIMENTS
     if (fused_l2_enabled()) {
       const size_t words = ((size_t)2 * (size_t)N + 31) / 32 + 4;
       m.ev_bits.ensure(words);
@@ -604,6 +619,7 @@ static void build_index(fa_mapper &m) {
       m.rec_hf.ensure((size_t)N + 4);
       hipLaunchKernelGGL(k_pack_hf, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_hash.p, m.rec_flags.p, m.rec_prev.p, N, m.rec_hf.p);
     }
+#endif
     m.packed_geo = m.cmw + 1 < (1 << GEO_BITS);
     if (m.packed_geo) {
       m.rec_geo.ensure((size_t)N + 4); m.rec_prev16.ensure((size_t)N + 4);
@@ -648,8 +664,9 @@ static uint32_t lds_seed_cap_max(int smax) {
 }
 
 
-// zero several device ranges with one launch (every DevBuf is at least 16-byte aligned; sizes are rounded up to 16 bytes,
-// which stays inside the allocation because ensure() callers below add slack)
+// zero several device ranges with one launch (every DevBuf is at least 16-byte aligned; sizes are rounded up to 16 bytes:
+// the buffers listed below are allocated with slack, and the cleared prefix of the status block is a multiple of 16 bytes
+// -- asserted next to PassStatus -- so the rounding never reaches the stamps behind it)
 struct ClearList {
   ClearArgs a;
   ClearList() { a.count = 0; a.stamp = nullptr; }
@@ -857,7 +874,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     // LDS also holds smax list offsets; the in-place merge keeps at most 32 seeds per thread in registers
     // threads per fragment in k_l1: 256 while 16 seeds per thread suffice (4-wave workgroups, eight per CU: a 5 Mb query
     // is one round of workgroups), else 512; FA_L1_THREADS = 256 / 512 / 1024 forces one
-    static const int l1_forced = (int)env_u64("FA_L1_THREADS", 0);
+    static const int l1_forced = (int)exp_u64("FA_L1_THREADS", 0);
     const int l1_threads = l1_forced ? l1_forced : (std::min(sp.seed_slots, lds_seed_cap_max(sp.smax)) <= 16 * 256 ? 256 : 512);
     const int l1_nt = l1_threads >= 1024 ? 1024 : (l1_threads >= 512 ? 512 : 256);
     const uint32_t seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * l1_nt));
@@ -966,12 +983,14 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.l_redo = ln.l_redo.p;
       a.redo_count = d_counters + 3;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
+#ifdef FA_EXPERIMENTS
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
+#endif
       // events of one locus staged in LDS per wave of k_l2_events (longer streams are stored directly): a stream holds
       // the records of about 2.6 windows twice, minus the first window -- 5.3 windows' worth at the longest in the bench;
       // the LDS this costs decides how many workgroups a CU holds (2048: 6, 1408: 7; 0.41 vs 0.38 ms for the L2 stage)
-      static const int ev_stage_env = (int)env_u64("FA_EV_STAGE", 0);
+      static const int ev_stage_env = (int)exp_u64("FA_EV_STAGE", 0);
       const int per_window = std::max(1, 2 * m.P.fragment_length / (m.P.window_size + 1));
       a.ev_stage = ev_stage_env ? (ev_stage_env & ~7) : std::min(2048, std::max(512, (per_window * 11 / 2 + 127) & ~127));
       const size_t ev_lds = ev_sketch_bytes(a.cnt_slots) + (size_t)a.ev_stage * (wide ? 4 : 2) * (EV_THREADS / 64) + 16;
@@ -985,7 +1004,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         return ln;
       };
       const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
-      static const size_t scan_pad = (size_t)env_u64("FA_SCAN_LDS_PAD", 0);   // experiment: fewer scan workgroups per CU
+      static const size_t scan_pad = (size_t)exp_u64("FA_SCAN_LDS_PAD", 0);   // experiment: fewer scan workgroups per CU
       const size_t lds8 = scan_lds(lanes8, 1) + scan_pad, lds16 = scan_lds(lanes16, 2);
       auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
         if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
@@ -1011,6 +1030,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
           hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
         }
       };
+#ifdef FA_EXPERIMENTS
       // FA_L2_FUSED=1 selects the fused form (events generated into an LDS ring and consumed in place: no event arena in
       // HBM, L2-stage traffic 0.45 GB instead of 1.08 GB per bench step).  It is bit-exact but measured SLOWER than the
       // two-kernel form on the bench step (0.81 ms against 0.42 ms): one or two producer waves per 64
@@ -1048,8 +1068,12 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         if (fl16 > 60 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl16));
         hipLaunchKernelGGL(k16, dim3(grid), dim3(fu_threads), fl16, st, a, F);
       };
+#else
+      const bool fused = false;
+#endif
       const bool pk = m.packed_geo && !getenv("FA_NO_PACKED_GEO");
       if (fused) {
+#ifdef FA_EXPERIMENTS
         auto pick = [&](auto ev_tag) {
           using EV = decltype(ev_tag);
           if (fu_nprod == 2) {
@@ -1062,6 +1086,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
         };
         if (wide) pick(uint32_t()); else pick(uint16_t());
         w.last_ms[14] = (float)smax; w.last_ms[15] = (float)fu_c;
+#endif
       } else if (wide) {
         if (pk) launch(k_l2_events<uint32_t, true>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
         else launch(k_l2_events<uint32_t, false>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
@@ -1081,6 +1106,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.frag_query = g.d_frag_query + f0; a.frag_qseq = g.d_frag_qseq + f0; a.bins = w.bins.p;
       a.bin_len = m.P.fragment_length - 20;
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
+      a.wide_launched = sp.redo ? 1 : 0;
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
     }
     // ---- the one hand-over of the part: results, statistics and the speculation verdict (publish_pass) ----
@@ -1695,6 +1721,7 @@ void fa_mapper_free(fa_mapper *m) {
 }
 int fa_mapper_freq_threshold(fa_mapper *m, int *thr) { *thr = m->freq_threshold; return FA_OK; }
 int fa_mapper_lookup_size(fa_mapper *m, int64_t *n) { *n = m->U; return FA_OK; }
+int fa_mapper_device(fa_mapper *m, int *device) { *device = m->device; return FA_OK; }
 int fa_mapper_lookup_export_device(fa_mapper *m, int64_t cap, uint32_t *d_keys, int32_t *d_counts) {
   return guarded([&] {
     std::lock_guard<std::mutex> lock(m->mtx);

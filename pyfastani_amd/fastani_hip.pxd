@@ -73,6 +73,7 @@ cdef extern from "fastani_hip.h" nogil:
     void fa_mapper_free(fa_mapper* m)                                                         # :839-840
     int fa_mapper_freq_threshold(fa_mapper* m, int* threshold)                                # getFreqThreshold, :600
     int fa_mapper_lookup_size(fa_mapper* m, int64_t* n)                                       # :1456
+    int fa_mapper_device(fa_mapper* m, int* device)
     int fa_mapper_lookup_export_device(fa_mapper* m, int64_t cap, uint32_t* d_keys, int32_t* d_counts)
     int fa_mapper_set_global_frequency(fa_mapper* m, int threshold, int64_t n_drop, const uint32_t* d_drop_keys)
     int fa_mapper_lookup_keys(fa_mapper* m, uint32_t* keys)                                   # :1458-1466

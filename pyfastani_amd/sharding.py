@@ -108,6 +108,7 @@ def all_vs_all(mapper, genomes, rank, world_size, device=None, group=None, chunk
     """
     import torch
 
+    genomes = [list(contigs) for contigs in genomes]      # (a generator of contigs would be used up by the balance pass)
     if balance == "fragments":
         frag = mapper.fragment_length
         owned = shard_by_fragments([sum(len(c) // frag for c in contigs) for contigs in genomes], world_size)[rank]

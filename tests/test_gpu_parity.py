@@ -271,6 +271,32 @@ def test_small_sketch_against_crowded_window():
     assert hit_tuples(hits) == ohits
 
 
+def test_void_redo_attempt_leaves_no_stale_bins():
+    # Two loci per fragment in ONE reference genome (the island planted in both of its contigs) with equal shared counts:
+    # the canonical tie-break keeps the locus of contig 0.  Sketches of ~40-75 minimizers against the ~1500 of a w=3
+    # super-window put the fullest rank right at the edge of the one-byte slide state, so for a dozen fragments the locus
+    # in contig 0 overflows while its twin in contig 1 does not.  A fresh mapper has not launched the wide-state scan yet:
+    # its first attempt is void and repeated -- and must leave nothing in the CGI bin table, or the twin (a lesser locus
+    # of the group, in a bin the true best never touches) stays behind and count_seq comes out too high.
+    g = syn.rng(77)
+    r, x = syn.random_codes(g, 400_000), syn.random_codes(g, 400_000)
+    nf = 120
+    q = bytearray(b"N" * 3000 * nf)
+    for f in range(nf):
+        n, a, b = 60 + (f * 7) % 80, 5000 + f * 3000, 7000 + f * 3000
+        x[b: b + n] = r[a: a + n]
+        q[f * 3000 + 1400: f * 3000 + 1400 + n] = bytes(syn.to_ascii(r[a: a + n]))
+    params = {"minimum_fraction": 0.0, "percentage_identity": 68.0}
+    mapper, hits, ohits, det = run_both(params, [[syn.to_ascii(r), syn.to_ascii(x)]], [bytes(q)], threads=8)
+    ms = (C.c_float * 16)()
+    lib.fa_mapper_last_timings(mapper._h, ms, 16)
+    assert ms[8] > 0 and ms[9] >= 1, "no locus left the byte state on the first attempt: the case does not test the repeat"
+    assert ms[8] < ms[6], "every locus overflowed: no twin could be left behind"
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
+    assert hit_tuples(mapper.query_draft([bytes(q)])) == ohits          # and again, now that the wide pass is always launched
+
+
 def test_protein_golden_on_device(golden_dir):
     # reference: src/pyfastani/tests/test_ani.py:96-115
     b1 = read_fasta(os.path.join(golden_dir, "BGC0001425.faa"))
