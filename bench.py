@@ -39,7 +39,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_PROFILE = "r02_traffic.json"
+TRAFFIC_PROFILE = "r03_traffic.json"                   # the timed step (1 query per launch)
+TRAFFIC_PROFILE_BATCH16 = "r03_batch16_traffic.json"     # `saturated.batch16`: 16 queries per launch
+TRAFFIC_PROFILE_CONFIG3 = "r03_config3_traffic.json"     # `saturated.config3`: 1000 x 1000, two steps profiled
 
 
 def parse_args():
@@ -57,6 +59,9 @@ def parse_args():
     ap.add_argument("--strong", action="store_true", help="strong scaling: BASELINE config 3 (all-vs-all) sharded by fragment count")
     ap.add_argument("--families", type=int, default=20, help="--strong: families of config 3")
     ap.add_argument("--members", type=int, default=50, help="--strong: members per family of config 3")
+    ap.add_argument("--no-boundary", action="store_true", help="N=1: skip the `boundary_call` leg (profiling: the last launches stay those of the timed step)")
+    ap.add_argument("--no-saturated", action="store_true", help="N=1: skip the `saturated` legs (16 queries per launch; config 3 at N=1)")
+    ap.add_argument("--saturated-steps", type=int, default=3, help="steps of the config-3 leg of `saturated` (its batch-16 leg runs 10)")
     return ap.parse_args()
 
 
@@ -283,9 +288,12 @@ def weak_scaling(ctx):
     }
     if world == 1:
         timed_rows = [table[i, 1: counts[i] + 1].cpu().numpy().reshape(-1).view(ROW_DTYPE) for i in range(args.steps)]
-        result["boundary_call"] = boundary_call(args, mapper, queries[0], timed_rows)
+        if not args.no_boundary:
+            result["boundary_call"] = boundary_call(args, mapper, queries[0], timed_rows)
         if args.clients > 1:
             result["concurrent_clients"] = concurrent_clients(args, batch, cap_rows, n_pairs_step)
+        if not args.no_saturated and args.batch == 1:
+            result["saturated"] = saturated_legs(ctx, mapper, anc)
         if not args.no_cpu_baseline:              # the CPU oracle legs are an N=1 measurement (rank 0 only)
             result.update(oracle_legs(args, anc, names, refs, mapper, queries[0], timed_rows))
     return result
@@ -369,12 +377,13 @@ def concurrent_clients(args, batch, cap_rows, n_pairs_step):
             "ms_per_step": dt / (n * k) * 1e3}
 
 
-def profiled_traffic(which):
-    """HBM bytes per step of the dominant stage from the committed rocprofv3 PMC passes (profiles/r02_traffic.json,
+def profiled_traffic(which, profile=None):
+    """HBM bytes per step of the dominant stage from the committed rocprofv3 PMC passes (profiles/r03_*traffic.json,
     collected on this exact workload by scripts/collect_profiles.sh): FETCH_SIZE and WRITE_SIZE come from separate
     passes, are in KB, and FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read
     from inside the benchmark, so this is the profiled value, not a live one; (None, None) if the profile is missing."""
-    path = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
+    profile = profile or TRAFFIC_PROFILE
+    path = os.path.join(ROOT, "profiles", profile)
     try:
         doc = json.load(open(path))
         table = doc["kernels"]
@@ -382,9 +391,67 @@ def profiled_traffic(which):
         if not pick:
             return None, None
         total = sum((2.0 * table[k]["fetch_size_kb"] + table[k]["write_size_kb"]) * 1024.0 * table[k].get("launches_per_step", 1) for k in pick)
-        return total, f"profiles/{TRAFFIC_PROFILE}@{doc.get('head', 'unknown')}"
+        return total / float(doc.get("steps_summed", 1)), f"profiles/{profile}@{doc.get('head', 'unknown')}"
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def stage_roofline(l2_records, l2_ms, traffic, traffic_source):
+    """`roofline`-shaped object of the L2 stage (k_l2_events + k_l2_scan): 12 algorithmic bytes per reference record
+    inside a locus range over the stage time taken from the device stamps."""
+    l2_bytes = float(l2_records) * 12.0
+    gbs = l2_bytes / max(l2_ms * 1e-3, 1e-12) / 1e9
+    return {"bound": "hbm", "kernel": "k_l2_events+k_l2_scan", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_over_algorithmic": (traffic / l2_bytes) if traffic and l2_bytes else None,
+            "kernel_ms": l2_ms, "kernel_ms_source": "device stamps (100 MHz counter) at the stage boundaries, summed over the passes of a step",
+            "algorithmic_bytes": l2_bytes}
+
+
+def saturated_legs(ctx, mapper, anc, batch16_steps=10):
+    """The throughput regime of the metric ("genome-pair ANI/sec ... at 1/2/4/8 MI355X" is quoted on all-vs-all work,
+    benches/mapping/bench.py:34-54 of the reference maps many queries against one mapper): many queries per launch, so
+    that every kernel runs many resident rounds instead of one.  Two legs, both at N = 1, both with per-stage times and an
+    L2 roofline on algorithmic bytes; never `value`.
+      batch16: config 2's index (1 x 100 references), 16 query genomes of 5 Mb per launch;
+      config3: BASELINE configs[2] at N = 1 -- 1000 x 1000 synthetic 5 Mb genomes all-vs-all, the strong-scaling step."""
+    args, torch = ctx["args"], ctx["torch"]
+    from pyfastani_amd import workloads
+    from pyfastani_amd._lib import lib
+    out = {}
+    # ---- 16 queries per launch on the bench index ----
+    nq = 16
+    queries = [workloads.config2_query(anc, 100 + i, 1)[0] for i in range(nq)]     # 16 different genomes (seeds 5100..5115)
+    batch = mapper.upload_genomes(queries)
+    cap = nq * args.refs
+    table = torch.zeros((cap, 5), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(2):
+        batch.query_rows_device(0, nq, table.data_ptr(), cap)
+    phase, rec, loci = np.zeros(5), 0.0, 0.0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(batch16_steps):
+        n_rows = batch.query_rows_device(0, nq, table.data_ptr(), cap)
+        ms = (C.c_float * 16)()
+        lib.fa_mapper_last_timings(mapper._h, ms, 16)
+        phase += np.array(list(ms)[:5]); rec += float(ms[5]); loci += float(ms[6])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    phase /= batch16_steps
+    traffic, src = (profiled_traffic("l2", TRAFFIC_PROFILE_BATCH16) if args.refs == 100 and args.length == 5_000_000 else (None, None))
+    out["batch16"] = {"workload": f"{nq} queries x {args.refs} synthetic {args.length / 1e6:g} Mb refs in ONE launch sequence, k=16 frag=3000",
+                      "value": nq * args.refs * batch16_steps / dt, "unit": "pairs/s", "steps": batch16_steps, "ms_per_step": dt / batch16_steps * 1e3,
+                      "ms_per_query": dt / batch16_steps / nq * 1e3, "rows_per_step": int(n_rows), "l2_loci": int(loci / batch16_steps),
+                      "phases_ms": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase])),
+                      "roofline": stage_roofline(rec / batch16_steps, float(phase[2]), traffic, src)}
+    del batch, table
+    # ---- config 3 at N = 1 ----
+    if args.saturated_steps > 0:
+        r = strong_core(ctx, args.saturated_steps, 1)
+        if r is not None:
+            out["config3"] = r
+    return out
 
 
 def oracle_legs(args, anc, names, refs, mapper, query, timed_rows):
@@ -470,12 +537,14 @@ def oracle_legs(args, anc, names, refs, mapper, query, timed_rows):
     }
 
 
-def strong_scaling(ctx):
+def strong_core(ctx, steps, warmup):
     """BASELINE config 3 (families x members genomes of --length, all-vs-all) with the QUERIES dealt to the ranks balanced by
-    fragment count, the index replicated, and ONE RCCL all-gather of the hit table per step."""
+    fragment count, the index replicated, and ONE all-gather of the device-resident hit table per step
+    (`sharding.ResidentHitTable`: rows written into a preallocated HBM table, query ids remapped by a device gather, no
+    host copy between the mapping and the collective).  Returns the measurements of rank 0 (None elsewhere)."""
     args, rank, world, share_gpu, torch, dist = (ctx[k] for k in ("args", "rank", "world", "share_gpu", "torch", "dist"))
     from pyfastani_amd import workloads, sharding
-    from pyfastani_amd._batch import ROW_DTYPE
+    from pyfastani_amd._lib import lib
     t0 = time.time()
     genomes, fam = workloads.config3(args.families, args.members, args.length)
     t_gen = time.time() - t0
@@ -483,42 +552,77 @@ def strong_scaling(ctx):
     mapper, index_mode, t_pack, t_index = build_mapper(ctx, list(range(n)), genomes)
     frag = mapper.fragment_length
     weights = [sum(len(c) // frag for c in contigs) for contigs in genomes]
-    owned = sharding.shard_by_fragments(weights, world)[rank]
+    deal = sharding.shard_by_fragments(weights, world)
+    owned = deal[rank]
     batch = mapper.upload_genomes([genomes[i] for i in owned])
-    max_rows = max(len(o) for o in sharding.shard_by_fragments(weights, world)) * n
-    dev = "cpu" if share_gpu else "cuda"
-    chunk = 24
+    max_rows = max(len(o) for o in deal) * n
+    exchange = sharding.ResidentHitTable(owned, max_rows, world, comm_device="cpu" if share_gpu else "cuda")
+    phase, rec, repeats = np.zeros(5), 0.0, 0.0
 
-    def step():
-        parts = [batch.query_rows(first, min(chunk, len(owned) - first)) for first in range(0, len(owned), chunk)]
-        rows = np.concatenate(parts) if parts else np.zeros(0, ROW_DTYPE)
-        rows = sharding.remap_query_ids(rows, owned)
-        if world == 1:
-            return rows
-        return sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows, dev), max_rows=max_rows))
+    def step(timed):
+        nonlocal phase, rec, repeats
+        tables = exchange.step(batch)
+        if timed:
+            ms = (C.c_float * 16)()
+            lib.fa_mapper_last_timings(mapper._h, ms, 16)     # sums over the passes of this call (device stamps)
+            phase += np.array(list(ms)[:5]); rec += float(ms[5]); repeats += float(ms[9])
+        return tables
 
-    for _ in range(max(args.warmup, 1)):
-        rows = step()
+    for _ in range(max(warmup, 1)):
+        tables = step(False)
     fence(ctx)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rows = step()
+    for _ in range(steps):
+        tables = step(True)
     fence(ctx)
     elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
     if rank != 0:
         return None
+    rows = sharding.ResidentHitTable.rows_of(tables)          # (outside the timed region: the table stays in HBM inside it)
+    phase /= max(steps, 1)
     self_rows = rows[rows["query_id"] == rows["ref_genome_id"]]
+    full = args.families == 20 and args.members == 50 and args.length == 5_000_000 and world == 1
+    traffic, src = profiled_traffic("l2", TRAFFIC_PROFILE_CONFIG3) if full else (None, None)
     return {
-        "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)", "value": n * n * args.steps / elapsed, "unit": "pairs/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "workload": f"{n} x {n} all-vs-all ({args.families} families x {args.members}), {args.length / 1e6:g} Mb genomes, k=16 frag=3000 w={mapper.window_size}",
+        "value": n * n * steps / elapsed, "unit": "pairs/s", "steps": steps, "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3,
+        "us_per_pair": elapsed / steps / (n * n) * 1e6,
+        "pairs_per_step": n * n, "rows_per_step": int(len(rows)), "parallelism": f"queries sharded by fragment count x{world}, index replicated",
+        "exchange": "rows written into a preallocated HBM table by the pass kernels, query ids remapped on the device, one all_gather_into_tensor per step" if world > 1
+                    else "rows written into a preallocated HBM table by the pass kernels (N = 1: no collective)",
+        "fragments_per_rank": [int(sum(weights[i] for i in o)) for o in deal],
+        "phases_ms_rank0": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase])),
+        "repeated_attempts_per_step": repeats / max(steps, 1),
+        "roofline": stage_roofline(rec / max(steps, 1), float(phase[2]), traffic, src),
+        "index_minimizers": len(mapper.minimizers), "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack,
+        "generate_s": t_gen,  # (exactly 100.0 except for the end-of-contig effect the oracle shows too: the fragment that ends at the contig end)
+        "self_rows_ok": bool(len(self_rows) == n and np.all(self_rows["identity"] >= 99.999)),
+        "self_rows_exactly_100": int(np.sum(self_rows["identity"] == 100.0)),
+        "table_sha256": _sha256_rows(rows), "head": git_head(),
+    }
+
+
+def _sha256_rows(rows):
+    """Digest of the hit table in (query, reference) order: equal tables at N = 1 and N > 1 have equal digests."""
+    import hashlib
+    order = np.lexsort((rows["ref_genome_id"], rows["query_id"]))
+    return hashlib.sha256(np.ascontiguousarray(rows[order]).tobytes()).hexdigest()[:16]
+
+
+def strong_scaling(ctx):
+    args, world = ctx["args"], ctx["world"]
+    r = strong_core(ctx, args.steps, args.warmup)
+    if r is None:
+        return None
+    config = {k: r[k] for k in ("workload", "pairs_per_step", "rows_per_step", "parallelism", "exchange", "fragments_per_rank", "index_minimizers",
+                                "index_build", "index_build_s", "host_pack_s", "generate_s", "self_rows_ok", "self_rows_exactly_100",
+                                "table_sha256", "head")}
+    return {
+        "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)", "value": r["value"], "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"{n} x {n} all-vs-all ({args.families} families x {args.members}), {args.length / 1e6:g} Mb genomes, k=16 frag=3000 w={mapper.window_size}",
-                   "pairs_per_step": n * n, "rows_per_step": int(len(rows)), "parallelism": f"queries sharded by fragment count x{world}, index replicated",
-                   "fragments_per_rank": [int(sum(weights[i] for i in o)) for o in sharding.shard_by_fragments(weights, world)],
-                   "index_minimizers": len(mapper.minimizers), "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack,
-                   "generate_s": t_gen, # (exactly 100.0 except for the end-of-contig effect the oracle shows too: the fragment that ends at the contig end)
-                   "self_rows_ok": bool(len(self_rows) == n and np.all(self_rows["identity"] >= 99.999)),
-                   "self_rows_exactly_100": int(np.sum(self_rows["identity"] == 100.0)), "head": git_head()},
+        "config": config, "roofline": r["roofline"], "phases_ms": r["phases_ms_rank0"],
+        "repeated_attempts_per_step": r["repeated_attempts_per_step"],
     }
 
 

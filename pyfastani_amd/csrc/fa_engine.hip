@@ -23,6 +23,7 @@
 #include "fa_fasta.h"
 #include "fa_map.hip.h"
 #include "fa_sketch.hip.h"
+#include "fa_sketch_fast.hip.h"
 #include "fa_stats.h"
 
 using namespace fa;
@@ -156,7 +157,19 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
     extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;          // (only the first launch zeroes)
   };
   // plain-ACGT tiles from the 2-bit image; protein tiles and tiles with other bytes through the byte image
-  if (!a.protein) { if (P.kmer_size == 16) launch(k_sketch_tiles<16, false>); else launch(k_sketch_tiles<0, false>); }
+  if (!a.protein && !k1_general && P.window_size >= SKF_MIN_W && P.window_size <= SKF_MAX_W) {
+    // the hot form (fa_sketch_fast.hip.h): 13 KB of LDS, eight workgroups per CU; k = 14 / 16 / 21 hash from the premix tables
+    const size_t flds = skf_layout(P.kmer_size, P.window_size).total;
+    auto launch_fast = [&](auto kernel) {
+      hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), flds + lds_pad, st, a);
+      extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;
+    };
+    if (P.kmer_size == 16 && P.window_size == 24) launch_fast(k_sketch_fast<16, 24>);
+    else if (P.kmer_size == 16) launch_fast(k_sketch_fast<16, 0>);
+    else if (P.kmer_size == 14) launch_fast(k_sketch_fast<14, 0>);
+    else if (P.kmer_size == 21) launch_fast(k_sketch_fast<21, 0>);
+    else launch_fast(k_sketch_fast<0, 0>);
+  } else if (!a.protein) { if (P.kmer_size == 16) launch(k_sketch_tiles<16, false>); else launch(k_sketch_tiles<0, false>); }
   if (a.protein || store.n_exc > 0) launch(k_sketch_tiles<0, true>);
   FA_HIP(hipGetLastError());
 }

@@ -100,6 +100,61 @@ def remap_query_ids(rows, owned):
     return rows
 
 
+class ResidentHitTable:
+    """The strong-scaling step with nothing on the host between the mapping and the collective.
+
+    Every rank owns a preallocated ``int32 [max_rows + 1, 5]`` tensor in HBM: row 0 carries the row count, the library
+    writes the hit rows of ALL owned genomes behind it (`GenomeBatch.query_rows_device`: pass-sized launches, the rows
+    never leave the device), the batch-local query ids are translated to global ones by a device gather, and ONE
+    ``all_gather_into_tensor`` (RCCL over xGMI for the ``nccl`` backend) exchanges the tables -- the north star's
+    "RCCL all-gather of per-pair hit tables" (what a rank computes: src/pyfastani/_fastani.pyx:1099-1118 of the reference).
+
+    ``comm_device`` is the device the process group communicates on; when it is the CPU (the gloo runs that share one
+    GPU between the ranks) the local table is copied to the host for the collective and nothing else changes.
+    """
+
+    def __init__(self, owned, max_rows, world_size, comm_device="cuda", group=None, table_device="cuda"):
+        import torch
+        self.torch, self.world, self.group, self.max_rows = torch, int(world_size), group, int(max_rows)
+        self.n_owned = len(owned)
+        self.comm_device = torch.device(comm_device)
+        self.table_device = torch.device(table_device)      # "cpu" only in the CPU tests (a stand-in batch writes host memory)
+        self.local = torch.zeros((self.max_rows + 1, 5), dtype=torch.int32, device=self.table_device)
+        self.owned = torch.as_tensor(np.asarray(owned, dtype=np.int64), device=self.table_device)
+        self.out = (torch.empty((self.world * (self.max_rows + 1), 5), dtype=torch.int32, device=self.comm_device)
+                    if self.world > 1 else None)
+        self._sync()
+
+    def _sync(self):
+        if self.table_device.type == "cuda":
+            self.torch.cuda.synchronize()
+
+    def step(self, batch):
+        """Map every owned genome of ``batch`` and exchange the tables.  Returns the tables of all ranks as an
+        ``int32 [world, max_rows + 1, 5]`` tensor (on ``comm_device`` for world > 1, in HBM otherwise)."""
+        torch = self.torch
+        self._sync()                              # the library writes on its own stream: torch's reads of `local` are done
+        n = batch.query_rows_device(0, self.n_owned, self.local[1:].data_ptr(), self.max_rows) if self.n_owned else 0
+        self.local[0, 0] = n
+        if n:
+            rows = self.local[1: n + 1]
+            rows[:, 0] = self.owned[rows[:, 0].long()].to(torch.int32)      # batch-local -> global query ids
+        if self.world == 1:
+            return self.local.view(1, self.max_rows + 1, 5)
+        import torch.distributed as dist
+        src = self.local if self.comm_device == self.table_device else self.local.to(self.comm_device)
+        dist.all_gather_into_tensor(self.out, src, group=self.group)
+        return self.out.view(self.world, self.max_rows + 1, 5)
+
+    @staticmethod
+    def rows_of(tables):
+        """Structured rows of an exchanged table (host side, after the timed region): ranks in order."""
+        t = tables.detach().cpu().numpy()
+        parts = [t[r, 1: int(t[r, 0, 0]) + 1] for r in range(t.shape[0])]
+        flat = np.ascontiguousarray(np.concatenate(parts, axis=0), dtype=np.int32) if parts else np.zeros((0, 5), np.int32)
+        return flat.reshape(-1).view(ROW_DTYPE)
+
+
 def all_vs_all(mapper, genomes, rank, world_size, device=None, group=None, chunk=64, balance="fragments"):
     """Map this rank's share of ``genomes`` against ``mapper`` and return the hit table of ALL ranks.
 

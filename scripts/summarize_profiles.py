@@ -21,8 +21,12 @@ def short(name):
     return name[:cut] if cut > 0 else name
 
 
+SUM_STEPS = int(os.environ.get("FA_PROFILE_SUM_STEPS", "0"))     # > 0: sum ALL launches of a kernel (a run of that many identical steps)
+
+
 def last_launch(pattern):
-    """{kernel: {counter: value}} of the last dispatch of every kernel in a counter_collection.csv"""
+    """{kernel: {counter: value}} of the last dispatch of every kernel in a counter_collection.csv -- or, with
+    FA_PROFILE_SUM_STEPS, of all its dispatches together (config 3: a step is ~36 passes, every one launches the kernels)"""
     out = {}
     for path in glob.glob(os.path.join(src, pattern, "**", "*counter_collection.csv"), recursive=True):
         rows = list(csv.DictReader(open(path)))
@@ -30,7 +34,7 @@ def last_launch(pattern):
         for r in rows:
             last[r["Kernel_Name"]] = max(last.get(r["Kernel_Name"], 0), int(r["Dispatch_Id"]))
         for r in rows:
-            if int(r["Dispatch_Id"]) == last[r["Kernel_Name"]]:
+            if SUM_STEPS or int(r["Dispatch_Id"]) == last[r["Kernel_Name"]]:
                 out.setdefault(short(r["Kernel_Name"]), {})[r["Counter_Name"]] = out.get(short(r["Kernel_Name"]), {}).get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     return out
 
@@ -48,9 +52,12 @@ fetch, write = last_launch("fetch"), last_launch("write")
 kernels = {k: {"fetch_size_kb": fetch.get(k, {}).get("FETCH_SIZE", 0.0), "write_size_kb": write.get(k, {}).get("WRITE_SIZE", 0.0)}
            for k in sorted(set(fetch) | set(write))}
 json.dump({"head": head(),
-           "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --clients 0",
-           "note": "KB per launch, last launch of each kernel (the query step; index-build kernels launch once).  On gfx950 FETCH_SIZE reports half "
-                   "the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM): bench.py doubles it; narrower access patterns are uncalibrated.",
+           "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, --pmc WRITE_SIZE) --output-format csv -- " + os.environ.get("FA_PROFILE_COMMAND", "python3 bench.py ..."),
+           "steps_summed": max(SUM_STEPS, 1),
+           "note": ("KB summed over ALL launches of each kernel in a run of `steps_summed` identical steps (bench.py divides by it)" if SUM_STEPS else
+                    "KB per launch, last launch of each kernel (the query step; index-build kernels launch once)") +
+                   ".  On gfx950 FETCH_SIZE reports half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM): bench.py doubles it; "
+                   "narrower access patterns are uncalibrated.",
            "kernels": kernels}, open(prefix + "_traffic.json", "w"), indent=1)
 sq = last_launch("sq_a")
 for k, v in last_launch("sq_b").items():

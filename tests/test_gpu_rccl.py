@@ -46,27 +46,39 @@ def _check_strong_line(out, n_gpus):
     return line
 
 
-def test_bench_strong_one_gpu():
-    """bench.py --strong at N = 1: config 3 in miniature, every genome hits itself at exactly 100.0."""
+@pytest.fixture(scope="module")
+def strong_n1():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + STRONG_SMALL, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stdout + res.stderr
-    _check_strong_line(res.stdout, 1)
+    return _check_strong_line(res.stdout, 1)
 
 
-def test_bench_strong_two_ranks_sharing_one_gpu():
-    """The N = 2 strong-scaling path (queries dealt by fragment count, sketch shards and hit tables exchanged) with both
-    ranks on GPU 0 and gloo as the transport (RCCL refuses two ranks on one device)."""
+def test_bench_strong_one_gpu(strong_n1):
+    """bench.py --strong at N = 1: config 3 in miniature, every genome hits itself at exactly 100.0; the step is
+    device-resident (rows written into a preallocated HBM table) and carries its L2 roofline."""
+    assert strong_n1["roofline"]["algorithmic_bytes"] > 0 and strong_n1["phases_ms"]["l2_ms"] > 0
+    assert "HBM table" in strong_n1["config"]["exchange"]
+
+
+def test_bench_strong_two_ranks_sharing_one_gpu(strong_n1):
+    """The N = 2 strong-scaling path (queries dealt by fragment count, sketch shards exchanged, the device-resident hit
+    tables all-gathered by ONE collective) with both ranks on GPU 0 and gloo as the transport (RCCL refuses two ranks on
+    one device): the all-gathered table equals the N = 1 table byte for byte (digest over the rows in (query, reference)
+    order)."""
     res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2"] + STRONG_SMALL, 2, env={"FA_BENCH_SHARE_GPU": "1"})
     assert res.returncode == 0, res.stdout + res.stderr
     line = _check_strong_line(res.stdout, 2)
     assert "sharded sketching x2" in line["config"]["index_build"]
+    assert line["config"]["rows_per_step"] == strong_n1["config"]["rows_per_step"]
+    assert line["config"]["table_sha256"] == strong_n1["config"]["table_sha256"]
 
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")
 def test_bench_strong_rccl_two_gpus():
     res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2"] + STRONG_SMALL, 2)
     assert res.returncode == 0, res.stdout + res.stderr
-    _check_strong_line(res.stdout, 2)
+    line = _check_strong_line(res.stdout, 2)
+    assert "all_gather_into_tensor" in line["config"]["exchange"]
 
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")

@@ -288,11 +288,29 @@ STRONG_WORKER = textwrap.dedent("""
     owned = shards[rank]
     rows = np.array([(local, r, weights[q] // 2, weights[q], 80.0 + q + r / 8) for local, q in enumerate(owned) for r in range(4) if (q + r) % 2 == 0],
                     dtype=ROW_DTYPE)
-    rows = sharding.remap_query_ids(rows, owned)
     max_rows = max(len(o) for o in shards) * 4
+    want = np.array([(q, r, weights[q] // 2, weights[q], 80.0 + q + r / 8) for q in range(9) for r in range(4) if (q + r) % 2 == 0], dtype=ROW_DTYPE)
+    # (a) the resident form bench.py --strong uses: a stand-in batch writes batch-local rows at the pointer it is given
+    # (as GenomeBatch.query_rows_device does into HBM), ids are remapped on the table's device, ONE all_gather_into_tensor
+    import ctypes
+    class Batch:
+        calls = 0
+        def query_rows_device(self, first, count, ptr, cap):
+            assert first == 0 and count == len(owned) and cap == max_rows
+            Batch.calls += 1
+            ctypes.memmove(ptr, rows.ctypes.data, rows.nbytes)
+            return len(rows)
+    table = sharding.ResidentHitTable(owned, max_rows, world, comm_device="cpu", table_device="cpu")
+    for _ in range(2):                                                   # a second step reuses the buffers
+        tables = table.step(Batch())
+    assert tuple(tables.shape) == (world, max_rows + 1, 5) and Batch.calls == 2
+    res = sharding.ResidentHitTable.rows_of(tables)
+    res = res[np.lexsort((res["ref_genome_id"], res["query_id"]))]
+    assert res.tobytes() == want.tobytes(), (rank, res.tolist())
+    # (b) the host form (sharding.all_vs_all)
+    rows = sharding.remap_query_ids(rows, owned)
     out = sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows), max_rows=max_rows))   # ONE collective
     out = out[np.lexsort((out["ref_genome_id"], out["query_id"]))]
-    want = np.array([(q, r, weights[q] // 2, weights[q], 80.0 + q + r / 8) for q in range(9) for r in range(4) if (q + r) % 2 == 0], dtype=ROW_DTYPE)
     assert out.tobytes() == want.tobytes(), (rank, out.tolist())
     loads = [sum(weights[i] for i in o) for o in shards]
     assert max(loads) - min(loads) <= max(weights)
