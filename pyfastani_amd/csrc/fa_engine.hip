@@ -388,6 +388,12 @@ struct Workspace {
   DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo, big_state;
+  // workgroup order of k_l2_events for passes of several genomes (L2Args::frag_order), cached while the same part repeats
+  DevBuf<int32_t> frag_order;
+  PinnedBuf pin_order;
+  const void *order_batch = nullptr;
+  int64_t order_f0 = -1, order_f1 = -1;
+  uint32_t order_len = 0;
   DevBuf<unsigned long long> group_best, bins;
   DevBuf<float> row_ident;
   DevBuf<fa_cgi_row> rows_dev;
@@ -716,6 +722,37 @@ static int64_t pass_fragments() {
   return v;
 }
 
+// Workgroup order of k_l2_events over the fragments [f0, f1) of a pass that holds several genomes: fragments sorted by their
+// offset inside their genome (then by genome), the groups of equal offset dealt to the eight XCDs in turn, and the eight
+// lists interleaved the way workgroups are dispatched (workgroup b runs on XCD b mod 8); -1 pads the shorter lists.
+static uint32_t build_frag_order(const fa_genomes &g, int32_t g0, int64_t f0, int64_t f1, std::vector<int32_t> &out) {
+  const int64_t F = f1 - f0;
+  int32_t q = g0;
+  while (g.genome_frag_lo[q + 1] <= f0) q++;
+  // offset of every fragment inside its genome, counting sort by it (stable: genomes stay in order inside a group)
+  std::vector<int32_t> off((size_t)F);
+  int32_t max_off = 0;
+  for (int64_t i = 0, qq = q; i < F; i++) {
+    while (g.genome_frag_lo[qq + 1] <= f0 + i) qq++;
+    off[(size_t)i] = (int32_t)(f0 + i - g.genome_frag_lo[qq]);
+    max_off = std::max(max_off, off[(size_t)i]);
+  }
+  std::vector<int32_t> start((size_t)max_off + 2, 0);
+  for (int64_t i = 0; i < F; i++) start[(size_t)off[(size_t)i] + 1]++;
+  for (int32_t p = 0; p <= max_off; p++) start[(size_t)p + 1] += start[(size_t)p];
+  std::vector<int32_t> sorted((size_t)F), fill(start.begin(), start.end() - 1);
+  for (int64_t i = 0; i < F; i++) sorted[(size_t)fill[(size_t)off[(size_t)i]]++] = (int32_t)i;
+  // groups -> XCD lists (group p goes to XCD p mod 8), then interleave
+  size_t len[8] = {0};
+  for (int32_t p = 0; p <= max_off; p++) len[p & 7] += (size_t)(start[(size_t)p + 1] - start[(size_t)p]);
+  const size_t longest = *std::max_element(len, len + 8);
+  out.assign(longest * 8, -1);
+  size_t at[8] = {0};
+  for (int32_t p = 0; p <= max_off; p++)
+    for (int32_t i = start[(size_t)p]; i < start[(size_t)p + 1]; i++) out[(at[p & 7]++) * 8 + (size_t)(p & 7)] = sorted[(size_t)i];
+  return (uint32_t)out.size();
+}
+
 // One pass of the hot path over genomes [g0, g1) of a resident batch.  Everything between the first kernel and the
 // final read-back is asynchronous on one stream: sizes that depend on the data (largest sketch, seed hits per
 // fragment, loci, slide events) are *speculated* from earlier passes (fa_mapper::spec), checked on the device, and the
@@ -996,6 +1033,23 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.l_redo = ln.l_redo.p;
       a.redo_count = d_counters + 3;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
+      // several genomes in the pass: the workgroups of k_l2_events in offset-major order (see build_frag_order)
+      a.frag_order = nullptr;
+      uint32_t ev_grid = (uint32_t)F;
+      static const bool order_on = !(getenv("FA_FRAG_ORDER") && atoi(getenv("FA_FRAG_ORDER")) == 0);
+      if (order_on && NQ >= 2 && F >= 64) {
+        if (ln.order_batch != (const void *)&g || ln.order_f0 != f0 || ln.order_f1 != f1) {
+          std::vector<int32_t> ord;
+          ln.order_len = build_frag_order(g, g0, f0, f1, ord);
+          ln.pin_order.ensure(ord.size() * sizeof(int32_t));
+          memcpy(ln.pin_order.p, ord.data(), ord.size() * sizeof(int32_t));
+          ln.frag_order.ensure(ord.size());
+          FA_HIP(hipMemcpyAsync(ln.frag_order.p, ln.pin_order.p, ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+          ln.order_batch = (const void *)&g; ln.order_f0 = f0; ln.order_f1 = f1;
+        }
+        a.frag_order = ln.frag_order.p;
+        ev_grid = ln.order_len;
+      }
 #ifdef FA_EXPERIMENTS
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
@@ -1021,7 +1075,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       const size_t lds8 = scan_lds(lanes8, 1) + scan_pad, lds16 = scan_lds(lanes16, 2);
       auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
         if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
-        hipLaunchKernelGGL(ev_kernel, dim3((unsigned)F), dim3(EV_THREADS), ev_lds, st, a);
+        hipLaunchKernelGGL(ev_kernel, dim3(ev_grid), dim3(EV_THREADS), ev_lds, st, a);
         debug_sync(st, "l2 events");
         // the number of loci is only known on the device: launch for the capacity, surplus workgroups exit at once
         a.lanes = lanes8;

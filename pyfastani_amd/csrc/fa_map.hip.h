@@ -1151,6 +1151,11 @@ struct L2Args {
   uint8_t *l_redo;                   // [loci] set by the uint8-state scan when a count overflowed
   uint32_t *redo_count;              // number of loci sent to the uint16 pass
   const uint32_t *f_loci_lo, *f_loci_n;   // [F] loci of each fragment
+  // k_l2_events, passes of several query genomes: workgroup b takes fragment frag_order[b] (-1: none).  The order puts the
+  // fragments that sit at the same offset of their genomes next to each other AND on one XCD (workgroups go to XCDs round
+  // robin): related genomes are largely co-linear, so those workgroups stream the same stretches of the index at the same
+  // time and all but the first find them in the XCD's L2 / the memory-side cache instead of HBM.  nullptr: identity.
+  const int32_t *frag_order;
   unsigned long long *stamp;         // stage_stamp: start of the L2 stage
 #ifdef FA_EXPERIMENTS
   int32_t dbg;                       // FA_FUSED_DEBUG (timing experiments only, results are void): 1 = slider idles,
@@ -1200,7 +1205,8 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   uint32_t *Q = (uint32_t *)lds;                                     // [s + EV_PROBE], staged once per fragment, with sentinels
   constexpr int QT_BITS = EV_QT_BITS;
   __shared__ uint16_t QT[(1 << QT_BITS) + 2];
-  const int f = blockIdx.x;
+  const int f = a.frag_order ? a.frag_order[blockIdx.x] : (int)blockIdx.x;
+  if (f < 0) return;
   const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
   if (l_n == 0) return;
   const int s = a.q_size[f];

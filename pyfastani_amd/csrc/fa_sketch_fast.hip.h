@@ -120,6 +120,10 @@ __global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
     return;
   }
   if (a.clear.stamp && blockIdx.x == 0 && tid == 0) a.clear.stamp[0] = __builtin_amdgcn_s_memrealtime();   // start of the pass
+  // the premix tables are on their way (constants of the code object, 16 KB away in L2) while the tile descriptor is fetched
+  constexpr bool TABLES = KT == 14 || KT == 16 || KT == 21;
+  uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;
+  if (TABLES) { const uint4 *src = (const uint4 *)d_premix.v; tv0 = src[tid]; tv1 = src[tid + SK_THREADS]; }
   const Tile t = a.tiles[blockIdx.x];
   if (t.exc_n > 0) return;                                          // a tile with other bytes: k_sketch_tiles<0, true> takes it
   const int k = KT ? KT : a.k, w = WT ? WT : a.w;
@@ -140,11 +144,7 @@ __global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
   // halo", and FRONT is chosen so that a thread's first read (position hb + 4 tid - w) is 16-byte aligned
   const int FRONT = w + ((4 - (hb & 3)) & 3);
   uint32_t *const Hs = Hst + FRONT;
-  if (KT == 14 || KT == 16 || KT == 21) {
-    const uint4 *src = (const uint4 *)d_premix.v;
-    uint4 *dst = (uint4 *)tc;
-    for (int i = tid; i < 512; i += SK_THREADS) dst[i] = src[i];
-  }
+  if (TABLES) { uint4 *dst = (uint4 *)tc; dst[tid] = tv0; dst[tid + SK_THREADS] = tv1; }
   // ---- 1. stage the 2-bit image ----
   const int64_t w0 = base0 >> 4;
   const int shift = (int)(base0 & 15);

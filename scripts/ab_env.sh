@@ -9,7 +9,7 @@ for v in "$@"; do
   rm -rf /tmp/abe_$i
   (
     for kv in $v; do export "$kv"; done
-    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abe_$i -- python3 scripts/time_pass.py 20 2> /tmp/abe_$i.err | tail -1
+    rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abe_$i -- python3 scripts/time_pass.py ${AB_STEPS:-20} ${AB_QUERIES:-1} 2> /tmp/abe_$i.err | tail -1
   )
   echo "== $v"
   f=$(find /tmp/abe_$i -name "*kernel_stats.csv" | head -1)

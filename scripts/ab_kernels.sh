@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 for v in "$@"; do
   cp pyfastani_amd/lib/$v pyfastani_amd/lib/libfastani_hip.so
   rm -rf /tmp/ab_$v
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -- python3 scripts/time_pass.py 20 > /dev/null 2> /tmp/ab_$v.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ab_$v -- python3 scripts/time_pass.py ${AB_STEPS:-20} ${AB_QUERIES:-1} > /dev/null 2> /tmp/ab_$v.err
   echo "== $v"
   f=$(find /tmp/ab_$v -name "*kernel_stats.csv" | head -1)
   python3 - "$f" <<'PY'

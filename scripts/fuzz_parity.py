@@ -1,6 +1,6 @@
 """Differential fuzzing of the HIP path against the CPU oracle: random genomes with planted repeats, tandem
 duplications, inversions, N runs and low-complexity stretches; random parameters.  Every L2 mapping and every hit must
-match.  Usage: python scripts/fuzz_parity.py [cases] [seed]"""
+match.  Usage: python scripts/fuzz_parity.py [cases] [seed] [seconds]   (stops after `seconds` if given: a time box)"""
 import sys, os, ctypes as C, warnings, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -52,6 +52,8 @@ def to_bytes(g, codes):
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+time_box = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+done = 0
 g = syn.rng(seed)
 bad = 0
 t0 = time.time()
@@ -88,6 +90,9 @@ def protein_case(g, case):
     return ok
 
 for case in range(cases):
+    if time_box and time.time() - t0 > time_box:
+        break
+    done = case + 1
     if case % 10 == 9:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -145,5 +150,5 @@ for case in range(cases):
         print(f"MISMATCH case {case} seed {seed} params {params} window {osk.window_size}: hits {hits} vs {ohits}; mappings gpu {len(gm)} oracle {len(omm)}")
         sg, so = set(gm), set(omm)
         print("   only gpu", sorted(sg - so)[:4], "only oracle", sorted(so - sg)[:4])
-print(f"{cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+print(f"{done} cases (seed {seed}), {bad} mismatches, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)
