@@ -255,10 +255,16 @@ def weak_scaling(ctx):
     l2_bytes = l2_records * 12.0
     l2_gbs = l2_bytes / max(phase["l2_ms"] * 1e-3, 1e-9) / 1e9
     l2_name = "k_l2_events+k_l2_scan"
-    dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_tiles"
-    roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_tiles": (k1_gbs, k1_ms.value)}[dominant]
+    dominant = l2_name if phase["l2_ms"] >= phase["sketch_ms"] else "k_sketch_fast"
+    roof = {l2_name: (l2_gbs, phase["l2_ms"]), "k_sketch_fast": (k1_gbs, k1_ms.value)}[dominant]
     traffic, traffic_source = (profiled_traffic("l2" if dominant == l2_name else "k1")
                                if args.batch == 1 and args.refs == 100 and args.length == 5_000_000 else (None, None))
+    standard = args.batch == 1 and args.refs == 100 and args.length == 5_000_000
+    roof_extra = issue_floor("step", phase["l2_ms"]) if standard and dominant == l2_name else {}
+    k1_model = valu_model().get("k_sketch_fast", {})
+    sketch_extra = ({"issue_floor_gbases_per_s": k1_model["issue_floor_gbases_per_s"],
+                     "valu_frac": bases.value / (k1_ms.value * 1e-3) / 1e9 / k1_model["issue_floor_gbases_per_s"],
+                     "issue_floor_source": "profiles/r03_valu_model.json"} if k1_model else {})
     result = {
         "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
         "value": value,
@@ -280,10 +286,10 @@ def weak_scaling(ctx):
                      "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": roof[1],
                      "kernel_ms_source": "device stamps (100 MHz counter) at the stage boundaries of every timed step, on the library's stream",
                      "kernel_ms_hip_events": ev_ms if dominant == l2_name else None,
-                     "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes},
-        "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_tiles", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes, **roof_extra},
+        "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,
-                            "algorithmic_bytes": k1_bytes},
+                            "algorithmic_bytes": k1_bytes, **sketch_extra},
         "phases_ms": phase,
     }
     if world == 1:
@@ -387,13 +393,32 @@ def profiled_traffic(which, profile=None):
     try:
         doc = json.load(open(path))
         table = doc["kernels"]
-        pick = [k for k in table if (k.startswith("k_l2_") if which == "l2" else k.startswith("k_sketch_tiles<16, false>"))]
+        pick = [k for k in table if (k.startswith("k_l2_") if which == "l2" else k.startswith("k_sketch_fast<16, 24>"))]
         if not pick:
             return None, None
         total = sum((2.0 * table[k]["fetch_size_kb"] + table[k]["write_size_kb"]) * 1024.0 * table[k].get("launches_per_step", 1) for k in pick)
         return total / float(doc.get("steps_summed", 1)), f"profiles/{profile}@{doc.get('head', 'unknown')}"
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def valu_model():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r03_valu_model.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+def issue_floor(regime, l2_ms):
+    """Vector-issue floor of the L2 stage from profiles/r03_valu_model.json (executed VALU wave-instructions of the two
+    kernels x the measured issue-slot cost of their instruction mix / (1024 SIMDs x clock)) and its share of the measured
+    stage time: the stage is integer work on the vector pipes, this -- not HBM -- is the roofline it actually sits under."""
+    rows = valu_model().get("regimes", {}).get(regime, {})
+    floors = {k: v["issue_floor_ms"] for k, v in rows.items() if k.startswith("k_l2_")}
+    if len(floors) < 2 or l2_ms <= 0:
+        return {}
+    return {"issue_floor_ms": sum(floors.values()), "valu_frac": sum(floors.values()) / l2_ms,
+            "issue_floor_ms_by_kernel": floors, "issue_floor_source": "profiles/r03_valu_model.json (scripts/valu_model.py)"}
 
 
 def stage_roofline(l2_records, l2_ms, traffic, traffic_source):
@@ -440,11 +465,14 @@ def saturated_legs(ctx, mapper, anc, batch16_steps=10):
     dt = time.perf_counter() - t0
     phase /= batch16_steps
     traffic, src = (profiled_traffic("l2", TRAFFIC_PROFILE_BATCH16) if args.refs == 100 and args.length == 5_000_000 else (None, None))
+    roof16 = stage_roofline(rec / batch16_steps, float(phase[2]), traffic, src)
+    if args.refs == 100 and args.length == 5_000_000:
+        roof16.update(issue_floor("batch16", float(phase[2])))
     out["batch16"] = {"workload": f"{nq} queries x {args.refs} synthetic {args.length / 1e6:g} Mb refs in ONE launch sequence, k=16 frag=3000",
                       "value": nq * args.refs * batch16_steps / dt, "unit": "pairs/s", "steps": batch16_steps, "ms_per_step": dt / batch16_steps * 1e3,
                       "ms_per_query": dt / batch16_steps / nq * 1e3, "rows_per_step": int(n_rows), "l2_loci": int(loci / batch16_steps),
                       "phases_ms": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase])),
-                      "roofline": stage_roofline(rec / batch16_steps, float(phase[2]), traffic, src)}
+                      "roofline": roof16}
     del batch, table
     # ---- config 3 at N = 1 ----
     if args.saturated_steps > 0:

@@ -438,7 +438,7 @@ struct fa_mapper {
   DevBuf<uint4> table;
   DevBuf<int32_t> rec_seq, rec_wpos, rec_prev, rec_fwd, rec_bwd, contig_rec, contig_genome, contig_bin, genome_bin;
   DevBuf<uint8_t> rec_flags;
-  DevBuf<uint32_t> rec_geo;       // packed window geometry + flags for k_l2_events (empty when cmw >= 8191)
+  DevBuf<uint2> rec_hg;           // (hash, packed window geometry + flags) for k_l2_events (empty when cmw >= 8191)
   DevBuf<uint16_t> rec_prev16;
   DevBuf<int2> rec_sw;            // (rec_seq, rec_wpos) interleaved for k_l1
 #ifdef FA_EXPERIMENTS
@@ -480,7 +480,7 @@ struct fa_mapper {
   IndexView view() const {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
-    v.rec_geo = packed_geo ? rec_geo.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_sw = rec_sw.p;
+    v.rec_hg = packed_geo ? rec_hg.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_sw = rec_sw.p;
 #ifdef FA_EXPERIMENTS
     v.ev_bits = ev_bits.p; v.rec_hf = rec_hf.p;
 #endif
@@ -641,9 +641,9 @@ static void build_index(fa_mapper &m) {
 #endif
     m.packed_geo = m.cmw + 1 < (1 << GEO_BITS);
     if (m.packed_geo) {
-      m.rec_geo.ensure((size_t)N + 4); m.rec_prev16.ensure((size_t)N + 4);
-      hipLaunchKernelGGL(k_pack_geometry, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_prev.p, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p, N,
-                         m.rec_geo.p, m.rec_prev16.p);
+      m.rec_hg.ensure((size_t)N + 4); m.rec_prev16.ensure((size_t)N + 4);
+      hipLaunchKernelGGL(k_pack_geometry, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_hash.p, m.rec_prev.p, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p, N,
+                         m.rec_hg.p, m.rec_prev16.p);
     }
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(st));

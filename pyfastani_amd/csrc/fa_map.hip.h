@@ -168,18 +168,18 @@ __global__ void k_interleave_seq_wpos(const int32_t *rec_seq, const int32_t *rec
   if (i < N) rec_sw[i] = make_int2(rec_seq[i], rec_wpos[i]);
 }
 
-// The same geometry packed for the hot loop of k_l2_events (fewer bytes per record, fewer loads): one 32-bit word
-//   geo[i] = (rec_fwd[i+1] - (i+1)) | (i - rec_bwd[i]) << 13 | flags << 26,   both distances are <= cmw < 8192,
+// The same geometry packed for the hot loop of k_l2_events (fewer bytes per record, ONE load and one address per record):
+//   hg[i] = { hash,  (rec_fwd[i+1] - (i+1)) | (i - rec_bwd[i]) << 13 | flags << 26 },   both distances are <= cmw < 8192,
 // and prev16[i] = min(i - rec_prev[i], 65535) (65535 also for "no earlier record with this hash in the contig": only
 // compared against distances < 8192).  Built only when cmw + 1 < 8192; otherwise the kernels read the plain arrays.
 constexpr int GEO_BITS = 13;
-__global__ void k_pack_geometry(const int32_t *rec_prev, const int32_t *rec_fwd, const int32_t *rec_bwd, const uint8_t *rec_flags, int64_t N,
-                                uint32_t *rec_geo, uint16_t *rec_prev16) {
+__global__ void k_pack_geometry(const uint32_t *rec_hash, const int32_t *rec_prev, const int32_t *rec_fwd, const int32_t *rec_bwd, const uint8_t *rec_flags,
+                                int64_t N, uint2 *rec_hg, uint16_t *rec_prev16) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const uint32_t fwd1 = i + 1 < N ? (uint32_t)(rec_fwd[i + 1] - (int32_t)(i + 1)) : 0u;
   const uint32_t bwd = (uint32_t)((int32_t)i - rec_bwd[i]);
-  rec_geo[i] = (fwd1 & ((1u << GEO_BITS) - 1u)) | ((bwd & ((1u << GEO_BITS) - 1u)) << GEO_BITS) | ((uint32_t)rec_flags[i] << (2 * GEO_BITS));
+  rec_hg[i] = make_uint2(rec_hash[i], (fwd1 & ((1u << GEO_BITS) - 1u)) | ((bwd & ((1u << GEO_BITS) - 1u)) << GEO_BITS) | ((uint32_t)rec_flags[i] << (2 * GEO_BITS)));
   const int32_t pv = rec_prev[i];
   rec_prev16[i] = (uint16_t)(pv < 0 ? 65535 : min((int32_t)i - pv, 65535));
 }
@@ -194,7 +194,7 @@ struct IndexView {
   const int32_t *rec_prev;
   const int32_t *rec_fwd, *rec_bwd;
   const uint8_t *rec_flags;
-  const uint32_t *rec_geo;      // packed geometry (k_pack_geometry), null when cmw is too large for it
+  const uint2 *rec_hg;          // (hash, packed geometry) (k_pack_geometry), null when cmw is too large for it
   const uint16_t *rec_prev16;
   const int2 *rec_sw;           // (rec_seq, rec_wpos) interleaved: one 8-byte gather per seed hit in k_l1
 #ifdef FA_EXPERIMENTS
@@ -1314,9 +1314,13 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
 #pragma unroll
     for (int u = 0; u < EV_RPL; u++) {
       const int ic = min(t0 + lane + 64 * u, hi - 1);
-      t.h[u] = a.ix.rec_hash[ic];
-      if (PACKED) t.geo[u] = a.ix.rec_geo[ic];
-      else { t.rf[u] = a.ix.rec_flags[ic]; t.bw[u] = a.ix.rec_bwd[ic]; t.fw[u] = a.ix.rec_fwd[ic + 1]; }
+      if (PACKED) {
+        // (a uniform base -- the first record of the trip -- plus a 32-bit byte offset: the load takes both as they are,
+        // where indexing with a signed record number cost a sign extension and a 64-bit shift-add per record)
+        const uint32_t off = min((uint32_t)(lane + 64 * u), (uint32_t)(hi - 1 - t0)) * (uint32_t)sizeof(uint2);
+        const uint2 hg = *(const uint2 *)((const char *)(a.ix.rec_hg + t0) + off);
+        t.h[u] = hg.x; t.geo[u] = hg.y;
+      } else { t.h[u] = a.ix.rec_hash[ic]; t.rf[u] = a.ix.rec_flags[ic]; t.bw[u] = a.ix.rec_bwd[ic]; t.fw[u] = a.ix.rec_fwd[ic + 1]; }
     }
     if (first) {                                                     // (uniform)
 #pragma unroll
@@ -1338,7 +1342,10 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     // EV_PROBE sketch entries at once; the few hashes that rank behind all of them walk on (the sentinels stop the
     // walk).  Both the sketch and the reference hashes crowd towards 0, so two entries were not enough: nine trips out
     // of ten still took the walk.
-    int x[EV_RPL]; uint32_t q[EV_RPL][EV_PROBE]; bool found[EV_RPL], more = false;
+    // (membership is read off the entry AT the final rank -- the sketch is sorted and distinct, so that entry is the first
+    // one >= the hash: one more LDS read instead of four equality tests whose results, kept as booleans across the walk,
+    // the compiler packed into bytes at ten instructions per record)
+    int x[EV_RPL]; uint32_t q[EV_RPL][EV_PROBE], qx[EV_RPL]; bool found[EV_RPL], more = false;
 #pragma unroll
     for (int u = 0; u < EV_RPL; u++) x[u] = QT[min(t.h[u] >> qshift, (uint32_t)(1 << QT_BITS))];   // the last bucket is [2^bits, inf): rank s
 #pragma unroll
@@ -1348,16 +1355,49 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     }
 #pragma unroll
     for (int u = 0; u < EV_RPL; u++) {
-      found[u] = false;
-      int below = 0;
 #pragma unroll
-      for (int j = 0; j < EV_PROBE; j++) { below += q[u][j] < t.h[u] ? 1 : 0; found[u] = found[u] || q[u][j] == t.h[u]; }
-      x[u] += below;
+      for (int j = 0; j < EV_PROBE; j++) x[u] += q[u][j] < t.h[u] ? 1 : 0;     // (a compare and an add-with-carry per entry)
       more = more || q[u][EV_PROBE - 1] < t.h[u];
     }
     if (__builtin_amdgcn_ballot_w64(more)) {
 #pragma unroll
-      for (int u = 0; u < EV_RPL; u++) if (q[u][EV_PROBE - 1] < t.h[u]) { while (Q[x[u]] < t.h[u]) x[u]++; found[u] = Q[x[u]] == t.h[u]; }
+      for (int u = 0; u < EV_RPL; u++) if (q[u][EV_PROBE - 1] < t.h[u]) { while (Q[x[u]] < t.h[u]) x[u]++; }
+    }
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) qx[u] = Q[x[u]];
+#pragma unroll
+    for (int u = 0; u < EV_RPL; u++) found[u] = qx[u] == t.h[u];
+    if constexpr (PACKED) {
+      // Bit arithmetic instead of compare + select: this kernel runs seven waves per SIMD and IS its vector issue slots
+      // (profiles/r03_valu_model.json), where v_and / v_or / v_add / v_sub / v_lshrrev cost 2.3 cycles and v_cmp, v_cndmask,
+      // v_bfe and the three-operand forms 4.2 (profiles/r03_valu_rates.txt).  With c = n_init_pad - end0 - beg (uniform),
+      // Bd / Fd the packed distances and the flags as single bits of the same word:
+      //   admit at  c + 2i - Bd,        value  base | (not linked ? unit : 0)
+      //   drop  at  c + 2i + 1 + Fd - same,    base | (not linked ? 3 unit : 0) | DROP | (same ? no-eval : 0)
+      // unit = 1 << EV_DM for a hash of the query sketch, 1 << EV_DW otherwise (the two-bit field then holds +1 resp. -1).
+      const int c2 = n_init_pad - end0 - beg + 2 * (t0 + lane);
+#pragma unroll
+      for (int u = 0; u < EV_RPL; u++) {
+        const int i = t0 + lane + 64 * u;
+        if (i >= hi) continue;
+        const uint32_t geo = t.geo[u], ng = ~geo;
+        const uint32_t base = (uint32_t)(x[u] + 1) << EV_SLOT;
+        const uint32_t unit = (found[u] && x[u] < s) ? (1u << EV_DM) : (1u << EV_DW);
+        if (FIRST) {
+          const bool prev_in = t.pd[u] <= (uint32_t)(i - beg);
+          store((uint32_t)(i - beg), base | (prev_in ? 0u : unit) | (i == end0 - 1 ? 0u : ev_noeval<T>()));
+        } else {
+          const uint32_t m_ins = 0u - ((ng >> (2 * GEO_BITS)) & 1u);                   // FLAG_INS_LINKED clear
+          store((uint32_t)(c2 + 128 * u) - ((geo >> GEO_BITS) & ((1u << GEO_BITS) - 1u)), base | (unit & m_ins));
+        }
+        if (i - beg < ndrop) {
+          const uint32_t same = (geo >> (2 * GEO_BITS + 2)) & 1u;                      // FLAG_SAME_STEP
+          const uint32_t m_del = 0u - ((ng >> (2 * GEO_BITS + 1)) & 1u);               // FLAG_DEL_LINKED clear
+          store((uint32_t)(c2 + 128 * u + 1) + (geo & ((1u << GEO_BITS) - 1u)) - same,
+                base | ((unit + unit + unit) & m_del) | (1u << EV_DROP) | ((0u - same) & ev_noeval<T>()));
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int u = 0; u < EV_RPL; u++) {

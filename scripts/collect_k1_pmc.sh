@@ -2,7 +2,7 @@
 # SQ counters of the sketch kernel alone (scripts/bench_k1.py 20 2), two rocprofv3 --pmc passes, summarised into
 # gpurun_out/<tag>_k1_pmc.json:   bash scripts/collect_k1_pmc.sh r02
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/${TAG}_k1_prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -15,7 +15,7 @@ tot, launches, rows = {}, {}, []
 for sub in ("a", "b"):
     for path in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(path)):
-            if "k_sketch_tiles<16, false>" not in r["Kernel_Name"]:
+            if "k_sketch_fast<16, 24>" not in r["Kernel_Name"]:
                 continue
             rows.append(r)
 grid = max(int(r["Grid_Size"]) for r in rows)                 # the launches over the whole batch, not the one-genome index's
@@ -32,11 +32,10 @@ d = {"command": "two rocprofv3 --pmc passes -- python3 scripts/bench_k1.py 20 2 
 if "SQ_INSTS_VALU" in per:
     d["derived"]["valu_lane_instructions_per_base"] = per["SQ_INSTS_VALU"] * 64.0 / bases
 ms = float(line.split("ms=")[1].split()[0])
-if "SQ_ACTIVE_INST_VALU" in per:
-    # SQ_ACTIVE_INST_* count quad-cycles summed over the chip (MI355X_MICROARCH.md): per CU-cycle they give the share of the
-    # four SIMDs' issue slots that carried a VALU instruction; 256 CUs at ~2.1 GHz under load, as in profiles/r01_k1_pmc.json
-    d["derived"]["valu_busy_fraction_of_simd_cycles"] = per["SQ_ACTIVE_INST_VALU"] / (ms * 1e-3 * 2.1e9 * 256.0)
-    d["derived"]["ms_per_launch_under_the_profiler"] = ms
+d["derived"]["ms_per_launch_under_the_profiler"] = ms
+d["derived"]["note"] = ("VALU wave-instructions per base = valu_lane_instructions_per_base / 64; scripts/valu_model.py prices them with the issue-slot "
+                        "costs measured by scripts/ubench/valu_rates.hip (profiles/r03_valu_rates.txt): 2.33 cycles for plain add / logic / right "
+                        "shift, 4.2 for everything else, multiplies included")
 json.dump(d, open(dst, "w"), indent=1)
 print(json.dumps(d["derived"]), line)
 PY

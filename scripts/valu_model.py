@@ -1,0 +1,58 @@
+"""Vector-issue floors of the hot kernels: executed VALU wave-instructions (rocprofv3 SQ_INSTS_VALU, profiles/r03_*_pmc.json)
+x the mean issue-slot cost of the kernel's hot loop (profiles/r03_isa_mix.json, priced with profiles/r03_valu_rates.txt)
+/ (SIMDs x clock):
+
+    python3 scripts/valu_model.py > profiles/r03_valu_model.json
+
+`issue_floor_ms` is what the kernel would take if every SIMD issued vector instructions back to back and nothing else
+ever stalled it; bench.py reports floor / measured time as `valu_frac`.  It is a lower bound, reached only where enough
+waves share a SIMD (k_sketch_fast: 8, k_l2_events: 7); k_l2_scan holds two waves per SIMD (its LDS state) and is bound by
+each wave's own issue cadence and LDS round trips instead (profiles/EXPERIMENTS.md, round 3)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+SIMDS = 1024            # 256 CUs x 4
+CLOCK_MHZ = 2300.0      # measured under integer-VALU load by scripts/ubench/valu_rates.hip (2.2 - 2.4 GHz; 2.4 nominal)
+
+
+def load(name):
+    try:
+        return json.load(open(os.path.join(P, name)))
+    except OSError:
+        return None
+
+
+def main():
+    mix = load("r03_isa_mix.json")
+    out = {"simds": SIMDS, "clock_mhz": CLOCK_MHZ, "slot_cycles": mix["slot_cycles"],
+           "sources": ["profiles/r03_isa_mix.json", "profiles/r03_map_kernels_pmc.json", "profiles/r03_batch16_map_kernels_pmc.json",
+                       "profiles/r03_k1_pmc.json", "profiles/r03_valu_rates.txt"], "regimes": {}}
+    slot = {k: v["mean_slot_cycles"] for k, v in mix["kernels"].items()}
+    alias = {"k_sketch_fast<16, 24>": "k_sketch_fast<16, 24>", "k_l2_scan<unsigned short, unsigned char, 64>": "k_l2_scan<unsigned short, unsigned char, 64>",
+             "k_l2_events<unsigned short, true>": "k_l2_events<unsigned short, true>", "k_l1<256, 16>": "k_l1<256, 16>"}
+    for regime, fname in (("step", "r03_map_kernels_pmc.json"), ("batch16", "r03_batch16_map_kernels_pmc.json")):
+        pmc = load(fname)
+        if not pmc:
+            continue
+        rows = {}
+        for k, c in pmc["kernels"].items():
+            if k in alias and c.get("SQ_INSTS_VALU"):
+                n = c["SQ_INSTS_VALU"]
+                rows[k] = {"valu_wave_instructions": n, "mean_slot_cycles": slot[alias[k]],
+                           "issue_floor_ms": n * slot[alias[k]] / (SIMDS * CLOCK_MHZ * 1e3)}
+        out["regimes"][regime] = rows
+    k1 = load("r03_k1_pmc.json")
+    if k1 and "valu_lane_instructions_per_base" in k1.get("derived", {}):
+        per_base = k1["derived"]["valu_lane_instructions_per_base"] / 64.0          # wave-instructions per base
+        c = slot["k_sketch_fast<16, 24>"]
+        out["k_sketch_fast"] = {"valu_wave_instructions_per_base": per_base, "mean_slot_cycles": c,
+                                "issue_floor_gbases_per_s": SIMDS * CLOCK_MHZ * 1e6 / (per_base * c) / 1e9}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
