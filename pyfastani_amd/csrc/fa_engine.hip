@@ -821,7 +821,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
   // again after it).  Measured: no gain (bench step 0.623 / 0.622 / 0.641 ms with 1 / 2 / 3 lanes, 16 queries per
   // launch 237 k / 240 k pairs/s, config 3 2.59 M / 2.55 M) -- every kernel of the path runs its workgroups in one or a
   // few resident rounds, so a third of the fragments takes nearly as long as all of them, and what the lanes add in
-  // overlap they lose in occupancy.  Hence one lane by default; DESIGN.md section 6.
+  // overlap they lose in occupancy.  Hence one lane by default; profiles/EXPERIMENTS.md.
   static const int lanes_wanted = (int)std::min<uint64_t>(3, std::max<uint64_t>(1, env_u64("FA_QUERY_LANES", 1)));
   static const int64_t lane_min_frags = (int64_t)env_u64("FA_LANE_MIN_FRAGMENTS", 256);
   const int64_t F_total = range_f1 - range_f0;
@@ -1100,7 +1100,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
 #ifdef FA_EXPERIMENTS
       // FA_L2_FUSED=1 selects the fused form (events generated into an LDS ring and consumed in place: no event arena in
       // HBM, L2-stage traffic 0.45 GB instead of 1.08 GB per bench step).  It is bit-exact but measured SLOWER than the
-      // two-kernel form on the bench step (0.81 ms against 0.42 ms): one or two producer waves per 64
+      // two-kernel form on the bench step (0.81 ms against 0.42 ms, profiles/EXPERIMENTS.md): one or two producer waves per 64
       // loci cannot hide their LDS round trips the way the 32 waves per CU of k_l2_events do, and the slide state (16-18 KB
       // per 64 loci) leaves no LDS for more.  Kept as an experiment; the default is k_l2_events + k_l2_scan.
       static const bool fused_on = fused_l2_enabled();

@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   // 64 x EV_RPL records (EV_RPL per lane): first the records of the first super-window, then the later ones, then the
   // stream is copied out.  (Measured and left out: issuing the reads of the next trip before working on the current one,
   // two register sets swapping roles, and fetching the ranges of the next locus a locus ahead -- 187 -> 187..195 us; the
-  // kernel moves ~0.85 GB at 4.5 TB/s and is bound by that)
+  // kernel was held to be HBM-bound then; it is bound by its vector issue slots, profiles/EXPERIMENTS.md.)
   const uint32_t l_end = l_lo + l_n;
   uint32_t l = l_lo + wv;
   if (l >= l_end) return;                                            // (no workgroup barrier below this line)

@@ -13,14 +13,19 @@
 //   A *tile* is up to TILE consecutive k-mer positions of one sequence (a reference contig, or one query
 //   fragment); one workgroup sketches one tile.
 //
-// Algorithm per tile (all in LDS, no atomics, no MFMA -- this is integer hashing):
-//   1. stage the packed words of the tile (+ halo of 2w-2 k-mer positions + k-1 bases) with coalesced loads;
-//   2. every lane rebuilds the k ASCII bytes of its k-mer from the 2-bit codes in registers
-//      (spread + v_perm_b32), hashes both strands with MurmurHash3_x64_128(seed 42), takes the canonical minimum
-//      and flags strand-symmetric k-mers as invalid (_fastani.pyx:202);
-//   3. keys (hash<<32 | ~position) go to LDS; log2(w) doubling passes build a sparse table so that the minimum of
-//      any length-w window is two LDS reads -- the argmin is the right-most minimum, as the reference's deque
-//      keeps (_fastani.pyx:211-212 pops on >=);
+// This file holds the host packer, the hash functions, and k_sketch_tiles -- the kernel for what the hot form
+// (k_sketch_fast, fa_sketch_fast.hip.h: plain-ACGT tiles, windows 4..64) does not serve: protein tiles and nucleotide tiles
+// that touch a byte outside ACGT (BYTES = true, hashed from a byte image), windows below 4 or above 64, FA_K1_GENERAL=1.
+//
+// Algorithm of k_sketch_tiles per tile (all in LDS, no atomics, no MFMA -- this is integer hashing):
+//   1. stage the packed words of the tile (+ halo of 2w-2 k-mer positions + k-1 bases) with coalesced loads (BYTES: expand
+//      to bytes and patch the exceptions back in);
+//   2. hash both strands with MurmurHash3_x64_128(seed 42) -- k = 16 from the 2-bit codes through 256-entry premix tables
+//      (the ASCII bytes are never formed), other k from ASCII bytes rebuilt in registers, BYTES from the byte image --,
+//      take the canonical minimum and flag strand-symmetric k-mers as invalid (_fastani.pyx:202);
+//   3. window minimum: tiles whose positions are all valid take 32-bit passes over the hashes (minima over spans growing
+//      x4, then x2); the others rebuild (hash<<32 | ~position) keys and run floor(log2 w) 64-bit doubling passes -- the
+//      argmin is the right-most minimum, as the reference's deque keeps (_fastani.pyx:211-212 pops on >=);
 //   4. a record is emitted where the window argmin differs from the argmin at the previous valid position
 //      (= the deque front changed, _fastani.pyx:219-222); wave ballots + popcount prefix give ordered compaction.
 // The one sequential quirk of the reference -- a new front whose hash equals the first emitted record is
