@@ -210,21 +210,23 @@ def weak_scaling(ctx):
     for i in range(args.warmup):
         step(i)
     exchange(max(args.warmup, 1))
-    phase_ms = np.zeros(5)
+    # stage times of every step (device stamps on the library's stream) land straight in a preallocated array: the timed loop
+    # holds the step and one C call, no Python arithmetic
+    stage_log = np.zeros((max(args.steps, 1), 8), dtype=np.float32)
+    stage_ptr = [C.cast(stage_log[i].ctypes.data, C.POINTER(C.c_float)) for i in range(stage_log.shape[0])]
+    handle = mapper._h
     n_last = 0
     fence(ctx)
     t0 = time.perf_counter()
     for i in range(args.steps):
         n_last = step(i)
-        ms = (C.c_float * 8)()
-        lib.fa_mapper_last_timings(mapper._h, ms, 8)     # stage times of this step: device stamps on the library's stream
-        phase_ms += np.array(list(ms)[:5])
+        lib.fa_mapper_last_timings(handle, stage_ptr[i], 8)
     gathered = exchange(args.steps)
     fence(ctx)
     elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
     # hits of one step over all ranks (every rank holds the whole table now)
     n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if world > 1 else int(n_last)
-    phase_ms /= max(args.steps, 1)
+    phase_ms = stage_log[: args.steps, :5].astype(np.float64).sum(axis=0) / max(args.steps, 1)
     if rank != 0:
         return None
 

@@ -1210,6 +1210,52 @@ def test_parts_pipelined_over_lanes_match(lanes, part):
     assert out["loci"] > 500 and (out["retries"] > 0 if part else True), out
 
 
+@pytest.mark.parametrize("part", [0, 700])
+def test_workgroup_order_of_multi_genome_passes_changes_nothing(part):
+    # Passes that hold several genomes run k_l2_events in offset-major, XCD-aware workgroup order (build_frag_order): a
+    # permutation of the work.  Uneven drafts (different fragment counts, short and empty genomes), with and without the pass
+    # cut into parts in the middle of a genome: the rows must equal the query-major run (FA_FRAG_ORDER=0) byte for byte
+    # AND the oracle's hits per genome.
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, os, json, hashlib, warnings
+        sys.path.insert(0, %r)
+        import numpy as np
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        from oracle.oracle import OracleSketch
+        g = syn.rng(777)
+        genomes = []
+        for fam in range(3):
+            anc = syn.random_codes(g, 260_000 + 90_000 * fam)
+            for d in (0.0, 0.02, 0.06, 0.12):
+                genomes.append(syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, d)), 4 + fam))
+        genomes.insert(5, [b"ACGT" * 3]); genomes.insert(9, [])
+        sk, osk = pf.Sketch(), OracleSketch()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for i, c in enumerate(genomes):
+                sk.add_draft(i, c); osk.add_draft(i, c)
+            mapper = sk.index(); osk.index()
+            batch = mapper.upload_genomes(genomes)
+            rows = batch.query_rows(0, len(genomes))
+            hits = [[(h.name, h.identity, h.matches, h.fragments) for h in hs] for hs in batch.query()]
+            want = [osk.query_draft(c, threads=8) for c in genomes]
+        assert hits == want, "hits differ from the oracle"
+        print(json.dumps({"rows": len(rows), "sha": hashlib.sha256(rows.tobytes()).hexdigest()}))
+    """) % (ROOT,)
+    outs = []
+    for order in ("1", "0"):
+        env = dict(os.environ, FA_FRAG_ORDER=order)
+        if part:
+            env.update(FA_PASS_FRAGMENTS=str(part))
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+        outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] and outs[0]["rows"] > 40, outs
+
+
 def test_stage_times_by_stamps_agree_with_hip_events():
     # the stage times of a pass come from device stamps of the 100 MHz counter (fa_mapper_last_timings [0..4]); on request
     # the L2 stage is bracketed by two HIP events on the library's stream as well ([16]): the two clocks must agree
