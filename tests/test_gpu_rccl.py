@@ -73,6 +73,19 @@ def test_bench_strong_two_ranks_sharing_one_gpu(strong_n1):
     assert line["config"]["table_sha256"] == strong_n1["config"]["table_sha256"]
 
 
+def test_bench_weak_two_ranks_sharing_one_gpu():
+    """The default (weak-scaled) mode at N = 2 -- what the driver launches for its scaling curve -- with both ranks on GPU 0 over
+    gloo: every rank maps its own query against the cooperatively built index, the hit tables of all steps are exchanged by
+    one all-gather at the end of the timed region, and the line carries the whole-job rate."""
+    args = ["--gpus", "2", "--refs", "6", "--length", "400000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    res = _run_ranks([os.path.join(ROOT, "bench.py")] + args, 2, env={"FA_BENCH_SHARE_GPU": "1"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
+    assert line["config"]["pairs_per_step_per_gpu"] == 6 and "sharded sketching x2" in line["config"]["index_build"]
+    assert line["config"]["hits_per_step"] >= 4 and "saturated" not in line and line["phases_ms"]["l2_ms"] > 0
+
+
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")
 def test_bench_strong_rccl_two_gpus():
     res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "2"] + STRONG_SMALL, 2)
