@@ -678,7 +678,9 @@ static void ensure_luts(fa_mapper &m, int smax) {
 
 // seed hits of one fragment sorted in LDS by k_l1 (4 bytes each); more go through HBM scratch
 static uint32_t lds_seed_cap_max(int smax) {
-  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 5 * 4 - ((int64_t)smax + 2) * 8 - 32;
+  // (the dynamic request of k_l1 -- l1_lds_bytes: seeds, list offsets and sources, six staged locus arrays -- plus its static
+  // LDS, a few hundred bytes, must stay within the 160 KB of a CU)
+  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 6 * 4 - ((int64_t)smax + 2) * 8 - 64;
   return (uint32_t)std::max<int64_t>(256, room / 4 / 256 * 256);
 }
 
@@ -997,7 +999,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       auto go = [&](auto nt_tag) {
         constexpr int NTT = decltype(nt_tag)::value;
         const size_t lds = l1_lds_bytes(seed_slots, smax);
-        FA_REQUIRE(lds <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS tables of the L1 kernel");
+        FA_REQUIRE(lds + 1024 <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS tables of the L1 kernel");
         static const bool dbg = getenv("FA_DEBUG_L1") != nullptr;
         if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);
         if (seed_slots <= 16 * (uint32_t)NTT) {
@@ -1214,7 +1216,9 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     };
     if (total_seeds >= (1ULL << 31)) { shrink_part((double)total_seeds, 2147483648.0, "seed hits"); publish_spec(sp); return false; }
     // bounds for the next pass (or the repeat of this one)
-    if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 16 + 31) / 32 * 32;
+    // (a multiple of 8 just above the largest sketch seen: every slot of the bound costs k_l2_scan 64 bytes of LDS per wave,
+    // and on the bench workload -- largest sketch 263 -- 272 slots let nine of its workgroups share a CU where 288 let eight)
+    if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 4 + 7) / 8 * 8;
     // LDS slots for the seed sort: a quarter of headroom over the largest fragment seen, (LDS per workgroup sets how many fragments a CU works on at once)
     uint32_t want_slots = std::min<uint32_t>(lds_seed_cap_max(sp.smax), std::max<uint32_t>(1024, (uint32_t)((std::min<uint64_t>(max_seeds + max_seeds / 4, 1u << 30) + 255) / 256 * 256)));
     const bool slots_changed = want_slots != sp.seed_slots;
