@@ -28,7 +28,10 @@ namespace fa {
 
 
 constexpr int MAP_THREADS = 256;
-constexpr int L1_STAGE = 256;     // loci of one fragment merged in LDS by k_l1 (more fall back to a second pass)
+// loci of one fragment merged in LDS by k_l1 (more fall back to a second pass that writes them to HBM).  128, not 256: with
+// 3 KB of stage instead of 6 the kernel's 21.7 KB let seven workgroups share a CU, i.e. the 1666 fragments of a 5 Mb query run
+// in ONE resident round (85 -> 81 us; 928 -> 872 us at 16 queries per launch); a fragment has one locus per related contig
+constexpr int L1_STAGE = 128;
 constexpr uint32_t SEED_PAD = 0xFFFFFFFFu;
 
 // ----------------------------------------------------------------------------------------------------------
