@@ -1,5 +1,5 @@
-"""Fills the @PLACEHOLDER@ fields of DESIGN.md section 6.3 / 6.4 from the head-of-round records under profiles/:
-   python3 scripts/dev/fill_design.py   (idempotent once the placeholders are gone)"""
+"""Regenerates DESIGN.md sections 6.3 / 6.4 from scripts/dev/design_6_3_template.md and the head-of-round records under
+profiles/ (bench line, kernel stats, K1 rates):   python3 scripts/dev/fill_design.py"""
 import csv, json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = os.path.join(ROOT, "profiles")
@@ -40,8 +40,13 @@ vals = {
     "SC_US": f"{pick(s1, 'k_l2_scan<unsigned short, unsigned char, 64>'):.0f}", "SC_16": f"{pick(s16, 'k_l2_scan<unsigned short, unsigned char, 64>') / 16:.0f} µs",
     "CGI_US": f"{pick(s1, 'k_cgi_bins') + pick(s1, 'k_cgi_rows'):.0f}", "CGI_16": f"{(pick(s16, 'k_cgi_bins') + pick(s16, 'k_cgi_rows')) / 16:.0f} µs",
 }
+vals["EV_TBS"] = f"{0.80e9 / (pick(s1, 'k_l2_events') * 1e-6) / 1e12:.1f}"
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
+# sections 6.3 and 6.4 are regenerated from the template every time
+tpl = open(os.path.join(ROOT, "scripts", "dev", "design_6_3_template.md")).read()
+i, j = s.index("### 6.3 Current numbers"), s.index("### 6.5 Where the next gains are")
+s = s[:i] + tpl + s[j:]
 for key, v in vals.items():
     s = s.replace(f"@{key}@", v)
 left = re.findall(r"@[A-Z0-9_]+@", s)
