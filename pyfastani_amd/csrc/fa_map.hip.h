@@ -1199,6 +1199,7 @@ constexpr int EV_PROBE = 4;                // sketch entries compared at once pe
 #define FA_EV_RPL 4
 #endif
 constexpr int EV_RPL = FA_EV_RPL;          // records per lane and trip of k_l2_events
+static_assert(EV_RPL >= 1 && EV_RPL <= 4, "the last trip of a phase is dispatched on 1..4 records per lane");
 __host__ __device__ inline size_t ev_sketch_bytes(int cnt_slots) { return ((size_t)(cnt_slots - 1 + EV_PROBE) * 4 + 15) / 16 * 16; }   // + sentinels
 
 template <typename T, bool PACKED>
@@ -1313,9 +1314,12 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   struct Trip { uint32_t h[EV_RPL], geo[EV_RPL], pd[EV_RPL]; int32_t pv[EV_RPL], bw[EV_RPL], fw[EV_RPL]; uint8_t rf[EV_RPL]; };
   // the HBM reads of a trip, issued together (unconditionally, from a clamped index: a predicated load would wait for
   // the one before it)
-  auto issue = [&](Trip &t, bool first, int t0, int hi) __attribute__((always_inline)) {
+  // (R = records per lane of this trip: EV_RPL, or fewer in the last trip of a phase -- its instructions are paid per
+  // record slot, filled or not)
+  auto issue = [&](auto rpl_tag, Trip &t, bool first, int t0, int hi) __attribute__((always_inline)) {
+    constexpr int R = decltype(rpl_tag)::value;
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) {
+    for (int u = 0; u < R; u++) {
       const int ic = min(t0 + lane + 64 * u, hi - 1);
       if (PACKED) {
         // (a uniform base -- the first record of the trip -- plus a 32-bit byte offset: the load takes both as they are,
@@ -1327,7 +1331,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     }
     if (first) {                                                     // (uniform)
 #pragma unroll
-      for (int u = 0; u < EV_RPL; u++) {
+      for (int u = 0; u < R; u++) {
         const int ic = min(t0 + lane + 64 * u, hi - 1);
         if (PACKED) t.pd[u] = (uint32_t)a.ix.rec_prev16[ic]; else t.pv[u] = a.ix.rec_prev[ic];
       }
@@ -1337,8 +1341,9 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   T *const out_lds = (T *)(lds + ev_sketch_bytes(a.cnt_slots)) + (size_t)wv * a.ev_stage;
   const uint32_t obase = (uint32_t)(uintptr_t)(lds_out_t)out_lds;
   // the events of the records [t0, hi) of one trip; FIRST = records of the first super-window
-  auto work = [&](auto first_tag, auto store, const Trip &t, const Locus &p, int t0, int hi) __attribute__((always_inline)) {
+  auto work = [&](auto rpl_tag, auto first_tag, auto store, const Trip &t, const Locus &p, int t0, int hi) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value;
+    constexpr int R = decltype(rpl_tag)::value;
     const int beg = p.beg, end0 = p.end0, ndrop = p.ndrop;
     const int n_init_pad = (end0 - beg + 7) & ~7;
     // rank of a reference hash among the query hashes and whether it is one of them: the bucket's first rank, then
@@ -1348,28 +1353,28 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     // (membership is read off the entry AT the final rank -- the sketch is sorted and distinct, so that entry is the first
     // one >= the hash: one more LDS read instead of four equality tests whose results, kept as booleans across the walk,
     // the compiler packed into bytes at ten instructions per record)
-    int x[EV_RPL]; uint32_t q[EV_RPL][EV_PROBE], qx[EV_RPL]; bool found[EV_RPL], more = false;
+    int x[R]; uint32_t q[R][EV_PROBE], qx[R]; bool found[R], more = false;
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) x[u] = QT[min(t.h[u] >> qshift, (uint32_t)(1 << QT_BITS))];   // the last bucket is [2^bits, inf): rank s
+    for (int u = 0; u < R; u++) x[u] = QT[min(t.h[u] >> qshift, (uint32_t)(1 << QT_BITS))];   // the last bucket is [2^bits, inf): rank s
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) {
+    for (int u = 0; u < R; u++) {
 #pragma unroll
       for (int j = 0; j < EV_PROBE; j++) q[u][j] = Q[x[u] + j];
     }
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) {
+    for (int u = 0; u < R; u++) {
 #pragma unroll
       for (int j = 0; j < EV_PROBE; j++) x[u] += q[u][j] < t.h[u] ? 1 : 0;     // (a compare and an add-with-carry per entry)
       more = more || q[u][EV_PROBE - 1] < t.h[u];
     }
     if (__builtin_amdgcn_ballot_w64(more)) {
 #pragma unroll
-      for (int u = 0; u < EV_RPL; u++) if (q[u][EV_PROBE - 1] < t.h[u]) { while (Q[x[u]] < t.h[u]) x[u]++; }
+      for (int u = 0; u < R; u++) if (q[u][EV_PROBE - 1] < t.h[u]) { while (Q[x[u]] < t.h[u]) x[u]++; }
     }
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) qx[u] = Q[x[u]];
+    for (int u = 0; u < R; u++) qx[u] = Q[x[u]];
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) found[u] = qx[u] == t.h[u];
+    for (int u = 0; u < R; u++) found[u] = qx[u] == t.h[u];
     if constexpr (PACKED) {
       // Bit arithmetic instead of compare + select: this kernel runs seven waves per SIMD and IS its vector issue slots
       // (profiles/r03_valu_model.json), where v_and / v_or / v_add / v_sub / v_lshrrev cost 2.3 cycles and v_cmp, v_cndmask,
@@ -1380,7 +1385,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
       // unit = 1 << EV_DM for a hash of the query sketch, 1 << EV_DW otherwise (the two-bit field then holds +1 resp. -1).
       const int c2 = n_init_pad - end0 - beg + 2 * (t0 + lane);
 #pragma unroll
-      for (int u = 0; u < EV_RPL; u++) {
+      for (int u = 0; u < R; u++) {
         const int i = t0 + lane + 64 * u;
         if (i >= hi) continue;
         const uint32_t geo = t.geo[u], ng = ~geo;
@@ -1403,7 +1408,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
       return;
     }
 #pragma unroll
-    for (int u = 0; u < EV_RPL; u++) {
+    for (int u = 0; u < R; u++) {
       const int i = t0 + lane + 64 * u;
       if (i >= hi) continue;
       uint32_t flags; bool prev_in; int32_t bwd, fwd1;
@@ -1465,8 +1470,23 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     const Stream st = begin_locus(cur, l);
     auto run = [&](auto store) __attribute__((always_inline)) {
       Trip t;
-      for (int t0 = cur.beg; t0 < cur.end0; t0 += 64 * EV_RPL) { issue(t, true, t0, cur.end0); work(std::true_type(), store, t, cur, t0, cur.end0); }
-      for (int t0 = cur.end0; t0 < cur.last; t0 += 64 * EV_RPL) { issue(t, false, t0, cur.last); work(std::false_type(), store, t, cur, t0, cur.last); }
+      // whole trips of EV_RPL records per lane, then ONE trip sized for what is left of the phase (a 630-record locus is 240
+      // + 390: trips of 256 filled 82 % of their record slots, this fills 94 %)
+      auto phase = [&](auto first_tag, int lo, int hi) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        int t0 = lo;
+        for (; t0 + 64 * EV_RPL <= hi; t0 += 64 * EV_RPL) {
+          issue(std::integral_constant<int, EV_RPL>(), t, FIRST, t0, hi); work(std::integral_constant<int, EV_RPL>(), first_tag, store, t, cur, t0, hi);
+        }
+        const int rem = hi - t0;                                       // (uniform)
+        auto tail = [&](auto rpl_tag) __attribute__((always_inline)) { issue(rpl_tag, t, FIRST, t0, hi); work(rpl_tag, first_tag, store, t, cur, t0, hi); };
+        if (rem > 64 * 3) tail(std::integral_constant<int, (EV_RPL >= 4 ? 4 : EV_RPL)>());
+        else if (rem > 64 * 2) tail(std::integral_constant<int, (EV_RPL >= 3 ? 3 : EV_RPL)>());
+        else if (rem > 64) tail(std::integral_constant<int, (EV_RPL >= 2 ? 2 : EV_RPL)>());
+        else if (rem > 0) tail(std::integral_constant<int, 1>());
+      };
+      phase(std::true_type(), cur.beg, cur.end0);
+      phase(std::false_type(), cur.end0, cur.last);
     };
     if (st.staged) run([&](uint32_t pos, uint32_t v) __attribute__((always_inline)) { *(lds_out_t)(uintptr_t)(obase + pos * (uint32_t)sizeof(T)) = (T)v; });
     else { T *gout = st.gout; run([&](uint32_t pos, uint32_t v) __attribute__((always_inline)) { gout[pos] = (T)v; }); }
