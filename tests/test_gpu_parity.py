@@ -1293,3 +1293,26 @@ def test_device_memory_is_stable():
     assert res.returncode == 0, res.stdout + res.stderr
     out = json.loads(res.stdout.strip().splitlines()[-1])
     assert out["after_600_queries_mb"] <= 1.0 and out["after_50_batches_mb"] <= 1.0 and out["after_20_mappers_mb"] <= 16.0, out
+
+
+@pytest.mark.parametrize("params,env", [
+    ({}, {"FA_NO_PACKED_GEO": "1"}),                       # default cell, 16-bit events, record geometry from the plain arrays
+    ({"fragment_length": 9000}, {}),                       # cmw + 1 >= 2^13: no packed geometry; sketches beyond 510: 32-bit events
+    ({"fragment_length": 20_000, "k": 14}, {}),
+])
+def test_unpacked_record_geometry(params, env, monkeypatch):
+    # k_l2_events<T, false>: the form every index takes whose fragment length leaves no room for the 13-bit distances of
+    # rec_hg (fa_engine.hip, packed_geo), and FA_NO_PACKED_GEO forces on any index
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    g = syn.rng(133)
+    anc = syn.random_codes(g, 400_000)
+    refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.01, 0.05, 0.12)]
+    inv = syn.mutate_codes(g, anc, 0.03)
+    refs.append([syn.to_ascii(np.concatenate([inv[:150_000], syn.reverse_complement_codes(inv[150_000:300_000]), inv[300_000:]]))])
+    refs.append([syn.to_ascii(syn.random_codes(g, 200_000))])
+    query = syn.split_contigs(g, syn.to_ascii(syn.mutate_codes(g, anc, 0.04)), 3)
+    mapper, hits, ohits, det = run_both(params, refs, query, threads=4)
+    assert len(ohits) >= 3
+    assert gpu_mappings(mapper) == oracle_mappings(det)
+    assert hit_tuples(hits) == ohits
