@@ -680,7 +680,7 @@ static void ensure_luts(fa_mapper &m, int smax) {
 static uint32_t lds_seed_cap_max(int smax) {
   // (the dynamic request of k_l1 -- l1_lds_bytes: seeds, list offsets and sources, six staged locus arrays -- plus its static
   // LDS, a few hundred bytes, must stay within the 160 KB of a CU)
-  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 6 * 4 - ((int64_t)smax + 2) * 8 - 64;
+  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 6 * 4 - std::max<int64_t>(((int64_t)smax + 2) * 8, 1024 * 8) - 64;
   return (uint32_t)std::max<int64_t>(256, room / 4 / 256 * 256);
 }
 
@@ -998,7 +998,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       // LDS round trips; 1024 threads pay more for barriers than they gain)
       auto go = [&](auto nt_tag) {
         constexpr int NTT = decltype(nt_tag)::value;
-        const size_t lds = l1_lds_bytes(seed_slots, smax);
+        const size_t lds = l1_lds_bytes(seed_slots, smax, l1_nt);
         FA_REQUIRE(lds + 1024 <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS tables of the L1 kernel");
         static const bool dbg = getenv("FA_DEBUG_L1") != nullptr;
         if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);

@@ -500,11 +500,13 @@ struct L1Args {
 // of L1_STAGE)
 constexpr int L1_INPLACE_MAX = 32;  // most seeds per thread the in-place merge keeps in registers (template parameter E: 16 or 32)
 __host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 4 + 15) / 16 * 16; }
-__host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax) {
-  return (l1_off_offset(seed_cap) + ((size_t)lut_smax + 2) * 8 + 15) / 16 * 16;   // list offsets + list sources
+// (nt = threads of the workgroup: once the lists are merged the same bytes hold (contig, window) of a trip's seeds by thread)
+__host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax, int nt) {
+  const size_t lists = ((size_t)lut_smax + 2) * 8, trip = (size_t)nt * 8;            // list offsets + list sources
+  return (l1_off_offset(seed_cap) + (lists > trip ? lists : trip) + 15) / 16 * 16;
 }
-__host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax) {
-  return l1_stage_offset(seed_cap, lut_smax) + (size_t)L1_STAGE * 6 * 4;
+__host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int nt) {
+  return l1_stage_offset(seed_cap, lut_smax, nt) + (size_t)L1_STAGE * 6 * 4;
 }
 
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
@@ -671,11 +673,12 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
 
   // ---- ordered passes over the candidates.  Pass 0 merges them into loci held in LDS (up to L1_STAGE per fragment) and
   //      is normally the only one; if a fragment has more loci, pass 0 only counted and pass 1 writes them to HBM. ----
-  int32_t *st_seq = (int32_t *)(lds + l1_stage_offset(a.lds_seed_cap, a.lut_smax));   // [L1_STAGE] each
+  int32_t *st_seq = (int32_t *)(lds + l1_stage_offset(a.lds_seed_cap, a.lut_smax, NT));   // [L1_STAGE] each
   int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
   int32_t *st_rpart = st_rlast + L1_STAGE;
   for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
   bool staged = true;
+  int2 *sw_trip = (int2 *)(lds + l1_off_offset(a.lds_seed_cap));        // [NT] (the list offsets are no longer needed)
   for (int pass = 0; pass < 2; pass++) {
     if (tid == 0) { sh_heads[0] = 0; sh_has_prev[0] = 0; sh_prev_seq[0] = -1; sh_prev_wa[0] = 0; }
     __syncthreads();
@@ -687,24 +690,29 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       uint32_t i = i0 + tid;
       bool flag = false;
       int start = 0;
-      // every lane fetches (contig, window) of its own seed once; the partner seed i+m-1 comes from a neighbour lane
+      // every lane fetches (contig, window) of its own seed once and leaves them in LDS for its wave: the partner seed
+      // i+m-1 and the previous flagged candidate are other lanes' seeds (an 8-byte LDS read each where a `__shfl` -- a
+      // ds_bpermute, ~18 cycles of the CU's LDS pipe -- per word cost a fifth of this kernel)
       const uint32_t ra = ra_n;
       const int seq = sw_n.x, wa = sw_n.y;
+      sw_trip[tid] = make_int2(seq, wa);
       if (i0 + NT < ncand) {
         const uint32_t in = i + NT;
         ra_n = in < n ? seeds[in] : 0u;
         sw_n = in < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
       }
-      int seqb = __shfl(seq, (lane + m - 1) & 63), wb = __shfl(wa, (lane + m - 1) & 63);
-      int rb = __shfl((int)ra, (lane + m - 1) & 63);                     // record of the partner seed: it fixes the locus start
-      if (lane + m - 1 >= 64 && i < ncand) { rb = (int)seeds[i + m - 1]; const int2 swb = a.ix.rec_sw[rb]; seqb = swb.x; wb = swb.y; }
+      const int rb = i < ncand ? (int)seeds[i + m - 1] : 0;               // record of the partner seed: it fixes the locus start
+      int2 swb = sw_trip[min(tid + m - 1, NT - 1)];                        // (read by its own wave only: LDS keeps a wave's order)
+      if (lane + m - 1 >= 64 && i < ncand) swb = a.ix.rec_sw[rb];
+      const int seqb = swb.x, wb = swb.y;
       if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
       __shared__ int w_last_seq[2][NT / 64], w_last_wa[2][NT / 64], w_any[2][NT / 64];
       uint64_t below = bal & ((1ULL << lane) - 1ULL);
       int src_lane = below ? 63 - __clzll(below) : -1;
-      int p_seq = __shfl(seq, src_lane < 0 ? 0 : src_lane), p_wa = __shfl(wa, src_lane < 0 ? 0 : src_lane);
+      const int2 swp = sw_trip[(tid & ~63) + max(src_lane, 0)];
+      int p_seq = swp.x, p_wa = swp.y;
       if (lane == 0) w_any[par][wv] = bal != 0;
       if (bal && lane == 63 - __clzll(bal)) { w_last_seq[par][wv] = seq; w_last_wa[par][wv] = wa; }
       __syncthreads();
