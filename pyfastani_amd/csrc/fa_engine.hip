@@ -122,11 +122,15 @@ struct StageTrace {
 // `clear` (a query pass): ranges zeroed by extra workgroups of the first launch, beside the hashing
 static uint64_t env_u64(const char *name, uint64_t dflt);
 static uint64_t exp_u64(const char *name, uint64_t dflt);     // the same in builds with -DFA_EXPERIMENTS, else `dflt`
-static void launch_sketch_tiles(const fa_params &P, const StoreView &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
-                                int32_t *stage_wpos, int32_t *tile_count, hipStream_t st, const ClearArgs *clear = nullptr) {
+
+// `fuse` (a query pass, F fragments): K1 and the per-fragment sketch in one launch (k_query_fused) where the pass qualifies
+// -- returns true then, and the caller skips k_query_sketch
+static bool launch_sketch_tiles(const fa_params &P, const StoreView &store, const Tile *d_tiles, int ntiles, uint32_t *stage_hash,
+                                int32_t *stage_wpos, int32_t *tile_count, hipStream_t st, const ClearArgs *clear = nullptr,
+                                const QuerySketchArgs *fuse = nullptr, int64_t F = 0) {
   if (ntiles <= 0) {
     if (clear && clear->count) hipLaunchKernelGGL(k_clear, dim3(256), dim3(256), 0, st, *clear);
-    return;
+    return false;
   }
   SketchArgs a;
   a.ntiles = ntiles;
@@ -160,6 +164,18 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   if (!a.protein && !k1_general && P.window_size >= SKF_MIN_W && P.window_size <= SKF_MAX_W) {
     // the hot form (fa_sketch_fast.hip.h): 13 KB of LDS, eight workgroups per CU; k = 14 / 16 / 21 hash from the premix tables
     const size_t flds = skf_layout(P.kmer_size, P.window_size).total;
+    // fused with the per-fragment sketch: no other bytes anywhere in the batch (their tiles go through k_sketch_tiles<0, true>
+    // and the staging arrays), and fragments whose records fit QF_CAP with room to spare (a denser one voids the pass)
+    static const bool fuse_on = !(getenv("FA_QUERY_FUSED") && atoi(getenv("FA_QUERY_FUSED")) == 0);
+    // (the default cell only, k = 16 / w = 24: its instantiation fits the registers of seven waves per SIMD; the run-time-w
+    // and k = 14 / 21 forms spill a few words to scratch memory, which the runtime then keeps per stream for good)
+    if (fuse && fuse_on && store.n_exc == 0 && P.kmer_size == 16 && P.window_size == 24 &&
+        (int64_t)5 * P.fragment_length / (P.window_size + 1) <= QF_CAP) {
+      const size_t qlds = flds + (size_t)QF_CAP * 4;
+      hipLaunchKernelGGL((k_query_fused<16, 24>), dim3((unsigned)F + extra), dim3(SK_THREADS), qlds + lds_pad, st, a, *fuse, (int)F);
+      FA_HIP(hipGetLastError());
+      return true;
+    }
     auto launch_fast = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), flds + lds_pad, st, a);
       extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;
@@ -172,6 +188,7 @@ static void launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   } else if (!a.protein) { if (P.kmer_size == 16) launch(k_sketch_tiles<16, false>); else launch(k_sketch_tiles<0, false>); }
   if (a.protein || store.n_exc > 0) launch(k_sketch_tiles<0, true>);
   FA_HIP(hipGetLastError());
+  return false;
 }
 
 // rocPRIM directly (device-wide scan / radix sort / run-length encode; sizes are size_t)
@@ -464,6 +481,7 @@ struct fa_mapper {
     int64_t l_cap = 0;
     int64_t part_frags = 0;   // fragments per part of a pass (shrinks when a part overflows the 32-bit workspace)
     bool redo = false;        // launch the wide-state scan as well (set once a locus overflowed the one-byte state)
+    bool fuse_off = false;    // k_query_fused met a fragment with more records than its LDS holds: K1 and k_query_sketch apart
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
   // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
@@ -806,6 +824,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ms.l_cap = std::max(ms.l_cap, sp.l_cap);
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
+    ms.fuse_off = ms.fuse_off || sp.fuse_off;
   };
   fetch_spec();
   // event offsets are 32-bit: at most this many slide events per part (FA_EVENTS_CAP_MAX: the tests force the split)
@@ -947,19 +966,22 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       cl.add(ln.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(ln.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(ln.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
       if (!bins_cleared) { cl.add(w.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long)); bins_cleared = true; }
-      // ---- K1 (its extra workgroups zero the ranges above beside the hashing) + per-fragment sort/unique ----
-      launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st, &cl.a);
-    }
-    {
       QuerySketchArgs a;
       a.frag_tile_lo = g.d_frag_tile_lo + f0;
       a.tile_count = ln.sk.tile_count.p; a.stage_hash = ln.sk.stage_hash.p; a.stage_wpos = ln.sk.stage_wpos.p;
       a.tile_base = t0;                              // frag_tile_lo holds batch-wide tile numbers
-      a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.stats = d_stats; a.qcap = qcap;
+      a.q_hash = ln.q_hash.p; a.q_size = ln.q_size.p; a.qcap = qcap;
       a.ix = ix; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p; a.n_seeds = ln.n_seeds.p;
       a.sort_cap = (int32_t)(qs_lds / 4);
-      if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
-      hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
+      a.rec_cap = getenv("FA_QF_CAP") ? std::max(0, std::min(QF_CAP, atoi(getenv("FA_QF_CAP")))) : QF_CAP;
+      // ---- K1 (its extra workgroups zero the ranges above beside the hashing) + per-fragment sort / unique / index lookup:
+      //      one launch where the pass qualifies (k_query_fused), else k_sketch_fast / k_sketch_tiles, then k_query_sketch ----
+      const bool fused = launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st, &cl.a,
+                                             sp.fuse_off ? nullptr : &a, F);
+      if (!fused) {
+        if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
+        hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
+      }
     }
     debug_sync(st, "sketch");
     // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch).  A kernel of its own
@@ -967,7 +989,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const bool fold_totals = sp.scratch_words == 0;
     if (!fold_totals)
       hipLaunchKernelGGL(k_seed_totals, dim3(1), dim3(1024), 0, st, ln.n_seeds.p, F, seed_slots, d_totals, ln.ovf_off.p,
-                         d_stats, smax, sp.scratch_words, d_pinfo, &ln.status.p->stamp[1]);
+                         d_stats, smax, sp.scratch_words, d_pinfo, &ln.status.p->stamp[1], ln.q_size.p);
     debug_sync(st, "lookup");
     // ---- L1 ----
     {
@@ -1229,6 +1251,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); publish_spec(sp); return false; }
       sp.l_cap = std::min(want, l_max);
     }
+    if (flags & SPEC_QFUSE) sp.fuse_off = true;
     if (flags & SPEC_EVENTS) {
       // every region has to hold its share: size the arena for the fullest one (the fused form reserves from one counter)
       const uint64_t need = std::max<uint64_t>(h_pinfo[0], ev_region_max * ev_regions_for(F));

@@ -22,6 +22,7 @@
 
 #include "fa_common.h"
 #include "fa_sketch.hip.h"
+#include "fa_sketch_fast.hip.h"
 
 namespace fa {
 
@@ -243,7 +244,6 @@ struct QuerySketchArgs {
   const int32_t *stage_wpos;
   uint32_t *q_hash;             // [F * qcap]
   int32_t *q_size;              // [F]
-  int32_t *stats;               // [0] max sketch size
   int32_t qcap;
   int32_t sort_cap;             // power of two >= max records of a fragment
   int32_t tile_base;            // first tile of this pass (staging is indexed pass-locally)
@@ -252,13 +252,14 @@ struct QuerySketchArgs {
   uint32_t *q_off;              // [F*qcap] start of the list in pos_ridx
   uint32_t *q_cnt;              // [F*qcap] list length (0 when absent or too frequent)
   uint32_t *n_seeds;            // [F]
+  int32_t rec_cap;              // k_query_fused: most records of a fragment it accepts (<= QF_CAP; FA_QF_CAP lowers it for the tests)
 };
 
 constexpr int QS_TILES = 16;      // tiles of a fragment whose counts k_query_sketch fetches in one go
+__device__ __forceinline__ void query_sketch_tail(const QuerySketchArgs &a, int f, uint32_t *buf, int n, uint32_t h0_in, int wpos0);
 __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a) {
   extern __shared__ __align__(16) unsigned char lds[];
   uint32_t *buf = (uint32_t *)lds;                 // [sort_cap]
-  __shared__ int sh_drop, sh_total;
   __shared__ uint32_t sh_h0;
   __shared__ int sh_wpos0;
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -287,11 +288,20 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
       n += c;
     }
   }
+  __syncthreads();
+  query_sketch_tail(a, f, buf, n, sh_h0, sh_wpos0);
+}
+
+// The records of a fragment, in position order in buf[0 .. n): the leading-run rule, sort by hash, unique, index lookup.
+// (All threads of the workgroup; h0 / wpos0 = hash and window of record 0, ignored when n == 0.)
+__device__ __forceinline__ void query_sketch_tail(const QuerySketchArgs &a, int f, uint32_t *buf, int n, uint32_t h0_in, int wpos0) {
+  const int tid = threadIdx.x;
+  __shared__ int sh_drop, sh_total;
   if (tid == 0) { sh_drop = n; }
   __syncthreads();
   // leading run: records 1..d equal to record 0's hash are dropped when record 0 sits at window 0
-  if (n > 1 && sh_wpos0 == 0) {
-    uint32_t h0 = sh_h0;
+  if (n > 1 && wpos0 == 0) {
+    uint32_t h0 = h0_in;
     int first_diff = n;
     for (int i = 1 + tid; i < n; i += blockDim.x) if (buf[i] != h0) { first_diff = i; break; }
     atomicMin(&sh_drop, first_diff);
@@ -361,12 +371,7 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
     if (tid == 0) { int tot = 0; for (int q = 0; q < MAP_THREADS / 64; q++) tot += wave_cnt[q]; sh_total += tot; }
     __syncthreads();
   }
-  if (tid == 0) {
-    a.q_size[f] = sh_total;
-    // ~1700 workgroups updating one address serialise in L2 (that alone was most of this kernel's time): the maximum
-    // only ever grows, so a plain read filters out nearly all of them
-    if (sh_total > *(volatile int32_t *)&a.stats[0]) atomicMax(&a.stats[0], sh_total);
-  }
+  if (tid == 0) a.q_size[f] = sh_total;                             // (the largest of the pass is taken by seed_totals)
   // ---- lookup: one 16-byte table probe per distinct minimizer (unordered_map::find), strict `< freqThreshold` ----
   __syncthreads();                                                  // (the hashes this workgroup wrote to `out`)
   const int s = sh_total;
@@ -396,28 +401,98 @@ __global__ __launch_bounds__(MAP_THREADS) void k_query_sketch(QuerySketchArgs a)
 // passes needed (largest sketch, LDS seed slots, HBM seed scratch, loci and event capacities).  Kernels check those
 // bounds on the device, skip the work that does not fit and raise a flag; the host reads the flags once at the end of
 // the pass and, if any is set, grows the bounds and runs the pass again.
-constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS = 8;
+constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS = 8, SPEC_QFUSE = 16;
+
+// ----------------------------------------------------------------------------------------------------------
+// K1 and the per-fragment sketch in ONE launch (query passes over plain-ACGT genomes, 4 <= w <= 64): workgroup f hashes
+// the tiles of fragment f one after the other (skf_tile, fa_sketch_fast.hip.h), collects their records in LDS instead
+// of the staging arrays, and goes on with query_sketch_tail.  On one 5 Mb query this is one resident round of 1666
+// workgroups where k_sketch_fast (2.4 rounds of 4998 tile workgroups) + k_query_sketch (a round of latency chains) were
+// two launches.  A fragment with more than QF_CAP records (low-complexity sequence under a small window) is marked
+// (q_size = -1, SPEC_QFUSE via seed_totals): the pass is void and runs again through the two kernels.  The workgroups
+// write nothing into the status block -- the zeroing workgroups of this very launch are clearing it.
+// ----------------------------------------------------------------------------------------------------------
+constexpr int QF_CAP = 1024;        // records of one fragment held in LDS (a power of two: the bitonic fallback sorts in place)
+template <int KT, int WT>
+__global__ __launch_bounds__(SK_THREADS, 7) void k_query_fused(SketchArgs a, QuerySketchArgs q, int F) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  static_assert(SK_THREADS == MAP_THREADS, "one workgroup runs both halves");
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= F) {                                         // the zeroing workgroups of the pass (as in k_sketch_fast)
+    if (a.clear.stamp && blockIdx.x == (uint32_t)F && tid == 0) a.clear.stamp[3] = 0;
+    clear_ranges(a.clear, blockIdx.x - (uint32_t)F, gridDim.x - (uint32_t)F);
+    return;
+  }
+  if (a.clear.stamp && blockIdx.x == 0 && tid == 0) a.clear.stamp[0] = __builtin_amdgcn_s_memrealtime();   // start of the pass
+  constexpr bool TABLES = KT == 14 || KT == 16 || KT == 21;
+  const int f = blockIdx.x;
+  const int t0 = q.frag_tile_lo[f] - q.tile_base, t1 = q.frag_tile_lo[f + 1] - q.tile_base;
+  const SkfLayout L = skf_layout(KT ? KT : a.k, WT ? WT : a.w);
+  // the premix tables go to LDS once per fragment (and again behind a tile that used their bytes: one in ~70 at k = 16)
+  auto put_tables = [&]() __attribute__((always_inline)) {
+    if (TABLES) { const uint4 *src = (const uint4 *)d_premix.v; uint4 *dst = (uint4 *)(lds + L.table_off); dst[tid] = src[tid]; dst[tid + SK_THREADS] = src[tid + SK_THREADS]; }
+  };
+  put_tables();
+  uint32_t *qbuf = (uint32_t *)(lds + L.total);                      // [QF_CAP]
+  __shared__ int sh_count, sh_add, sh_wpos0;
+  if (tid == 0) { sh_count = 0; sh_wpos0 = -1; }
+  __syncthreads();
+  struct Collected {                                                 // the records behind those of the fragment's earlier tiles
+    uint32_t *qbuf; int base; int *add, *wpos0;
+    __device__ __forceinline__ void count(int32_t n) const { *add = n; }
+    __device__ __forceinline__ void emit(uint32_t i, uint32_t hash, int32_t wpos) const {
+      const uint32_t o = (uint32_t)base + i;
+      if (o < (uint32_t)QF_CAP) qbuf[o] = hash;
+      if (o == 0) *wpos0 = wpos;
+    }
+  };
+  const uint4 none = make_uint4(0, 0, 0, 0);
+  for (int t = t0; t < t1; t++) {
+    const Tile tile = a.tiles[t];
+    const bool intact = skf_tile<KT, WT>(a, tile, lds, false, none, none, Collected{qbuf, sh_count, &sh_add, &sh_wpos0});
+    __syncthreads();
+    if (tid == 0) sh_count += sh_add;
+    if (!intact) put_tables();                                       // (uniform: a tile with k-mer-less positions used the tables' bytes)
+    __syncthreads();
+  }
+  const int n = sh_count;
+  if (n > q.rec_cap) {                                               // (uniform) void pass: seed_totals raises SPEC_QFUSE, the host repeats it unfused
+    if (tid == 0) { q.q_size[f] = -1; q.n_seeds[f] = 0; }
+    return;
+  }
+  query_sketch_tail(q, f, qbuf, n, n > 0 ? qbuf[0] : 0u, sh_wpos0);
+}
 
 // totals[0] = sum of seeds, [1] = largest fragment, [2] = HBM scratch words for fragments whose seeds do not fit the
 // LDS slots of k_l1 (their offsets go to ovf_off).  One workgroup: thousands of same-address atomics from k_lookup cost
 // more than this.  Also checks the speculated sketch-size and scratch bounds.
 // (one workgroup of any size: a kernel of its own when k_l1 needs the scratch offsets, else an extra workgroup of k_l1)
+// stats[0] = the largest query sketch of the pass, taken here from q_size (one writer, in a launch behind the one that
+// zeroes the status block: the sketch kernels themselves must not write into that block -- k_query_fused shares its launch
+// with the zeroing workgroups).  q_size[f] < 0 is k_query_fused's "more records than my LDS holds": SPEC_QFUSE.
 __device__ __forceinline__ void seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
-                                            uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
-                                            uint64_t spec_scratch_words, unsigned long long *pinfo) {
+                                            uint32_t *ovf_off, int32_t *stats, int32_t spec_smax,
+                                            uint64_t spec_scratch_words, unsigned long long *pinfo, const int32_t *q_size) {
   __shared__ unsigned long long sh_sum;
   __shared__ unsigned int sh_max, sh_any;
-  if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; }
+  __shared__ int sh_smax, sh_qf;
+  if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; sh_smax = 0; sh_qf = 0; }
   __syncthreads();
   unsigned long long sum = 0;
   unsigned int mx = 0, any = 0;
+  int smx = 0, qf = 0;
   for (int64_t f = threadIdx.x; f < F; f += blockDim.x) {
     const uint32_t n = n_seeds[f];
     sum += n; mx = max(mx, n); any |= n > lds_seed_cap;
     ovf_off[f] = 0;
+    const int s = q_size[f];
+    smx = max(smx, s); qf |= s < 0 ? 1 : 0;
   }
-  for (int d = 32; d > 0; d >>= 1) { sum += __shfl_down(sum, d); mx = max(mx, (unsigned int)__shfl_down((int)mx, d)); any |= (unsigned int)__shfl_down((int)any, d); }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&sh_sum, sum); atomicMax(&sh_max, mx); atomicOr(&sh_any, any); }
+  for (int d = 32; d > 0; d >>= 1) {
+    sum += __shfl_down(sum, d); mx = max(mx, (unsigned int)__shfl_down((int)mx, d)); any |= (unsigned int)__shfl_down((int)any, d);
+    smx = max(smx, __shfl_down(smx, d)); qf |= __shfl_down(qf, d);
+  }
+  if ((threadIdx.x & 63) == 0) { atomicAdd(&sh_sum, sum); atomicMax(&sh_max, mx); atomicOr(&sh_any, any); atomicMax(&sh_smax, smx); atomicOr(&sh_qf, qf); }
   __syncthreads();
   // scratch of the oversized fragments, in fragment order: exclusive prefix sum of their padded sizes
   __shared__ unsigned long long sh_words, sh_wave[16];
@@ -447,16 +522,19 @@ __device__ __forceinline__ void seed_totals(const uint32_t *n_seeds, int64_t F, 
     const unsigned long long words = sh_words;
     totals[2] = words;
     unsigned long long flags = 0;
-    if (stats[0] > spec_smax) flags |= SPEC_SMAX;
+    stats[0] = sh_smax;
+    if (sh_smax > spec_smax) flags |= SPEC_SMAX;
+    if (sh_qf) flags |= SPEC_QFUSE;
     if (words > spec_scratch_words || words >= (1ULL << 32)) flags |= SPEC_SCRATCH;
     if (flags) atomicOr(&pinfo[1], flags);
   }
 }
 __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, int64_t F, uint32_t lds_seed_cap, uint64_t *totals,
-                                                      uint32_t *ovf_off, const int32_t *stats, int32_t spec_smax,
-                                                      uint64_t spec_scratch_words, unsigned long long *pinfo, unsigned long long *stamp) {
+                                                      uint32_t *ovf_off, int32_t *stats, int32_t spec_smax,
+                                                      uint64_t spec_scratch_words, unsigned long long *pinfo, unsigned long long *stamp,
+                                                      const int32_t *q_size) {
   stage_stamp(stamp);                                                // start of the L1 stage
-  seed_totals(n_seeds, F, lds_seed_cap, totals, ovf_off, stats, spec_smax, spec_scratch_words, pinfo);
+  seed_totals(n_seeds, F, lds_seed_cap, totals, ovf_off, stats, spec_smax, spec_scratch_words, pinfo, q_size);
 }
 
 // ----------------------------------------------------------------------------------------------------------
@@ -470,7 +548,7 @@ struct L1Args {
   int32_t fold_totals, spec_smax;
   int64_t F;
   uint64_t *totals;
-  const int32_t *stats;
+  int32_t *stats;
   uint64_t spec_scratch_words;
   unsigned long long *stamp;     // stage_stamp: start of the L1 stage (when the totals are folded in)
   IndexView ix;
@@ -517,7 +595,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   if (a.fold_totals) {
     stage_stamp(a.stamp);
     if ((int64_t)blockIdx.x == a.F) {
-      seed_totals(a.n_seeds, a.F, a.lds_seed_cap, a.totals, a.ovf_off, a.stats, a.spec_smax, a.spec_scratch_words, a.pinfo);
+      seed_totals(a.n_seeds, a.F, a.lds_seed_cap, a.totals, a.ovf_off, a.stats, a.spec_smax, a.spec_scratch_words, a.pinfo, a.q_size);
       return;
     }
   }

@@ -109,23 +109,16 @@ __device__ __forceinline__ bool skf_hash(const uint32_t *codes, int b, int k_rt,
 
 __device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }   // v_min3_u32
 
+// One tile through the hot form.  `sink.emit(i, hash, wpos)` receives the i-th record of the tile (position order, any
+// thread), `sink.count(n)` their number (thread 0).  The premix tables are written to LDS from tv0 / tv1 when
+// `install` is set; a tile with positions that hold no k-mer reuses their bytes (returns false: install them again
+// before the next tile).
 // WT = window size at compile time (0: a.w); KT = k at compile time (0: a.k, hashed without tables)
-template <int KT, int WT>
-__global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
-  extern __shared__ __align__(16) unsigned char lds[];
+template <int KT, int WT, typename Sink>
+__device__ __forceinline__ bool skf_tile(const SketchArgs &a, const Tile &t, unsigned char *lds, bool install, const uint4 &tv0, const uint4 &tv1,
+                                         Sink sink) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= a.ntiles) {                                // not a tile: one of the zeroing workgroups of a query pass
-    if (a.clear.stamp && blockIdx.x == (uint32_t)a.ntiles && tid == 0) a.clear.stamp[3] = 0;   // [3]: CGI stage, if any
-    clear_ranges(a.clear, blockIdx.x - (uint32_t)a.ntiles, gridDim.x - (uint32_t)a.ntiles);
-    return;
-  }
-  if (a.clear.stamp && blockIdx.x == 0 && tid == 0) a.clear.stamp[0] = __builtin_amdgcn_s_memrealtime();   // start of the pass
-  // the premix tables are on their way (constants of the code object, 16 KB away in L2) while the tile descriptor is fetched
   constexpr bool TABLES = KT == 14 || KT == 16 || KT == 21;
-  uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;
-  if (TABLES) { const uint4 *src = (const uint4 *)d_premix.v; tv0 = src[tid]; tv1 = src[tid + SK_THREADS]; }
-  const Tile t = a.tiles[blockIdx.x];
-  if (t.exc_n > 0) return;                                          // a tile with other bytes: k_sketch_tiles<0, true> takes it
   const int k = KT ? KT : a.k, w = WT ? WT : a.w;
   const SkfLayout L = skf_layout(k, w);
   uint32_t *codes = (uint32_t *)lds;
@@ -144,7 +137,7 @@ __global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
   // halo", and FRONT is chosen so that a thread's first read (position hb + 4 tid - w) is 16-byte aligned
   const int FRONT = w + ((4 - (hb & 3)) & 3);
   uint32_t *const Hs = Hst + FRONT;
-  if (TABLES) { uint4 *dst = (uint4 *)tc; dst[tid] = tv0; dst[tid + SK_THREADS] = tv1; }
+  if (TABLES && install) { uint4 *dst = (uint4 *)tc; dst[tid] = tv0; dst[tid + SK_THREADS] = tv1; }
   // ---- 1. stage the 2-bit image ----
   const int64_t w0 = base0 >> 4;
   const int shift = (int)(base0 & 15);
@@ -155,7 +148,6 @@ __global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
   __shared__ int tile_plain;                      // every position holds a k-mer
   if (tid == 0) tile_plain = 1;
   __syncthreads();
-
   // ---- 2. hash both strands, canonical minimum, validity ----
   for (int j0 = 0; j0 < npt; j0 += SK_THREADS) {
     const int j = j0 + tid;
@@ -252,16 +244,43 @@ __global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
   __syncthreads();
   const uint4 tot = *(const uint4 *)wtot;
   const uint32_t wbase = (wave > 0 ? tot.x : 0u) + (wave > 1 ? tot.y : 0u) + (wave > 2 ? tot.z : 0u);
-  if (tid == 0) a.tile_count[blockIdx.x] = (int32_t)(tot.x + tot.y + tot.z + tot.w);
-  const size_t out0 = (size_t)blockIdx.x * TILE + wbase + below;
+  if (tid == 0) sink.count((int32_t)(tot.x + tot.y + tot.z + tot.w));
+  const uint32_t out0 = wbase + below;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (em[j]) {
-      a.stage_hash[out0 + mine] = hsh[j];
-      a.stage_wpos[out0 + mine] = t.pos0 + tt0 + j - w + 1;
+      sink.emit(out0 + mine, hsh[j], t.pos0 + tt0 + j - w + 1);
       mine++;
     }
   }
+  return plain;
+}
+
+template <int KT, int WT>
+__global__ __launch_bounds__(SK_THREADS, 8) void k_sketch_fast(SketchArgs a) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const int tid = threadIdx.x;
+  if ((int)blockIdx.x >= a.ntiles) {                                // not a tile: one of the zeroing workgroups of a query pass
+    if (a.clear.stamp && blockIdx.x == (uint32_t)a.ntiles && tid == 0) a.clear.stamp[3] = 0;   // [3]: CGI stage, if any
+    clear_ranges(a.clear, blockIdx.x - (uint32_t)a.ntiles, gridDim.x - (uint32_t)a.ntiles);
+    return;
+  }
+  if (a.clear.stamp && blockIdx.x == 0 && tid == 0) a.clear.stamp[0] = __builtin_amdgcn_s_memrealtime();   // start of the pass
+  // the premix tables are on their way (constants of the code object, 16 KB away in L2) while the tile descriptor is fetched
+  constexpr bool TABLES = KT == 14 || KT == 16 || KT == 21;
+  uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0;
+  if (TABLES) { const uint4 *src = (const uint4 *)d_premix.v; tv0 = src[tid]; tv1 = src[tid + SK_THREADS]; }
+  const Tile t = a.tiles[blockIdx.x];
+  if (t.exc_n > 0) return;                                          // a tile with other bytes: k_sketch_tiles<0, true> takes it
+  struct Staged {                                                    // the records to the staging arrays of the tile
+    const SketchArgs &a;
+    __device__ __forceinline__ void count(int32_t n) const { a.tile_count[blockIdx.x] = n; }
+    __device__ __forceinline__ void emit(uint32_t i, uint32_t hash, int32_t wpos) const {
+      const size_t o = (size_t)blockIdx.x * TILE + i;
+      a.stage_hash[o] = hash; a.stage_wpos[o] = wpos;
+    }
+  };
+  skf_tile<KT, WT>(a, t, lds, true, tv0, tv1, Staged{a});
 }
 
 }  // namespace fa

@@ -1,6 +1,8 @@
 """Differential fuzzing of the HIP path against the CPU oracle: random genomes with planted repeats, tandem
 duplications, inversions, N runs and low-complexity stretches; random parameters.  Every L2 mapping and every hit must
-match.  Usage: python scripts/fuzz_parity.py [cases] [seed] [seconds]   (stops after `seconds` if given: a time box)"""
+match.  Usage: python scripts/fuzz_parity.py [cases] [seed] [seconds] [default-cell]   (stops after `seconds` if given: a time
+box; a fourth argument keeps every nucleotide case in the default cell k = 16 / fragment 3000 / 80 % with queries of plain
+ACGT -- the cell whose query passes run K1 and the fragment sketch as ONE launch, k_query_fused)"""
 import sys, os, ctypes as C, warnings, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -53,6 +55,7 @@ def to_bytes(g, codes):
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 time_box = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+default_cell = len(sys.argv) > 4
 done = 0
 g = syn.rng(seed)
 bad = 0
@@ -102,6 +105,8 @@ for case in range(cases):
     frag = int(g.choice([200, 500, 1000, 1500, 3000, 3000, 5000]))
     pid = float(g.choice([70, 75, 80, 80, 85, 90, 95]))
     minfrac = float(g.choice([0.0, 0.1, 0.2, 0.5]))
+    if default_cell:
+        k, frag, pid = 16, 3000, 80.0
     params = dict(k=k, fragment_length=frag, percentage_identity=pid, minimum_fraction=minfrac)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
@@ -124,7 +129,7 @@ for case in range(cases):
         queries = []
         for _ in range(int(g.integers(1, 4)) if case % 4 == 0 else 1):
             q = scramble(g, syn.mutate_codes(g, anc, float(g.choice([0.0, 0.02, 0.05, 0.1])))) if g.random() < 0.5 else syn.mutate_codes(g, anc, 0.03)
-            queries.append([to_bytes(g, x) for x in syn.split_contigs(g, q, int(g.integers(1, 4)))])
+            queries.append([(bytes(syn.to_ascii(x)) if default_cell else to_bytes(g, x)) for x in syn.split_contigs(g, q, int(g.integers(1, 4)))])
         if len(queries) > 1:
             # the resident-batch API must give, per genome, what one query_draft call gives
             got = [[(h.name, h.identity, h.matches, h.fragments) for h in hs] for hs in mapper.upload_genomes(queries).query()]

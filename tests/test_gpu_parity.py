@@ -1316,3 +1316,32 @@ def test_unpacked_record_geometry(params, env, monkeypatch):
     assert len(ohits) >= 3
     assert gpu_mappings(mapper) == oracle_mappings(det)
     assert hit_tuples(hits) == ohits
+
+
+def test_fused_query_sketch_overflow_falls_back(monkeypatch):
+    # k_query_fused (K1 + per-fragment sketch in one launch) holds a fragment's records in LDS; one with more than its
+    # capacity voids the pass, which then runs through k_sketch_fast + k_query_sketch.  FA_QF_CAP lowers the capacity so
+    # that ordinary fragments (about 240 records) take that road.
+    g = syn.rng(141)
+    anc = syn.random_codes(g, 300_000)
+    refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.02, 0.08)]
+    query = [syn.to_ascii(syn.mutate_codes(g, anc, 0.04))]
+    mapper, hits, ohits, det = run_both({}, refs, query)              # fused (the default where it applies)
+    assert gpu_mappings(mapper) == oracle_mappings(det) and hit_tuples(hits) == ohits and len(ohits) == 2
+    ms = (C.c_float * 16)()
+
+    def again():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            h = mapper.query_draft(query)
+        lib.fa_mapper_last_timings(mapper._h, ms, 16)
+        return hit_tuples(h), int(ms[9])
+
+    assert again() == (ohits, 0)                                      # (the first call had sized the workspace)
+    monkeypatch.setenv("FA_QF_CAP", "100")
+    h, repeats = again()
+    assert repeats >= 1, "the fused launch should have been voided"
+    assert h == ohits and gpu_mappings(mapper) == oracle_mappings(det)
+    assert again() == (ohits, 0)                                      # the mapper remembers: straight through the two kernels
+    monkeypatch.delenv("FA_QF_CAP")
+    assert again() == (ohits, 0)
