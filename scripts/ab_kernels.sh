@@ -12,7 +12,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"]
-    if any(k in n for k in ("k_l2_events", "k_l2_scan", "k_l1<", "k_sketch_tiles", "k_lookup", "k_query_sketch", "k_cgi", "k_publish", "k_clear", "k_seed")):
+    if any(k in n for k in ("k_l2_events", "k_l2_scan", "k_l1<", "k_sketch_tiles", "k_lookup", "k_query_sketch", "k_query_fused", "k_sketch_fast", "k_cgi", "k_publish", "k_clear", "k_seed")):
         print(f'{n[:60]:60s} calls {r["Calls"]:>5s} avg_us {float(r["AverageNs"])/1000:8.1f}')
 PY
 done

@@ -32,9 +32,9 @@ vals = {
     "C3_TRAFFIC": f"{c3['roofline']['traffic_over_algorithmic']:.2f}×" if c3["roofline"].get("traffic_over_algorithmic") else "n/a",
     "CC_VALUE": k(b["concurrent_clients"]["value"]), "CPU_CORES": str(b["cpu_baseline"]["cores"]), "CPU_VALUE": f"{b['cpu_baseline']['value']:.0f} pairs/s",
     "CPU_1T": f"{b['cpu_baseline']['single_thread_value']:.1f}",
-    "K1_US": f"{rs['kernel_ms'] * 1e3:.0f}", "K1_16": f"{pick(s16, 'k_sketch_fast<16, 24>') / 16:.0f} µs", "K1_GB": f"{gb(k1[0]):.0f}", "K1_SINGLE": f"{gb(k1[3]):.0f}",
+    "K1_US": f"{rs['kernel_ms'] * 1e3:.0f}", "K1_GB": f"{gb(k1[0]):.0f}", "K1_SINGLE": f"{gb(k1[3]):.0f}",
+    "QF_US": f"{pick(s1, 'k_query_fused'):.0f}", "QF_16": f"{pick(s16, 'k_query_fused') / 16:.0f} µs",
     "K1_VALU": f"{rs.get('valu_frac', 0) * gb(k1[0]) / rs['gbases_per_s']:.2f}", "K1_HBM": f"{(gb(k1[0]) * 1.21) / 8000 * 100:.1f} %",
-    "QS_US": f"{pick(s1, 'k_query_sketch'):.0f}", "QS_16": f"{pick(s16, 'k_query_sketch') / 16:.0f} µs",
     "L1_US": f"{pick(s1, 'k_l1<256, 16>'):.0f}", "L1_16": f"{pick(s16, 'k_l1<256, 16>') / 16:.0f} µs",
     "EV_US": f"{pick(s1, 'k_l2_events'):.0f}", "EV_16": f"{pick(s16, 'k_l2_events') / 16:.0f} µs",
     "SC_US": f"{pick(s1, 'k_l2_scan<unsigned short, unsigned char, 64>'):.0f}", "SC_16": f"{pick(s16, 'k_l2_scan<unsigned short, unsigned char, 64>') / 16:.0f} µs",

@@ -24,6 +24,7 @@ SLOT = {"fast": 2.33, "slow": 4.2}
 # kernel (substring of the demangled name) -> (marker opcode of its hot loop, work items one trip of the loop serves per LANE, unit)
 KERNELS = {
     "k_sketch_fast<16, 24>": ("v_mad_u64_u32", 1, "k-mer position (both strands hashed)"),
+    "k_query_fused<16, 24>": ("v_mad_u64_u32", 1, "k-mer position (both strands hashed; the query pass's form of the kernel above)"),
     "k_sketch_fast<14, 0>": ("v_mad_u64_u32", 1, "k-mer position"),
     "k_sketch_fast<21, 0>": ("v_mad_u64_u32", 1, "k-mer position"),
     "k_l2_scan<unsigned short, unsigned char, 64>": ("ds_write_b8", 8, "slide event"),
