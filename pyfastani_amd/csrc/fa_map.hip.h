@@ -664,10 +664,12 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     // elements sequentially -- one LDS read and a compare per output, the same number of steps in every lane -- keeps
     // them in registers across the barrier that separates the reads of a level from its writes, and writes them back.
     // 4 bytes of LDS per seed; the chain of dependent LDS round trips per level is (two searches) + per.
-    const uint32_t per = (n + NT - 1) / NT;                              // outputs per thread (<= E)
+    // outputs per thread (<= E + 1), made ODD: thread t reads and writes around A[t x per], and with an even stride the
+    // 64 lanes of a wave share 32 / gcd(per, 64) ... banks (per = 12: four-way, per = 16: sixteen-way conflicts)
+    const uint32_t per = ((n + NT - 1) / NT) | 1u;
     const uint32_t o_lo = (uint32_t)tid * per;
     for (int k = 0; (1 << k) < s; k++) {
-      uint32_t out[E];
+      uint32_t out[E + 1];
       const int w2 = 2 << k;                                             // lists per pair of runs
       const int npairs = (s + w2 - 1) / w2;
       uint32_t A0 = 0, A1 = 0, A2 = 0, ia = 0, ib = 0;
@@ -687,7 +689,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       uint32_t ka = (o_lo < n && A0 + ia < A1) ? A[A0 + ia] : 0xFFFFFFFFu;
       uint32_t kb = (o_lo < n && A1 + ib < A2) ? A[A1 + ib] : 0xFFFFFFFFu;
 #pragma unroll
-      for (int e = 0; e < E; e++) {
+      for (int e = 0; e < E + 1; e++) {
         const uint32_t o = o_lo + e;
         out[e] = 0;
         if ((uint32_t)e < per && o < n) {
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       }
       __syncthreads();
 #pragma unroll
-      for (int e = 0; e < E; e++) {
+      for (int e = 0; e < E + 1; e++) {
         const uint32_t o = o_lo + e;
         if ((uint32_t)e < per && o < n) A[o] = out[e];
       }
@@ -1028,10 +1030,10 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
     for (uint32_t i = tid; i < nc; i += NT) { const int j = locate(i); A[i] = a.ix.pos_ridx[qo[j] + (i - off[j])]; }
     __syncthreads();
     {
-      const uint32_t per = (nc + NT - 1) / NT;
+      const uint32_t per = ((nc + NT - 1) / NT) | 1u;                  // (odd, as in k_l1: no bank conflicts between the lanes' ranges)
       const uint32_t o_lo = (uint32_t)tid * per;
       for (int k = 0; (1 << k) < s; k++) {
-        uint32_t out[E];
+        uint32_t out[E + 1];
         const int w2 = 2 << k;
         const int npairs = (s + w2 - 1) / w2;
         uint32_t A0 = 0, A1 = 0, A2 = 0, ia = 0, ib = 0;
@@ -1049,7 +1051,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
         uint32_t ka = (o_lo < nc && A0 + ia < A1) ? A[A0 + ia] : 0xFFFFFFFFu;
         uint32_t kb = (o_lo < nc && A1 + ib < A2) ? A[A1 + ib] : 0xFFFFFFFFu;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
+        for (int e = 0; e < E + 1; e++) {
           const uint32_t o = o_lo + e;
           out[e] = 0;
           if ((uint32_t)e < per && o < nc) {
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < E; e++) {
+        for (int e = 0; e < E + 1; e++) {
           const uint32_t o = o_lo + e;
           if ((uint32_t)e < per && o < nc) A[o] = out[e];
         }
