@@ -291,7 +291,9 @@ def weak_scaling(ctx):
                      "algorithmic_bytes": l2_bytes if dominant == l2_name else k1_bytes, **roof_extra},
         "roofline_sketch": {"bound": "hbm", "kernel": "k_sketch_fast", "achieved": k1_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": k1_gbs / HBM_PEAK_GBS, "kernel_ms": k1_ms.value, "gbases_per_s": bases.value / (k1_ms.value * 1e-3) / 1e9,
-                            "algorithmic_bytes": k1_bytes, **sketch_extra},
+                            "algorithmic_bytes": k1_bytes,
+                            "note": "the sketch kernel alone over the query's tiles (50 launches, fa_bench_sketch_kernel); in the timed step the same tile body runs inside k_query_fused, in one launch with the per-fragment sort and index lookup",
+                            **sketch_extra},
         "phases_ms": phase,
     }
     if world == 1:
