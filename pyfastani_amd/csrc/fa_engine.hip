@@ -938,7 +938,6 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     uint64_t *const d_totals = ln.status.p->totals;
     uint32_t *const d_counters = ln.status.p->counters;
     unsigned long long *const d_pinfo = ln.status.p->pinfo;
-    int32_t *const d_total_rows = &ln.status.p->total_rows;
     // ---- buffers and tables sized by the speculated bounds ----
     const int smax = sp.smax;
     const int64_t l_cap = sp.l_cap;

@@ -757,7 +757,6 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
   int32_t *st_rpart = st_rlast + L1_STAGE;
   for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
-  bool staged = true;
   int2 *sw_trip = (int2 *)(lds + l1_off_offset(a.lds_seed_cap));        // [NT] (the list offsets are no longer needed)
   for (int pass = 0; pass < 2; pass++) {
     if (tid == 0) { sh_heads[0] = 0; sh_has_prev[0] = 0; sh_prev_seq[0] = -1; sh_prev_wa[0] = 0; }
@@ -886,7 +885,6 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       }
       __syncthreads();
       if (sh_gbase == 0) return;
-      staged = false;
     }
   }
   // ---- groups: consecutive loci of this fragment on the same reference genome ----
@@ -940,7 +938,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   constexpr int NT = L1_BIG_THREADS, E = L1_BIG_E;
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sh_scan[NT / 64], sh_min[NT / 64], sh_first[NT / 64];
-  __shared__ uint32_t sh_run, sh_loci, sh_v, sh_firstrem, sh_bound, sh_base, sh_cnt;
+  __shared__ uint32_t sh_run, sh_loci, sh_firstrem, sh_bound, sh_base, sh_cnt;
   __shared__ int sh_prev_seq, sh_prev_wa, sh_has_prev, sh_fail, sh_last;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
