@@ -42,6 +42,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 TRAFFIC_PROFILE = "r03_traffic.json"                   # the timed step (1 query per launch)
 TRAFFIC_PROFILE_BATCH16 = "r03_batch16_traffic.json"     # `saturated.batch16`: 16 queries per launch
 TRAFFIC_PROFILE_CONFIG3 = "r03_config3_traffic.json"     # `saturated.config3`: 1000 x 1000, two steps profiled
+# digest of the config-3 hit table (20 x 50 x 5 Mb) as the driver-run N = 1 benches of rounds 2 and 3 printed it (BENCH_r03.json,
+# profiles/r03_bench_default.json: `saturated.config3.table_sha256`); an N > 1 run must reproduce it
+COMMITTED_CONFIG3_DIGEST = "f3eea1ae46a1386c"
+ROTATE = 4                     # resident query sets the timed steps rotate over
 
 
 def parse_args():
@@ -72,16 +76,34 @@ def git_head():
         return None
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks as a CHILD `torch.distributed.run` (one
+    process per GPU, rendezvous on 127.0.0.1) with this command line, relay its output -- the one JSON line of rank 0 --
+    and return its status.  Decided before `import torch` or any HIP call: this process never touches the GPU, and
+    nothing is exec'ed over a process that has."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (python bench.py --gpus N does it itself)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # FA_BENCH_SHARE_GPU=1 is a debugging aid for 1-GPU boxes: every rank uses cuda:0 and the hit tables are gathered
@@ -180,8 +202,11 @@ def weak_scaling(ctx):
     anc, names, refs = workloads.config2_references(args.refs, args.length)
     mapper, index_mode, t_pack, t_index = build_mapper(ctx, names, refs)
     n_min = len(mapper.minimizers)
-    queries = workloads.config2_query(anc, rank, args.batch)
-    batch = mapper.upload_genomes(queries)
+    # the timed steps ROTATE over four resident query sets (seeds 5000 + rank + world * j: ranks 0-3 of the generator at N = 1),
+    # so that `value` is not twenty replays of one query; every step's rows are still compared with the oracle's
+    rot_queries = [workloads.config2_query(anc, rank + world * j, args.batch) for j in range(ROTATE)]
+    queries = rot_queries[0]
+    batch = mapper.upload_genomes([q for qs in rot_queries for q in qs])
     n_pairs_step = args.refs * args.batch
 
     # Every step maps this rank's query and leaves its hit rows in HBM; the hit tables of all ranks are exchanged ONCE, by a
@@ -193,7 +218,7 @@ def weak_scaling(ctx):
     row_ptr = [table[i, 1:].data_ptr() for i in range(table.shape[0])]
 
     def step(i):
-        counts[i] = batch.query_rows_device(0, args.batch, row_ptr[i], cap_rows)
+        counts[i] = batch.query_rows_device((i % ROTATE) * args.batch, args.batch, row_ptr[i], cap_rows)
         return counts[i]
 
     def exchange(k):
@@ -227,6 +252,12 @@ def weak_scaling(ctx):
     # hits of one step over all ranks (every rank holds the whole table now)
     n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if world > 1 else int(n_last)
     phase_ms = stage_log[: args.steps, :5].astype(np.float64).sum(axis=0) / max(args.steps, 1)
+    # N > 1: the STRONG leg rides in the same line -- BASELINE config 3 dealt over the N ranks by fragment count, one all-gather of
+    # the device-resident hit table per step, digest compared with the table rank 0 computes alone (never `value`: the N = 1
+    # point of `value` must be the BENCH line).  Every rank takes part.
+    strong = None
+    if world > 1 and not args.no_saturated and args.saturated_steps > 0:
+        strong = strong_core(ctx, args.saturated_steps, 1)
     if rank != 0:
         return None
 
@@ -236,7 +267,8 @@ def weak_scaling(ctx):
     phase = dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase_ms]))
     # K1 alone, repeated, for the minimizer-extraction roofline the north star asks for
     k1_ms, bases, mins = C.c_float(0), C.c_uint64(0), C.c_uint64(0)
-    check(lib.fa_bench_sketch_kernel(mapper._h, batch._h, 50, C.byref(k1_ms), C.byref(bases), C.byref(mins)))
+    one_genome = mapper.upload_genomes(queries[:1])           # (one 5 Mb genome: the launch a one-query pass issues)
+    check(lib.fa_bench_sketch_kernel(mapper._h, one_genome._h, 50, C.byref(k1_ms), C.byref(bases), C.byref(mins)))
     k1_bytes = bases.value * 0.25 + mins.value * 12.0   # 2-bit input + 12 B per emitted MinimizerInfo
     k1_gbs = k1_bytes / (k1_ms.value * 1e-3) / 1e9
     ms = (C.c_float * 8)()
@@ -282,7 +314,7 @@ def weak_scaling(ctx):
         "data": "synthetic",
         "config": {"workload": f"{args.batch} query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
                    "timed_region": "device-resident pass (packed query in HBM -> hit rows in HBM); the host-bytes -> Hit-list call is `boundary_call`",
-                   "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
+                   "queries_rotated": ROTATE, "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
                    "index_minimizers": n_min, "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack, "head": git_head()},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": roof[1],
@@ -295,17 +327,24 @@ def weak_scaling(ctx):
                             "note": "the sketch kernel alone over the query's tiles (50 launches, fa_bench_sketch_kernel); in the timed step the same tile body runs inside k_query_fused, in one launch with the per-fragment sort and index lookup",
                             **sketch_extra},
         "phases_ms": phase,
+        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+        "backend": (dist.get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if share_gpu else " (RCCL over xGMI)")) if world > 1 else "none (one rank)",
     }
+    if strong is not None:
+        if strong["digest_matches_n1"] is False:
+            raise SystemExit(f"STRONG LEG FAILURE: the all-gathered hit table of {world} ranks ({strong['table_sha256']}) differs from the "
+                             f"table one rank computes ({strong['table_sha256_n1']})")
+        result["strong"] = strong
     if world == 1:
         timed_rows = [table[i, 1: counts[i] + 1].cpu().numpy().reshape(-1).view(ROW_DTYPE) for i in range(args.steps)]
         if not args.no_boundary:
-            result["boundary_call"] = boundary_call(args, mapper, queries[0], timed_rows)
+            result["boundary_call"] = boundary_call(args, mapper, queries[0], timed_rows[::ROTATE])
         if args.clients > 1:
             result["concurrent_clients"] = concurrent_clients(args, batch, cap_rows, n_pairs_step)
         if not args.no_saturated and args.batch == 1:
             result["saturated"] = saturated_legs(ctx, mapper, anc)
         if not args.no_cpu_baseline:              # the CPU oracle legs are an N=1 measurement (rank 0 only)
-            result.update(oracle_legs(args, anc, names, refs, mapper, queries[0], timed_rows))
+            result.update(oracle_legs(args, anc, names, refs, mapper, [qs[0] for qs in rot_queries], timed_rows))
     return result
 
 
@@ -486,7 +525,7 @@ def saturated_legs(ctx, mapper, anc, batch16_steps=10):
     return out
 
 
-def oracle_legs(args, anc, names, refs, mapper, query, timed_rows):
+def oracle_legs(args, anc, names, refs, mapper, rot_queries, timed_rows):
     """Parity check and CPU baseline on the CPU oracle (a restatement: the reference's own C++ cannot be built,
     DESIGN.md section 2), on this box's host cores, outside the timed region.
 
@@ -518,20 +557,24 @@ def oracle_legs(args, anc, names, refs, mapper, query, timed_rows):
     osk.add_drafts(s_names, s_refs, threads=cores)
     osk.index()
     t_oracle_index = time.time() - t0
+    query = rot_queries[0]
     ohits, det = osk.query_draft(query, threads=cores, details=True)
-    # ---- parity: rows ----
-    o = det["rows"]
+    # ---- parity: rows (step i mapped query i mod ROTATE) ----
     if full:
         gpu_row_sets = timed_rows
+        dets = [det] + [osk.query_draft(q, threads=cores, details=True)[1] for q in rot_queries[1: max(1, min(ROTATE, len(timed_rows)))]]
     else:
         gpu_row_sets = [g_mapper.upload_genomes([query]).query_rows(0, 1)]
+        dets = [det]
     rows_compared = 0
-    for rows in gpu_row_sets:
+    for i, rows in enumerate(gpu_row_sets):
+        d = dets[i % len(dets)]
+        o = d["rows"]
         ok = (len(rows) == len(o["genome"]) and np.array_equal(rows["ref_genome_id"], o["genome"])
               and np.array_equal(rows["count_seq"], o["count"]) and np.array_equal(rows["identity"], o["identity"])
-              and bool(np.all(rows["total_query_fragments"] == det["total_fragments"])))
+              and bool(np.all(rows["total_query_fragments"] == d["total_fragments"])))
         if not ok:
-            raise SystemExit(f"PARITY FAILURE: the HIP rows differ from the CPU oracle's ({len(rows)} vs {len(o['genome'])} rows)")
+            raise SystemExit(f"PARITY FAILURE: the HIP rows of step {i} differ from the CPU oracle's ({len(rows)} vs {len(o['genome'])} rows)")
         rows_compared += len(rows)
     # ---- parity: every L2 mapping of one boundary call, and its hits ----
     hits = g_mapper.query_draft([bytes(c) for c in query])
@@ -557,7 +600,7 @@ def oracle_legs(args, anc, names, refs, mapper, query, timed_rows):
     n_rel = sum(1 for x in s_names if x.startswith("A"))
     return {
         "parity_checked": True, "rows_compared": rows_compared, "mappings_compared": len(want),
-        "parity": {"against": "oracle/ (CPU restatement)", "index_refs": n_refs, "timed_steps_checked": len(gpu_row_sets) if full else 0,
+        "parity": {"against": "oracle/ (CPU restatement)", "index_refs": n_refs, "timed_steps_checked": len(gpu_row_sets) if full else 0, "queries_checked": len(dets),
                    "hits_compared": len(ohits), "oracle_index_build_s": t_oracle_index},
         "cpu_baseline": {
             "value": repeats * n_refs / seconds, "unit": "pairs/s", "cores": cores, "kind": "port",
@@ -608,6 +651,16 @@ def strong_core(ctx, steps, warmup):
         tables = step(True)
     fence(ctx)
     elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
+    exchange_ms = max_over_ranks(ctx, exchange.exchange_ms(steps))
+    # ---- N > 1: the table every rank holds now must be the table ONE rank computes.  Rank 0 maps all genomes against its
+    #      replica (outside the timed region, no collective) and the digests are compared; the other ranks wait at the fence. ----
+    n1_digest = None
+    if world > 1 and rank == 0:
+        everything = mapper.upload_genomes(genomes)
+        alone = sharding.ResidentHitTable(list(range(n)), n * n, 1)
+        n1_digest = _sha256_rows(sharding.ResidentHitTable.rows_of(alone.step(everything)))
+        del everything, alone
+    fence(ctx)
     if rank != 0:
         return None
     rows = sharding.ResidentHitTable.rows_of(tables)          # (outside the timed region: the table stays in HBM inside it)
@@ -631,6 +684,9 @@ def strong_core(ctx, steps, warmup):
         "self_rows_ok": bool(len(self_rows) == n and np.all(self_rows["identity"] >= 99.999)),
         "self_rows_exactly_100": int(np.sum(self_rows["identity"] == 100.0)),
         "table_sha256": _sha256_rows(rows), "head": git_head(),
+        "exchange_ms": exchange_ms, "exchange_bytes_per_rank": int((max_rows + 1) * 20),
+        "table_sha256_n1": n1_digest, "digest_matches_n1": (None if n1_digest is None else bool(n1_digest == _sha256_rows(rows))),
+        "table_sha256_committed_n1": COMMITTED_CONFIG3_DIGEST if (args.families, args.members, args.length) == (20, 50, 5_000_000) else None,
     }
 
 
@@ -648,13 +704,19 @@ def strong_scaling(ctx):
         return None
     config = {k: r[k] for k in ("workload", "pairs_per_step", "rows_per_step", "parallelism", "exchange", "fragments_per_rank", "index_minimizers",
                                 "index_build", "index_build_s", "host_pack_s", "generate_s", "self_rows_ok", "self_rows_exactly_100",
-                                "table_sha256", "head")}
+                                "table_sha256", "head", "exchange_ms", "exchange_bytes_per_rank", "table_sha256_n1", "digest_matches_n1",
+                                "table_sha256_committed_n1")}
+    if r["digest_matches_n1"] is False:
+        raise SystemExit(f"STRONG SCALING FAILURE: the all-gathered hit table of {world} ranks ({r['table_sha256']}) differs from the "
+                         f"table one rank computes ({r['table_sha256_n1']})")
     return {
         "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)", "value": r["value"], "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": config, "roofline": r["roofline"], "phases_ms": r["phases_ms_rank0"],
         "repeated_attempts_per_step": r["repeated_attempts_per_step"],
+        "rccl_ranks": ctx["dist"].get_world_size() if world > 1 else 1,
+        "backend": (ctx["dist"].get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if ctx["share_gpu"] else " (RCCL over xGMI)")) if world > 1 else "none (one rank)",
     }
 
 

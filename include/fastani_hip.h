@@ -219,7 +219,9 @@ int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, in
  * the wide L2 state, [9] passes repeated because a speculated buffer size was too small; after fa_mapper_query also
  * the host-side wall-clock split of that call: [10] packing ms, [11] fragment / tile tables ms, [12] uploads ms,
  * [13] device pass + rows ms; [14], [15] development (fused L2 form); [16] the L2 stage once more, bracketed by HIP
- * events on the library's stream, when fa_mapper_set_stage_events is on (0 otherwise).  n <= 24. */
+ * events on the library's stream, when fa_mapper_set_stage_events is on (0 otherwise); [17] parts of the call whose sketch
+ * stage ran as ONE launch (k_query_fused), [18] parts that ran K1 and the fragment sketch as two kernels, [19] parts whose
+ * k_l2_events workgroups ran in the offset-major order.  n <= 24. */
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n);
 /* on != 0: also bracket the L2 stage of every pass with two HIP events (slot [16] above).  Off by default: an event
  * record costs the stream about as much as a small kernel. */

@@ -6,6 +6,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdlib>
@@ -336,7 +337,9 @@ struct fa_genomes {
   int64_t F = 0, ntiles = 0;
   uint64_t total_bases = 0;                 // bases inside fragments
   std::vector<unsigned char> host_image;    // staging image when no pinned buffer is supplied
+  uint64_t serial = 0;                      // a new number for every upload (caches keyed on a batch compare this, not its address)
 };
+static std::atomic<uint64_t> g_batch_serial{0};
 
 // Every small counter / statistic of a pass in ONE device block, mirrored into pinned host memory by one copy.
 static uint64_t env_u64(const char *name, uint64_t dflt) {
@@ -408,7 +411,7 @@ struct Workspace {
   // workgroup order of k_l2_events for passes of several genomes (L2Args::frag_order), cached while the same part repeats
   DevBuf<int32_t> frag_order;
   PinnedBuf pin_order;
-  const void *order_batch = nullptr;
+  uint64_t order_batch = 0;            // fa_genomes::serial of the batch the cached order was built for
   int64_t order_f0 = -1, order_f1 = -1;
   uint32_t order_len = 0;
   DevBuf<unsigned long long> group_best, bins;
@@ -481,7 +484,13 @@ struct fa_mapper {
     int64_t l_cap = 0;
     int64_t part_frags = 0;   // fragments per part of a pass (shrinks when a part overflows the 32-bit workspace)
     bool redo = false;        // launch the wide-state scan as well (set once a locus overflowed the one-byte state)
-    bool fuse_off = false;    // k_query_fused met a fragment with more records than its LDS holds: K1 and k_query_sketch apart
+    // k_query_fused met a fragment with more records than its LDS holds: the void range runs again through the two kernels
+    // (`fuse_off`, a property of that attempt only).  The mapper keeps a back-off, not a verdict: the first overflow costs
+    // nothing afterwards, consecutive ones skip 1, 3, 7 ... 63 passes before the fused form is tried again, and a fused pass
+    // that is accepted clears the record -- one dense fragment no longer decides every later query of the mapper.
+    bool fuse_off = false;
+    int fuse_skip = 0, fuse_penalty = 0;
+    int smax_misses = 0;      // times the largest sketch outgrew the bound (the first growth is tight, later ones are not)
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
   // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
@@ -743,10 +752,14 @@ static int64_t pass_fragments() {
 }
 
 // Workgroup order of k_l2_events over the fragments [f0, f1) of a pass that holds several genomes: fragments sorted by their
-// offset inside their genome (then by genome), the groups of equal offset dealt to the eight XCDs in turn, and the eight
-// lists interleaved the way workgroups are dispatched (workgroup b runs on XCD b mod 8); -1 pads the shorter lists.
+// offset inside their genome (then by genome), every group of equal offset dealt to the XCD whose list is the shortest so far
+// (equal-sized genomes: group p lands on XCD p mod 8), and the eight lists interleaved the way workgroups are dispatched
+// (workgroup b runs on XCD b mod 8); -1 pads the shorter lists.  Returns 0 -- the caller keeps the identity order -- when
+// the lists cannot be balanced: fewer groups than XCDs (a batch of plasmids or viral contigs of one or two fragments each
+// would put every real workgroup on one XCD) or more than 15 % of padding.
 static uint32_t build_frag_order(const fa_genomes &g, int32_t g0, int64_t f0, int64_t f1, std::vector<int32_t> &out) {
   const int64_t F = f1 - f0;
+  out.clear();
   int32_t q = g0;
   while (g.genome_frag_lo[q + 1] <= f0) q++;
   // offset of every fragment inside its genome, counting sort by it (stable: genomes stay in order inside a group)
@@ -757,19 +770,29 @@ static uint32_t build_frag_order(const fa_genomes &g, int32_t g0, int64_t f0, in
     off[(size_t)i] = (int32_t)(f0 + i - g.genome_frag_lo[qq]);
     max_off = std::max(max_off, off[(size_t)i]);
   }
+  if (max_off + 1 < 8) return 0;
   std::vector<int32_t> start((size_t)max_off + 2, 0);
   for (int64_t i = 0; i < F; i++) start[(size_t)off[(size_t)i] + 1]++;
   for (int32_t p = 0; p <= max_off; p++) start[(size_t)p + 1] += start[(size_t)p];
   std::vector<int32_t> sorted((size_t)F), fill(start.begin(), start.end() - 1);
   for (int64_t i = 0; i < F; i++) sorted[(size_t)fill[(size_t)off[(size_t)i]]++] = (int32_t)i;
-  // groups -> XCD lists (group p goes to XCD p mod 8), then interleave
+  // groups -> XCD lists (the shortest list takes the next group; ties to the lowest XCD), then interleave
   size_t len[8] = {0};
-  for (int32_t p = 0; p <= max_off; p++) len[p & 7] += (size_t)(start[(size_t)p + 1] - start[(size_t)p]);
+  std::vector<uint8_t> xcd_of((size_t)max_off + 1);
+  for (int32_t p = 0; p <= max_off; p++) {
+    int x = 0;
+    for (int i = 1; i < 8; i++) if (len[i] < len[x]) x = i;
+    xcd_of[(size_t)p] = (uint8_t)x;
+    len[x] += (size_t)(start[(size_t)p + 1] - start[(size_t)p]);
+  }
   const size_t longest = *std::max_element(len, len + 8);
+  if ((double)longest * 8.0 > 1.15 * (double)F) return 0;
   out.assign(longest * 8, -1);
   size_t at[8] = {0};
-  for (int32_t p = 0; p <= max_off; p++)
-    for (int32_t i = start[(size_t)p]; i < start[(size_t)p + 1]; i++) out[(at[p & 7]++) * 8 + (size_t)(p & 7)] = sorted[(size_t)i];
+  for (int32_t p = 0; p <= max_off; p++) {
+    const size_t x = xcd_of[(size_t)p];
+    for (int32_t i = start[(size_t)p]; i < start[(size_t)p + 1]; i++) out[(at[x]++) * 8 + x] = sorted[(size_t)i];
+  }
   return (uint32_t)out.size();
 }
 
@@ -810,6 +833,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       ms.part_frags = pass_fragments();
     }
     sp = ms;
+    sp.fuse_off = ms.fuse_skip > 0;
     FA_REQUIRE(sp.smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
     ensure_luts(m, sp.smax);
     w.lut_min_hits = m.d_min_hits.p; w.lut_pass = m.d_pass.p; w.lut_ident = m.d_ident.p;
@@ -824,7 +848,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ms.l_cap = std::max(ms.l_cap, sp.l_cap);
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
-    ms.fuse_off = ms.fuse_off || sp.fuse_off;
+    ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
   };
   fetch_spec();
   // event offsets are 32-bit: at most this many slide events per part (FA_EVENTS_CAP_MAX: the tests force the split)
@@ -874,9 +898,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     FA_HIP(hipEventRecord(w.ev_bins, st));
   }
 
-  struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; };
-  std::deque<std::pair<int64_t, int64_t>> todo;
-  todo.emplace_back(range_f0, range_f1);
+  struct Range { int64_t f0, f1; bool unfused; };     // unfused: the repeat of a range that overflowed k_query_fused
+  struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; bool fused = false, forced_unfused = false, ordered = false; };
+  std::deque<Range> todo;
+  todo.push_back(Range{range_f0, range_f1, false});
   std::deque<Run> flight;
   bool busy[3] = {false, false, false}, ran[3] = {false, false, false};
   bool rows_valid = false;
@@ -976,7 +1001,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       // ---- K1 (its extra workgroups zero the ranges above beside the hashing) + per-fragment sort / unique / index lookup:
       //      one launch where the pass qualifies (k_query_fused), else k_sketch_fast / k_sketch_tiles, then k_query_sketch ----
       const bool fused = launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st, &cl.a,
-                                             sp.fuse_off ? nullptr : &a, F);
+                                             (sp.fuse_off || r.forced_unfused) ? nullptr : &a, F);
+      r.fused = fused;
       if (!fused) {
         if (qs_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_query_sketch, hipFuncAttributeMaxDynamicSharedMemorySize, (int)qs_lds));
         hipLaunchKernelGGL(k_query_sketch, dim3((unsigned)F), dim3(MAP_THREADS), qs_lds, st, a);
@@ -1061,17 +1087,18 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       uint32_t ev_grid = (uint32_t)F;
       static const bool order_on = !(getenv("FA_FRAG_ORDER") && atoi(getenv("FA_FRAG_ORDER")) == 0);
       if (order_on && NQ >= 2 && F >= 64) {
-        if (ln.order_batch != (const void *)&g || ln.order_f0 != f0 || ln.order_f1 != f1) {
+        if (ln.order_batch != g.serial || ln.order_f0 != f0 || ln.order_f1 != f1) {
           std::vector<int32_t> ord;
-          ln.order_len = build_frag_order(g, g0, f0, f1, ord);
-          ln.pin_order.ensure(ord.size() * sizeof(int32_t));
-          memcpy(ln.pin_order.p, ord.data(), ord.size() * sizeof(int32_t));
-          ln.frag_order.ensure(ord.size());
-          FA_HIP(hipMemcpyAsync(ln.frag_order.p, ln.pin_order.p, ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-          ln.order_batch = (const void *)&g; ln.order_f0 = f0; ln.order_f1 = f1;
+          ln.order_len = build_frag_order(g, g0, f0, f1, ord);       // 0: the lists cannot be balanced, identity order
+          if (ln.order_len) {
+            ln.pin_order.ensure(ord.size() * sizeof(int32_t));
+            memcpy(ln.pin_order.p, ord.data(), ord.size() * sizeof(int32_t));
+            ln.frag_order.ensure(ord.size());
+            FA_HIP(hipMemcpyAsync(ln.frag_order.p, ln.pin_order.p, ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+          }
+          ln.order_batch = g.serial; ln.order_f0 = f0; ln.order_f1 = f1;
         }
-        a.frag_order = ln.frag_order.p;
-        ev_grid = ln.order_len;
+        if (ln.order_len) { a.frag_order = ln.frag_order.p; ev_grid = ln.order_len; r.ordered = true; }
       }
 #ifdef FA_EXPERIMENTS
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
@@ -1212,6 +1239,25 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     if (!published) hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, st, pub);
     ran[r.lane] = true;
   };
+  // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
+  // instantiation (wide events, fewer than 64 loci per scan workgroup) or the runtime does not say
+  auto scan_occupancy = [&](int smax) -> int {
+    const int slots = smax + 1;
+    if (slots + 1 >= (1 << EvBits<uint16_t>::RANK) || !m.packed_geo) return 0;
+    const size_t lds_scan = ((size_t)(slots + 1) * L2_THREADS + 15) / 16 * 16;
+    if (lds_scan > 64 * 1024) return 0;
+    const int per_window = std::max(1, 2 * m.P.fragment_length / (m.P.window_size + 1));
+    const int ev_stage = std::min(2048, std::max(512, (per_window * 11 / 2 + 127) & ~127));
+    const size_t lds_ev = ev_sketch_bytes(slots) + (size_t)ev_stage * 2 * (EV_THREADS / 64) + 16;
+    if (lds_ev > 64 * 1024) return 0;
+    int n_scan = 0, n_ev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_scan, (const void *)k_l2_scan<uint16_t, uint8_t, 64>, L2_THREADS, lds_scan) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_ev, (const void *)k_l2_events<uint16_t, true>, EV_THREADS, lds_ev) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    return n_scan > 0 && n_ev > 0 ? n_scan * 64 + n_ev : 0;
+  };
   // waits for a part and reads its verdict: true = accepted, false = void (its range has to run again)
   auto finish_part = [&](Run &r) -> bool {
     Workspace &ln = *lanes[r.lane];
@@ -1239,7 +1285,21 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     // bounds for the next pass (or the repeat of this one)
     // (a multiple of 8 just above the largest sketch seen: every slot of the bound costs k_l2_scan 64 bytes of LDS per wave,
     // and on the bench workload -- largest sketch 263 -- 272 slots let nine of its workgroups share a CU where 288 let eight)
-    if (h_stats[0] > sp.smax) sp.smax = (h_stats[0] + 4 + 7) / 8 * 8;
+    // The first growth is that tight bound; if the workload keeps producing larger sketches (every raise voids a pass and
+    // rebuilds the O(s^2) LUTs) later ones take an eighth of headroom, cut back to the largest bound that leaves k_l2_scan and
+    // k_l2_events the workgroups per CU the tight bound would (scan_occupancy).
+    if (h_stats[0] > sp.smax) {
+      const int tight = (h_stats[0] + 4 + 7) / 8 * 8;
+      int bound = tight;
+      if (sp.smax_misses > 0) {
+        const int roomy = (h_stats[0] + h_stats[0] / 8 + 7) / 8 * 8;
+        const int want = scan_occupancy(tight);
+        bound = want > 0 ? tight : roomy;
+        for (int s2 = tight + 8; want > 0 && s2 <= roomy && scan_occupancy(s2) == want; s2 += 8) bound = s2;
+      }
+      sp.smax = bound;
+      sp.smax_misses++;
+    }
     // LDS slots for the seed sort: a quarter of headroom over the largest fragment seen, (LDS per workgroup sets how many fragments a CU works on at once)
     uint32_t want_slots = std::min<uint32_t>(lds_seed_cap_max(sp.smax), std::max<uint32_t>(1024, (uint32_t)((std::min<uint64_t>(max_seeds + max_seeds / 4, 1u << 30) + 255) / 256 * 256)));
     const bool slots_changed = want_slots != sp.seed_slots;
@@ -1250,7 +1310,12 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); publish_spec(sp); return false; }
       sp.l_cap = std::min(want, l_max);
     }
-    if (flags & SPEC_QFUSE) sp.fuse_off = true;
+    if (flags & SPEC_QFUSE) {
+      r.forced_unfused = true;                           // this range again, through the two kernels
+      std::lock_guard<std::mutex> lock(m.mtx);
+      m.spec.fuse_penalty = m.spec.fuse_penalty ? std::min(64, m.spec.fuse_penalty * 2) : 1;
+      m.spec.fuse_skip = m.spec.fuse_penalty - 1;
+    }
     if (flags & SPEC_EVENTS) {
       // every region has to hold its share: size the arena for the fullest one (the fused form reserves from one counter)
       const uint64_t need = std::max<uint64_t>(h_pinfo[0], ev_region_max * ev_regions_for(F));
@@ -1265,6 +1330,13 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     }
     publish_spec(sp);
     // ---- accepted ----
+    {
+      std::lock_guard<std::mutex> lock(m.mtx);
+      if (r.fused) m.spec.fuse_penalty = 0;                                             // the fused form holds again
+      else if (sp.fuse_off && !r.forced_unfused && m.spec.fuse_skip > 0) m.spec.fuse_skip--;   // one pass of the back-off served
+    }
+    w.last_ms[r.fused ? 17 : 18] += 1.0f;
+    if (r.ordered) w.last_ms[19] += 1.0f;
     if (m.stage_events) {
       float ev_ms = 0;
       FA_HIP(hipEventSynchronize(ln.ev[3]));
@@ -1292,10 +1364,11 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
                  "query pass did not converge on its buffer sizes");
       attempts++;
       fetch_spec();
-      auto range = todo.front(); todo.pop_front();
-      const int64_t f1 = std::min(range.second, range.first + std::max<int64_t>(1, std::min(auto_part, sp.part_frags)));
-      if (f1 < range.second) todo.emplace_front(f1, range.second);
-      Run r{i, range.first, f1, sp, todo.empty() && npairs > 0};
+      const Range range = todo.front(); todo.pop_front();
+      const int64_t f1 = std::min(range.f1, range.f0 + std::max<int64_t>(1, std::min(auto_part, sp.part_frags)));
+      if (f1 < range.f1) todo.push_front(Range{f1, range.f1, range.unfused});
+      Run r{i, range.f0, f1, sp, todo.empty() && npairs > 0};
+      r.forced_unfused = range.unfused;
       if (r.with_rows) rows_valid = false;
       launch_part(r);
       busy[i] = true;
@@ -1306,7 +1379,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     const bool ok = finish_part(r);
     busy[r.lane] = false;
     if (!ok) {
-      todo.emplace_front(r.f0, r.f1);
+      todo.push_front(Range{r.f0, r.f1, r.forced_unfused});
       rows_valid = false;                     // (rows formed meanwhile lack this part)
     }
   }
@@ -1414,6 +1487,7 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   FA_REQUIRE(width == 1 || width == 2 || width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
   std::unique_ptr<fa_genomes> g = reuse ? std::move(reuse) : std::unique_ptr<fa_genomes>(new fa_genomes());
   g->P = P;
+  g->serial = ++g_batch_serial;
   g->n_genomes = n_genomes;
   g->total_fragments.assign(n_genomes, 0); g->total_length.assign(n_genomes, 0); g->n_short.assign(n_genomes, 0);
   g->total_bases = 0;

@@ -775,6 +775,10 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       const uint32_t ra = ra_n;
       const int seq = sw_n.x, wa = sw_n.y;
       sw_trip[tid] = make_int2(seq, wa);
+      // (the slots written above are read below by OTHER lanes of the same wave only: order the store before those reads
+      // explicitly -- no instruction on gfx950, where a wave's LDS operations complete in order -- instead of relying on it)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       if (i0 + NT < ncand) {
         const uint32_t in = i + NT;
         ra_n = in < n ? seeds[in] : 0u;

@@ -123,6 +123,7 @@ class ResidentHitTable:
         self.owned = torch.as_tensor(np.asarray(owned, dtype=np.int64), device=self.table_device)
         self.out = (torch.empty((self.world * (self.max_rows + 1), 5), dtype=torch.int32, device=self.comm_device)
                     if self.world > 1 else None)
+        self.exchange_marks = []                  # per step: a pair of CUDA events (device collective) or seconds (host collective)
         self._sync()
 
     def _sync(self):
@@ -142,9 +143,36 @@ class ResidentHitTable:
         if self.world == 1:
             return self.local.view(1, self.max_rows + 1, 5)
         import torch.distributed as dist
+        # the collective is bracketed by two events on torch's stream (a blocking collective makes that stream wait for it);
+        # nothing is synchronised here -- `exchange_ms` reads the events after the timed region
+        on_device = self.comm_device.type == "cuda"
+        if on_device:
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+        else:
+            import time
+            self._sync()
+            t0 = time.perf_counter()
         src = self.local if self.comm_device == self.table_device else self.local.to(self.comm_device)
         dist.all_gather_into_tensor(self.out, src, group=self.group)
+        if on_device:
+            t1.record()
+            self.exchange_marks.append((t0, t1))
+        else:
+            self.exchange_marks.append(time.perf_counter() - t0)
         return self.out.view(self.world, self.max_rows + 1, 5)
+
+    def exchange_ms(self, last=None):
+        """Mean duration of the all-gather over the last ``last`` steps (all, if None), in ms; 0.0 at world size 1.
+        Call it after the steps are done: it synchronises."""
+        marks = self.exchange_marks[-last:] if last else self.exchange_marks
+        if not marks:
+            return 0.0
+        self._sync()
+        if self.comm_device.type == "cuda":
+            self.torch.cuda.synchronize()
+            return float(sum(a.elapsed_time(b) for a, b in marks) / len(marks))
+        return float(sum(marks) / len(marks) * 1e3)
 
     @staticmethod
     def rows_of(tables):

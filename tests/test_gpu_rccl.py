@@ -77,13 +77,52 @@ def test_bench_weak_two_ranks_sharing_one_gpu():
     """The default (weak-scaled) mode at N = 2 -- what the driver launches for its scaling curve -- with both ranks on GPU 0 over
     gloo: every rank maps its own query against the cooperatively built index, the hit tables of all steps are exchanged by
     one all-gather at the end of the timed region, and the line carries the whole-job rate."""
-    args = ["--gpus", "2", "--refs", "6", "--length", "400000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+    args = ["--gpus", "2", "--refs", "6", "--length", "400000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-saturated"]
     res = _run_ranks([os.path.join(ROOT, "bench.py")] + args, 2, env={"FA_BENCH_SHARE_GPU": "1"})
     assert res.returncode == 0, res.stdout + res.stderr
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
     assert line["config"]["pairs_per_step_per_gpu"] == 6 and "sharded sketching x2" in line["config"]["index_build"]
     assert line["config"]["hits_per_step"] >= 4 and "saturated" not in line and line["phases_ms"]["l2_ms"] > 0
+    assert "strong" not in line
+
+
+def test_bench_launches_its_own_ranks_and_carries_the_strong_leg():
+    """`python bench.py --gpus 2` with NO launcher around it (the command a scaling run issues): the process starts its two
+    ranks as a child `torch.distributed.run` before it imports torch, relays rank 0's line and exits with the child's status.
+    The line is the weak-scaled step (`value`) AND the strong leg -- config 3 in miniature dealt over both ranks, the
+    all-gathered table's digest equal to the digest of the table rank 0 computes alone."""
+    args = ["--gpus", "2", "--refs", "6", "--length", "300000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+            "--families", "2", "--members", "5", "--saturated-steps", "2"]
+    env = dict(os.environ, FA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"].startswith("gloo")
+    assert line["config"]["queries_rotated"] == 4 and line["value"] > 0
+    s = line["strong"]
+    assert s["pairs_per_step"] == 100 and len(s["fragments_per_rank"]) == 2 and s["self_rows_ok"] is True
+    assert s["digest_matches_n1"] is True and s["table_sha256"] == s["table_sha256_n1"]
+    assert s["exchange_ms"] > 0 and s["ms_per_step"] > 0
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"], 2, env={"FA_BENCH_SHARE_GPU": "1"})
+    assert res.returncode != 0 and "WORLD_SIZE" in (res.stdout + res.stderr)
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")
+def test_bench_self_launch_rccl_two_gpus():
+    """The same command on two real GPUs: RCCL (`nccl` backend) carries the all-gathers."""
+    args = ["--gpus", "2", "--refs", "6", "--length", "300000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+            "--families", "2", "--members", "5", "--saturated-steps", "2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FA_BENCH_SHARE_GPU")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["backend"].startswith("nccl") and line["strong"]["digest_matches_n1"] is True
 
 
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL: one rank per device)")
