@@ -355,6 +355,7 @@ struct PassStatus {
   uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
+  unsigned long long dbg[8];        // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the workgroups (thread 0's view)
   unsigned long long stamp[6];      // stage_stamp: pass start, lookup, L2, CGI, end (100 MHz ticks); not cleared with the rest
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
@@ -460,7 +461,8 @@ struct fa_mapper {
   DevBuf<uint8_t> rec_flags;
   DevBuf<uint2> rec_hg;           // (hash, packed window geometry + flags) for k_l2_events (empty when cmw >= 8191)
   DevBuf<uint16_t> rec_prev16;
-  DevBuf<int2> rec_sw;            // (rec_seq, rec_wpos) interleaved for k_l1
+  DevBuf<uint32_t> rec_gpos, wrap_rec;   // padded global coordinate of every record (low word) + its 2^32 boundaries, for k_l1
+  int32_t n_wraps = 0;
 #ifdef FA_EXPERIMENTS
   DevBuf<uint32_t> ev_bits;       // merged admit / drop order of the slide (k_event_bits), 2 bits per record
   DevBuf<uint2> rec_hf;           // hash + flags + distance to the previous record of the hash (k_pack_hf), for k_l2_fused
@@ -507,7 +509,7 @@ struct fa_mapper {
   IndexView view() const {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
-    v.rec_hg = packed_geo ? rec_hg.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_sw = rec_sw.p;
+    v.rec_hg = packed_geo ? rec_hg.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_gpos = rec_gpos.p; v.wrap_rec = wrap_rec.p; v.n_wraps = n_wraps;
 #ifdef FA_EXPERIMENTS
     v.ev_bits = ev_bits.p; v.rec_hf = rec_hf.p;
 #endif
@@ -654,8 +656,23 @@ static void build_index(fa_mapper &m) {
                        m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
     hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, m.contig_rec.p, N, m.cmw,
                        m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
-    m.rec_sw.ensure((size_t)N + 4);
-    hipLaunchKernelGGL(k_interleave_seq_wpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, N, m.rec_sw.p);
+    {
+      // padded global coordinate of every record (k_rec_gpos): spans of the contigs, their prefix sums, the low words
+      DevBuf<unsigned long long> span, base;
+      DevBuf<int32_t> d_wraps;
+      span.ensure((size_t)m.C + 2); base.ensure((size_t)m.C + 2); d_wraps.ensure(1);
+      hipLaunchKernelGGL(k_contig_span, dim3(ceil_div(m.C + 1, 256)), dim3(256), 0, st, m.contig_rec.p, m.rec_wpos.p, m.C, m.P.fragment_length, span.p);
+      bytes = 0;
+      FA_HIP(rocprim::exclusive_scan(nullptr, bytes, span.p, base.p, 0ULL, (size_t)m.C + 1, rocprim::plus<unsigned long long>(), st));
+      temp.ensure(bytes + 16);
+      FA_HIP(rocprim::exclusive_scan(temp.p, bytes, span.p, base.p, 0ULL, (size_t)m.C + 1, rocprim::plus<unsigned long long>(), st));
+      m.rec_gpos.ensure((size_t)N + 4);
+      m.wrap_rec.ensure(GPOS_MAX_WRAPS);
+      hipLaunchKernelGGL(k_rec_gpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, base.p, N, m.rec_gpos.p, m.wrap_rec.p, d_wraps.p);
+      d_wraps.download(&m.n_wraps, 1, st);
+      FA_HIP(hipStreamSynchronize(st));
+      FA_REQUIRE(m.n_wraps <= GPOS_MAX_WRAPS, FA_ERR_UNSUPPORTED, "the index spans more than 2^40 bases (shard the references)");
+    }
 #ifdef FA_EXPERIMENTS
     if (fused_l2_enabled()) {
       const size_t words = ((size_t)2 * (size_t)N + 31) / 32 + 4;
@@ -680,6 +697,7 @@ static void build_index(fa_mapper &m) {
     m.table.ensure(16);
     FA_HIP(hipMemsetAsync(m.table.p, 0, 16 * sizeof(uint4), st));
     m.uniq_hash.ensure(2); m.uniq_off.ensure(2);
+    m.rec_gpos.ensure(4); m.wrap_rec.ensure(GPOS_MAX_WRAPS); m.n_wraps = 0;
     FA_HIP(hipMemsetAsync(m.uniq_off.p, 0, 2 * sizeof(uint32_t), st));
     FA_HIP(hipStreamSynchronize(st));
   }
@@ -1028,6 +1046,10 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
+      static const bool l1_block_sort_on = !(getenv("FA_L1_BLOCK_SORT") && atoi(getenv("FA_L1_BLOCK_SORT")) == 0);
+      static const bool l1_stats = getenv("FA_L1_STATS") && atoi(getenv("FA_L1_STATS")) != 0;
+      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0);
+      a.dbg = ln.status.p->dbg;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
       // into LDS-sized chunks at contig boundaries by k_l1_big first; what it cannot cut stays with k_l1's HBM path
       static const bool l1_big = !(getenv("FA_L1_BIG") && atoi(getenv("FA_L1_BIG")) == 0);
@@ -1353,6 +1375,13 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     w.last_ms[6] += (float)h_counters[0];
     w.last_ms[7] += (float)events_total;  // slide events
     w.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
+    w.last_ms[20] += (float)h_counters[5]; w.last_ms[21] += (float)h_counters[6];   // FA_L1_STATS=1: fragments block-sorted / merged by k_l1
+    if (h_counters[5] + h_counters[6] > 0) {
+      const double nf = (double)(h_counters[5] + h_counters[6]);
+      fprintf(stderr, "[fa] k_l1 phases, shader-clock ticks per fragment (thread 0):");
+      for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", (double)ln.h_status->dbg[i] / nf);
+      fprintf(stderr, "  (%u block-sorted, %u merged)\n", h_counters[5], h_counters[6]);
+    }
     return true;
   };
 

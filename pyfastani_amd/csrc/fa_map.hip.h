@@ -167,9 +167,35 @@ __global__ void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, 
   }
 }
 
-__global__ void k_interleave_seq_wpos(const int32_t *rec_seq, const int32_t *rec_wpos, int64_t N, int2 *rec_sw) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < N) rec_sw[i] = make_int2(rec_seq[i], rec_wpos[i]);
+// Padded global coordinate of every record, for the candidate pass of k_l1: contig c starts at
+//   base[c] = sum over c' < c of (last window position of c' + 1 + fragment_length),
+// and G(r) = base[rec_seq[r]] + rec_wpos[r].  Records are ordered by (contig, window), so G grows with the record number;
+// inside a contig G differences ARE window differences, and two records of different contigs are at least a fragment
+// length apart -- "same contig and wb - wa < fragment_length" (computeL1CandidateRegions) is ONE unsigned compare of a G
+// difference, with no contig number per seed hit.  rec_gpos keeps the low 32 bits (4 bytes gathered per hit where
+// (seqId, wpos) took 8); the high word of G(r) is the number of entries of wrap_rec (first record of every 2^32 boundary
+// crossed, a handful for the largest index HBM holds) that are <= r.
+constexpr int GPOS_MAX_WRAPS = 256;
+__global__ void k_contig_span(const int32_t *contig_rec, const int32_t *rec_wpos, int C, int pad, unsigned long long *span) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  unsigned long long v = 0;
+  if (c < C) {
+    const int lo = contig_rec[c], hi = contig_rec[c + 1];
+    v = (unsigned long long)(hi > lo ? rec_wpos[hi - 1] + 1 : 0) + (unsigned long long)pad;
+  }
+  span[c] = v;
+}
+__global__ void k_rec_gpos(const int32_t *rec_seq, const int32_t *rec_wpos, const unsigned long long *contig_base, int64_t N,
+                           uint32_t *rec_gpos, uint32_t *wrap_rec, int32_t *n_wraps) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const unsigned long long g = contig_base[rec_seq[i]] + (unsigned long long)rec_wpos[i];
+  rec_gpos[i] = (uint32_t)g;
+  const uint32_t hi = (uint32_t)(g >> 32);
+  const uint32_t hi_prev = i ? (uint32_t)((contig_base[rec_seq[i - 1]] + (unsigned long long)rec_wpos[i - 1]) >> 32) : 0u;
+  for (uint32_t h = hi_prev + 1; h <= hi; h++) if (h - 1 < (uint32_t)GPOS_MAX_WRAPS) wrap_rec[h - 1] = (uint32_t)i;
+  if (i == N - 1) *n_wraps = (int32_t)hi;
 }
 
 // The same geometry packed for the hot loop of k_l2_events (fewer bytes per record, ONE load and one address per record):
@@ -200,7 +226,9 @@ struct IndexView {
   const uint8_t *rec_flags;
   const uint2 *rec_hg;          // (hash, packed geometry) (k_pack_geometry), null when cmw is too large for it
   const uint16_t *rec_prev16;
-  const int2 *rec_sw;           // (rec_seq, rec_wpos) interleaved: one 8-byte gather per seed hit in k_l1
+  const uint32_t *rec_gpos;     // low word of the padded global coordinate (k_rec_gpos): one 4-byte gather per seed hit in k_l1
+  const uint32_t *wrap_rec;     // [n_wraps] first record behind every 2^32 boundary of that coordinate
+  int32_t n_wraps;
 #ifdef FA_EXPERIMENTS
   const uint32_t *ev_bits;      // merged admit / drop order of the L2 slide, one bit per event (k_event_bits)
   const uint2 *rec_hf;          // (hash, flags | distance to the previous record of the hash << 8) for k_l2_fused
@@ -219,6 +247,14 @@ struct IndexView {
   int32_t freq_threshold;
   int32_t total_bins;
 };
+
+// padded global coordinate of record r (lo = rec_gpos[r], fetched by the caller)
+__device__ __forceinline__ uint64_t gpos_make(const IndexView &ix, uint32_t r, uint32_t lo) {
+  uint32_t hi = 0;
+  for (int w = 0; w < ix.n_wraps; w++) hi += r >= ix.wrap_rec[w] ? 1u : 0u;   // (uniform loop, scalar loads; no trip below 4.29 Gbases)
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t gpos_of(const IndexView &ix, uint32_t r) { return gpos_make(ix, r, ix.rec_gpos[r]); }
 
 // position list of hash h: true if present; off / cnt receive the CSR slice
 __device__ __forceinline__ bool index_find(const IndexView &ix, uint32_t h, uint32_t &off, uint32_t &cnt) {
@@ -569,6 +605,8 @@ struct L1Args {
   uint64_t scratch_words;        // capacity of ovf_buf
   int32_t qcap, frag_len, l_cap;
   uint32_t lds_seed_cap;
+  unsigned long long *dbg;       // [8] FA_L1_STATS=1: ticks of the phases of k_l1
+  int32_t block_sort;            // k_l1: bit 0 = try l1_block_sort before the merge (FA_L1_BLOCK_SORT=0 switches it off), bit 1 = count the roads taken
   uint8_t *big_state;            // [F] k_l1_big: 1 = this fragment was handled there, 0 = not (k_l1 takes it)
   int32_t big_enabled;           // k_l1_big ran before k_l1 in this pass
   uint32_t big_cap;              // seed hits per chunk of k_l1_big (<= L1_BIG_E x L1_BIG_THREADS)
@@ -585,6 +623,140 @@ __host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_sma
 }
 __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int nt) {
   return l1_stage_offset(seed_cap, lut_smax, nt) + (size_t)L1_STAGE * 6 * 4;
+}
+
+// Sorting the seed hits of a fragment WITHOUT merging them, for the regime the workloads live in: the hits of a fragment are
+// record numbers, records are ordered by (contig, window), and a query fragment that has relatives in the index finds them in
+// a few dozen STRETCHES of consecutive records (one per related genome, about a fragment's worth of records each) -- 4 000
+// hits fall into some 450 blocks of 32 consecutive records.  So the hits are not sorted, their blocks are:
+//   1. every hit sets its bit in an open-addressing LDS table {block number + 1, 32-bit bitmap} (one returning and one
+//      plain LDS atomic per hit; a record sits in one position list only, so no bit is set twice);
+//   2. the occupied entries are compacted in place (through registers) and bitonic-sorted by block number -- a few hundred
+//      8-byte entries, most stages local to a wave;
+//   3. a prefix sum over the bitmaps' population counts gives every entry its place, and the bits are expanded into the
+//      sorted array of record numbers -- the array the merge produces, bit for bit, for about a fifth of the instructions
+//      (eight merge levels cost ~330 vector instructions per thread and level at 8-9 hits per thread).
+// Table, compacted entries and the sorted hits share the LDS of the seed slots (table = half as many entries as slots).
+// Returns false -- the caller then gathers and merges as before -- when the hits are too scattered for the table (a probe
+// sequence longer than BS_MAX_PROBES) or the counts do not add up.  The verdict is uniform over the workgroup.
+constexpr uint32_t BS_MAX_PROBES = 48;
+template <int NT, int SPT>
+__device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n, uint32_t cap, uint32_t *A, const uint32_t *off, const uint32_t *qo) {
+  __shared__ uint32_t bs_fail, bs_total;
+  __shared__ uint32_t bs_wsum[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t lg = 31u - (uint32_t)__clz((int)(cap >> 1));            // table entries: the largest power of two <= cap / 2
+  const uint32_t capT = 1u << lg, mask = capT - 1u;
+  uint2 *T = (uint2 *)A;
+  const bool dbg = (a.block_sort & 2) && tid == 0;
+  long long tk = dbg ? clock64() : 0;
+  auto phase = [&](int k) __attribute__((always_inline)) {
+    if (dbg) { const long long now = clock64(); atomicAdd(&a.dbg[k], (unsigned long long)(now - tk)); tk = now; }
+  };
+  for (uint32_t i = tid; i < capT; i += NT) T[i] = make_uint2(0u, 0u);
+  if (tid == 0) bs_fail = 0;
+  __syncthreads();
+  // ---- 1. the hits, flat: hit i of the fragment is entry i - off[j] of list j (off = prefix sums of the list lengths, qo = where
+  //      every list starts in the index; the caller left both in LDS).  Four hits per thread and trip, so that four index
+  //      reads are in flight: the workgroup's time is a chain of memory round trips, not instructions ----
+  {
+    auto locate = [&](uint32_t i) __attribute__((always_inline)) {
+      int lo = 0, hi = s - 1;                                              // the list j with off[j] <= i < off[j + 1]
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid + 1] <= i) lo = mid + 1; else hi = mid; }
+      return lo;
+    };
+    auto place = [&](uint32_t r) __attribute__((always_inline)) {
+      const uint32_t key1 = (r >> 5) + 1u, bit = 1u << (r & 31u);
+      uint32_t h = ((r >> 5) * 0x9E3779B1u) >> (32u - lg);
+      for (uint32_t probes = 0;; probes++) {
+        const uint32_t old = atomicCAS(&T[h].x, 0u, key1);
+        if (old == 0u || old == key1) { atomicOr(&T[h].y, bit); break; }
+        if (probes >= BS_MAX_PROBES) { bs_fail = 1; break; }
+        h = (h + 1u) & mask;
+      }
+    };
+    for (uint32_t i0 = tid; i0 < n; i0 += 4 * NT) {
+      uint32_t r[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t i = i0 + (uint32_t)u * NT;
+        r[u] = 0;
+        if (i < n) { const int j = locate(i); r[u] = a.ix.pos_ridx[qo[j] + (i - off[j])]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (i0 + (uint32_t)u * NT < n) place(r[u]);
+      if (*(volatile uint32_t *)&bs_fail) break;
+    }
+  }
+  __syncthreads();
+  phase(5);
+  if (bs_fail) { __syncthreads(); return false; }
+  // ---- 2. compaction in place (the table's entries pass through registers), then the sort by block number ----
+  uint2 ent[SPT];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < SPT; q++) {
+    const uint32_t slot = (uint32_t)q * NT + tid;
+    ent[q] = slot < capT ? T[slot] : make_uint2(0u, 0u);
+    mine += ent[q].x != 0u ? 1u : 0u;
+  }
+  auto block_exclusive = [&](uint32_t v, uint32_t &total) __attribute__((always_inline)) {
+    uint32_t incl = v;
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) bs_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - v, tot = 0;
+    for (int q = 0; q < NT / 64; q++) { const uint32_t w = bs_wsum[q]; base += q < wv ? w : 0u; tot += w; }
+    total = tot;
+    __syncthreads();
+    return base;
+  };
+  uint32_t nb = 0;
+  uint32_t at = block_exclusive(mine, nb);                               // (its barriers also end the reads of the table)
+  uint32_t nb32 = 64; while (nb32 < nb) nb32 <<= 1;                      // (nb <= capT, a power of two >= 512)
+  uint2 *K = T;
+#pragma unroll
+  for (int q = 0; q < SPT; q++) if (ent[q].x != 0u) K[at++] = ent[q];
+  for (uint32_t i = nb + tid; i < nb32; i += NT) K[i] = make_uint2(0xFFFFFFFFu, 0u);
+  __syncthreads();
+  phase(6);
+  for (uint32_t size = 2; size <= nb32; size <<= 1) {
+    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+      for (uint32_t t = tid; t < nb32 / 2; t += NT) {
+        const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint2 x = K[lo], y = K[hi];
+        if ((x.x > y.x) == up) { K[lo] = y; K[hi] = x; }
+      }
+      // comparators 64 w .. 64 w + 63 work inside entries 128 w .. 128 w + 127 while the stride is <= 64: those stages only
+      // need the wave's own LDS order; a stage with a longer stride is fenced off by workgroup barriers on both sides
+      const uint32_t next = stride > 1 ? stride >> 1 : size;              // stride of the stage that follows
+      if (stride > 64 || next > 64) __syncthreads();
+      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+    }
+  }
+  __syncthreads();
+  phase(7);
+  // ---- 3. places from the population counts, bits expanded into the sorted record numbers ----
+  const uint32_t ept = nb32 >= (uint32_t)NT ? nb32 / NT : 1u;            // entries per thread, consecutive (<= SPT)
+  uint32_t bits_mine = 0;
+#pragma unroll
+  for (int q = 0; q < SPT; q++) {
+    const uint32_t e = (uint32_t)tid * ept + q;
+    ent[q] = ((uint32_t)q < ept && e < nb) ? K[e] : make_uint2(0u, 0u);
+    bits_mine += __popc(ent[q].y);
+  }
+  uint32_t total = 0;
+  uint32_t o = block_exclusive(bits_mine, total);                        // (barriers: every entry is in registers now)
+  if (total != n) return false;                                          // (cannot happen: a record sits in one list only)
+#pragma unroll
+  for (int q = 0; q < SPT; q++) {
+    uint32_t bits = ent[q].y;
+    const uint32_t first = (ent[q].x - 1u) << 5;
+    while (bits) { A[o++] = first | (uint32_t)(__ffs((int)bits) - 1); bits &= bits - 1u; }
+  }
+  __syncthreads();
+  return true;
 }
 
 // NT threads per workgroup (256 measured best: wider workgroups pay more for the cross-wave scans and barriers).
@@ -604,7 +776,8 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   // candidate pass: running head count and the last flagged candidate so far, double-buffered by trip parity so that
   // thread 0 can publish the next trip's values while slower waves still read this trip's
   __shared__ uint32_t sh_heads[2];
-  __shared__ int sh_prev_seq[2], sh_prev_wa[2], sh_has_prev[2];
+  __shared__ int sh_has_prev[2];
+  __shared__ uint64_t sh_prev_g[2];
   __shared__ uint32_t sh_base, sh_gbase, sh_grp;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
@@ -618,6 +791,11 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   const bool in_lds = n <= a.lds_seed_cap;                               // (the host keeps lds_seed_cap <= E x NT)
   if (!in_lds && (uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;   // SPEC_SCRATCH, same
   uint32_t *seeds;
+  const bool l1_dbg = (a.block_sort & 2) && tid == 0;
+  long long tk = l1_dbg ? clock64() : 0;
+  auto phase = [&](int k) __attribute__((always_inline)) {
+    if (l1_dbg) { const long long now = clock64(); atomicAdd(&a.dbg[k], (unsigned long long)(now - tk)); tk = now; }
+  };
   if (in_lds) {
     // ---- the position lists of the query minimizers are each sorted already (CSR order = record order): gather them
     //      back to back and merge them pairwise, bottom-up (record indices are unique: no ties).  A run is a group of
@@ -644,6 +822,12 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     }
     if (tid == 0) off[s] = n;
     __syncthreads();
+    phase(0);
+    // hits that cluster in stretches of the index (the usual case) are sorted block-wise: l1_block_sort
+    const bool block_sorted = (a.block_sort & 1) && cap >= 1024u && l1_block_sort<NT, E / 2>(a, s, n, cap, A, off, qo);
+    if ((a.block_sort & 2) && tid == 0) atomicAdd(&a.counters[block_sorted ? 5 : 6], 1u);   // FA_L1_STATS=1: which road the fragments took
+    phase(1);
+    if (!block_sorted) {
     // flat gather, two elements per thread and trip so that two index reads are in flight
     auto locate = [&](uint32_t i) __attribute__((always_inline)) {
       int lo = 0, hi = s - 1;                                              // the list j with off[j] <= i < off[j + 1]
@@ -716,6 +900,8 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       }
       __syncthreads();
     }
+    }
+    phase(2);
     seeds = A;
   } else {
     // ---- more seed hits than LDS holds: lists gathered into HBM scratch and sorted there ----
@@ -752,29 +938,33 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   const int len = a.frag_len;
 
   // ---- ordered passes over the candidates.  Pass 0 merges them into loci held in LDS (up to L1_STAGE per fragment) and
-  //      is normally the only one; if a fragment has more loci, pass 0 only counted and pass 1 writes them to HBM. ----
+  //      is normally the only one; if a fragment has more loci, pass 0 only counted and pass 1 writes them to HBM.
+  //      A seed is handled as its padded global coordinate G (k_rec_gpos): "same contig and wb - wa < len" is Gb - Ga < len,
+  //      "the previous candidate's end reaches this one's start" is Gb - Gprev < len (the previous flagged seed precedes
+  //      this one, so it shares the contig of the partner iff it shares this seed's).  A locus is carried as three record
+  //      numbers -- its first seed, that seed's partner, its last flagged seed -- and turned into (contig, start, end) once,
+  //      at the end: 4 bytes gathered per hit instead of 8, three gathers per locus. ----
   int32_t *st_seq = (int32_t *)(lds + l1_stage_offset(a.lds_seed_cap, a.lut_smax, NT));   // [L1_STAGE] each
   int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
   int32_t *st_rpart = st_rlast + L1_STAGE;
-  for (int i = tid; i < L1_STAGE; i += NT) { st_end[i] = 0; st_rlast[i] = 0; }
-  int2 *sw_trip = (int2 *)(lds + l1_off_offset(a.lds_seed_cap));        // [NT] (the list offsets are no longer needed)
+  for (int i = tid; i < L1_STAGE; i += NT) st_rlast[i] = 0;
+  uint64_t *g_trip = (uint64_t *)(lds + l1_off_offset(a.lds_seed_cap));  // [NT] (the list offsets are no longer needed)
+  const uint64_t len64 = (uint64_t)len;
   for (int pass = 0; pass < 2; pass++) {
-    if (tid == 0) { sh_heads[0] = 0; sh_has_prev[0] = 0; sh_prev_seq[0] = -1; sh_prev_wa[0] = 0; }
+    if (tid == 0) { sh_heads[0] = 0; sh_has_prev[0] = 0; sh_prev_g[0] = 0; }
     __syncthreads();
     int par = 0;
-    // (contig, window) of the seed this thread owns in the first trip; later trips are fetched one trip ahead
+    // coordinate of the seed this thread owns in the first trip; later trips are fetched one trip ahead
     uint32_t ra_n = (uint32_t)tid < n ? seeds[tid] : 0u;
-    int2 sw_n = (uint32_t)tid < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
+    uint32_t lo_n = (uint32_t)tid < n ? a.ix.rec_gpos[ra_n] : 0u;
     for (uint32_t i0 = 0; i0 < ncand; i0 += NT) {
       uint32_t i = i0 + tid;
-      bool flag = false;
-      int start = 0;
-      // every lane fetches (contig, window) of its own seed once and leaves them in LDS for its wave: the partner seed
+      // every lane fetches the coordinate of its own seed once and leaves it in LDS for its wave: the partner seed
       // i+m-1 and the previous flagged candidate are other lanes' seeds (an 8-byte LDS read each where a `__shfl` -- a
       // ds_bpermute, ~18 cycles of the CU's LDS pipe -- per word cost a fifth of this kernel)
       const uint32_t ra = ra_n;
-      const int seq = sw_n.x, wa = sw_n.y;
-      sw_trip[tid] = make_int2(seq, wa);
+      const uint64_t ga = gpos_make(a.ix, ra, lo_n);
+      g_trip[tid] = ga;
       // (the slots written above are read below by OTHER lanes of the same wave only: order the store before those reads
       // explicitly -- no instruction on gfx950, where a wave's LDS operations complete in order -- instead of relying on it)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -782,29 +972,28 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       if (i0 + NT < ncand) {
         const uint32_t in = i + NT;
         ra_n = in < n ? seeds[in] : 0u;
-        sw_n = in < n ? a.ix.rec_sw[ra_n] : make_int2(-1, 0);
+        lo_n = in < n ? a.ix.rec_gpos[ra_n] : 0u;
       }
       const int rb = i < ncand ? (int)seeds[i + m - 1] : 0;               // record of the partner seed: it fixes the locus start
-      int2 swb = sw_trip[min(tid + m - 1, NT - 1)];                        // (read by its own wave only: LDS keeps a wave's order)
-      if (lane + m - 1 >= 64 && i < ncand) swb = a.ix.rec_sw[rb];
-      const int seqb = swb.x, wb = swb.y;
-      if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
+      uint64_t gb = g_trip[min(tid + m - 1, NT - 1)];                      // (read by its own wave only: LDS keeps a wave's order)
+      if (lane + m - 1 >= 64 && i < ncand) gb = gpos_of(a.ix, (uint32_t)rb);
+      const bool flag = i < ncand && gb - ga < len64;
       // previous flagged candidate (in order): inside the wave, else earlier waves, else the carry
       uint64_t bal = __ballot(flag);
-      __shared__ int w_last_seq[2][NT / 64], w_last_wa[2][NT / 64], w_any[2][NT / 64];
+      __shared__ uint64_t w_last_g[2][NT / 64];
+      __shared__ int w_any[2][NT / 64];
       uint64_t below = bal & ((1ULL << lane) - 1ULL);
       int src_lane = below ? 63 - __clzll(below) : -1;
-      const int2 swp = sw_trip[(tid & ~63) + max(src_lane, 0)];
-      int p_seq = swp.x, p_wa = swp.y;
+      uint64_t gp = g_trip[(tid & ~63) + max(src_lane, 0)];
       if (lane == 0) w_any[par][wv] = bal != 0;
-      if (bal && lane == 63 - __clzll(bal)) { w_last_seq[par][wv] = seq; w_last_wa[par][wv] = wa; }
+      if (bal && lane == 63 - __clzll(bal)) w_last_g[par][wv] = ga;
       __syncthreads();
       bool has_prev = src_lane >= 0;
       if (!has_prev) {
-        for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[par][q]) { has_prev = true; p_seq = w_last_seq[par][q]; p_wa = w_last_wa[par][q]; }
-        if (!has_prev && sh_has_prev[par]) { has_prev = true; p_seq = sh_prev_seq[par]; p_wa = sh_prev_wa[par]; }
+        for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[par][q]) { has_prev = true; gp = w_last_g[par][q]; }
+        if (!has_prev && sh_has_prev[par]) { has_prev = true; gp = sh_prev_g[par]; }
       }
-      bool head = flag && !(has_prev && p_seq == seq && p_wa >= start);
+      bool head = flag && !(has_prev && gb - gp < len64);
       // inclusive scan of heads -> slot of the locus every flagged candidate belongs to
       uint64_t hb = __ballot(head);
       __shared__ uint32_t w_heads[NT / 64];
@@ -819,13 +1008,13 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
         if (pass == 0) {
           if (slot <= (uint32_t)L1_STAGE) {
-            if (head) { st_seq[slot - 1] = seq; st_start[slot - 1] = start; st_rfirst[slot - 1] = (int32_t)ra; st_rpart[slot - 1] = rb; }
-            if (last_here) { atomicMax(&st_end[slot - 1], wa); atomicMax(&st_rlast[slot - 1], (int32_t)ra); }
+            if (head) { st_rfirst[slot - 1] = (int32_t)ra; st_rpart[slot - 1] = rb; }
+            if (last_here) atomicMax(&st_rlast[slot - 1], (int32_t)ra);
           }
         } else {
           uint32_t li = sh_base + slot - 1;
-          if (head) { a.l_frag[li] = f; a.l_seq[li] = seq; a.l_start[li] = start; a.l_rfirst[li] = (int32_t)ra; a.l_rpart[li] = rb; }
-          if (last_here) { atomicMax(&a.l_end[li], wa); atomicMax(&a.l_rlast[li], (int32_t)ra); }
+          if (head) { a.l_frag[li] = f; a.l_rfirst[li] = (int32_t)ra; a.l_rpart[li] = rb; }
+          if (last_here) atomicMax(&a.l_rlast[li], (int32_t)ra);
         }
       }
       if (tid == 0) {
@@ -833,13 +1022,15 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         uint32_t tot = sh_heads[par];
         for (int q = 0; q < NT / 64; q++) tot += w_heads[q];
         sh_heads[par ^ 1] = tot;
-        int hp = sh_has_prev[par], ps = sh_prev_seq[par], pw = sh_prev_wa[par];
-        for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[par][q]) { hp = 1; ps = w_last_seq[par][q]; pw = w_last_wa[par][q]; break; }
-        sh_has_prev[par ^ 1] = hp; sh_prev_seq[par ^ 1] = ps; sh_prev_wa[par ^ 1] = pw;
+        int hp = sh_has_prev[par];
+        uint64_t pg = sh_prev_g[par];
+        for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[par][q]) { hp = 1; pg = w_last_g[par][q]; break; }
+        sh_has_prev[par ^ 1] = hp; sh_prev_g[par ^ 1] = pg;
       }
       par ^= 1;
     }
     __syncthreads();
+    phase(3);
     if (pass == 0) {
       const uint32_t cnt0 = sh_heads[par];
       if (cnt0 > 0 && cnt0 <= (uint32_t)L1_STAGE) {
@@ -848,6 +1039,13 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         // adjacent counters -- thousands of workgroups queue up on that address for ~12 ns each, and two reservations
         // per workgroup cost k_l1 11 of its 96 us.
         uint32_t *st_grp = (uint32_t *)(lds + l1_off_offset(a.lds_seed_cap));   // (the list offsets are no longer needed)
+        // (contig, start, end) of every locus from its three records
+        for (uint32_t q = tid; q < cnt0; q += NT) {
+          st_seq[q] = a.ix.rec_seq[st_rfirst[q]];
+          st_start[q] = max(0, a.ix.rec_wpos[st_rpart[q]] - len + 1);
+          st_end[q] = a.ix.rec_wpos[st_rlast[q]];
+        }
+        __syncthreads();
         if (wv == 0) {
           uint32_t run = 0;
           for (uint32_t i0 = 0; i0 < cnt0; i0 += 64) {
@@ -876,6 +1074,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
           a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q]; a.l_rpart[li] = st_rpart[q];
           a.l_group[li] = (int32_t)(sh_grp + st_grp[q]);
         }
+        phase(4);
         return;
       }
       // more loci than the stage holds (or none): reserve, then a second pass writes them straight to HBM
@@ -891,10 +1090,19 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       if (sh_gbase == 0) return;
     }
   }
-  // ---- groups: consecutive loci of this fragment on the same reference genome ----
+  // ---- (contig, start, end) of the loci written by pass 1, then the groups: consecutive loci of this fragment on the same
+  //      reference genome ----
   __threadfence_block();
   __syncthreads();
   const uint32_t nl = sh_gbase, base = sh_base;
+  for (uint32_t q = tid; q < nl; q += NT) {
+    const uint32_t li = base + q;
+    a.l_seq[li] = a.ix.rec_seq[a.l_rfirst[li]];
+    a.l_start[li] = max(0, a.ix.rec_wpos[a.l_rpart[li]] - len + 1);
+    a.l_end[li] = a.ix.rec_wpos[a.l_rlast[li]];
+  }
+  __threadfence_block();
+  __syncthreads();
   if (wv == 0) {
     uint32_t run = 0, gbase = 0;
     // count groups first
@@ -943,7 +1151,8 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   __shared__ uint32_t sh_scan[NT / 64], sh_min[NT / 64], sh_first[NT / 64];
   __shared__ uint32_t sh_run, sh_loci, sh_firstrem, sh_bound, sh_base, sh_cnt;
-  __shared__ int sh_prev_seq, sh_prev_wa, sh_has_prev, sh_fail, sh_last;
+  __shared__ int sh_has_prev, sh_fail, sh_last;
+  __shared__ uint64_t sh_prev_g;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
   const uint32_t n = a.n_seeds[f];
@@ -956,11 +1165,12 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   uint32_t *off = (uint32_t *)(lds + ((size_t)cap * 4 + 15) / 16 * 16);  // [s + 1] first hit of every list inside the chunk
   uint32_t *qo = off + a.lut_smax + 2;                                   // [s] where the chunk's part of every list starts in the index
   uint32_t *cur = qo + a.lut_smax + 2, *nxt = cur + a.lut_smax + 2;      // [s] cursor of every list, and its value after the chunk
-  // loci collected in the fragment's scratch: five arrays of LC entries
+  // loci collected in the fragment's scratch as three record numbers each (first seed, its partner, last flagged seed: see
+  // k_l1), arrays of LC entries
   const uint32_t LC = n32 / 5;
   int32_t *S = (int32_t *)(a.ovf_buf + a.ovf_off[f]);
-  int32_t *S_seq = S, *S_start = S + LC, *S_rfirst = S + 2 * (size_t)LC, *S_end = S + 3 * (size_t)LC, *S_rlast = S + 4 * (size_t)LC;
-  for (uint32_t i = tid; i < LC; i += NT) { S_end[i] = 0; S_rlast[i] = 0; }
+  int32_t *S_rfirst = S, *S_rpart = S + LC, *S_rlast = S + 2 * (size_t)LC;
+  for (uint32_t i = tid; i < LC; i += NT) S_rlast[i] = 0;
   for (int j = tid; j < s; j += NT) cur[j] = 0;
   if (tid == 0) { sh_loci = 0; sh_fail = 0; }
   int m = a.min_hits_lut[s];
@@ -986,7 +1196,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
       for (int q = 0; q < NT / 64; q++) { v = min(v, sh_min[q]); fr = min(fr, sh_first[q]); }
       uint32_t bound = 0xFFFFFFFFu;                                     // everything that is left
       if (v != 0xFFFFFFFFu) {
-        bound = (uint32_t)a.ix.contig_rec[a.ix.rec_sw[v].x];            // first record of the contig that holds v
+        bound = (uint32_t)a.ix.contig_rec[a.ix.rec_seq[v]];             // first record of the contig that holds v
         if (bound <= fr) sh_fail = 1;                                    // that contig alone is too much: cannot cut here
       }
       sh_bound = bound; sh_last = v == 0xFFFFFFFFu; sh_firstrem = fr;
@@ -1084,32 +1294,34 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
     // ---- candidates of the chunk (computeL1CandidateRegions on its sorted hits; nothing carries over a contig start) ----
     if ((uint32_t)m <= nc) {
       const uint32_t ncand = nc - (uint32_t)m + 1;
-      if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_seq = -1; sh_prev_wa = 0; }
+      if (tid == 0) { sh_run = 0; sh_has_prev = 0; sh_prev_g = 0; }
       __syncthreads();
       const uint32_t loci0 = sh_loci;
+      const uint64_t len64 = (uint64_t)len;
       for (uint32_t i0 = 0; i0 < ncand; i0 += NT) {
         const uint32_t i = i0 + tid;
-        bool flag = false;
-        int start = 0, seq = -1, wa = 0;
-        uint32_t ra = 0;
-        if (i < nc) { ra = A[i]; const int2 sw = a.ix.rec_sw[ra]; seq = sw.x; wa = sw.y; }
-        int seqb = __shfl(seq, (lane + m - 1) & 63), wb = __shfl(wa, (lane + m - 1) & 63);
-        if (lane + m - 1 >= 64 && i < ncand) { const int2 swb = a.ix.rec_sw[A[i + m - 1]]; seqb = swb.x; wb = swb.y; }
-        if (i < ncand && seq == seqb && wb - wa < len) { flag = true; start = max(0, wb - len + 1); }
+        uint32_t ra = 0, rb = 0;
+        uint64_t ga = 0;
+        if (i < nc) { ra = A[i]; ga = gpos_of(a.ix, ra); }
+        uint64_t gb = (uint64_t)__shfl((long long)ga, (lane + m - 1) & 63);
+        if (i < ncand) rb = A[i + m - 1];
+        if (lane + m - 1 >= 64 && i < ncand) gb = gpos_of(a.ix, rb);
+        const bool flag = i < ncand && gb - ga < len64;
         uint64_t bal = __ballot(flag);
-        __shared__ int w_last_seq[NT / 64], w_last_wa[NT / 64], w_any[NT / 64];
+        __shared__ uint64_t w_last_g[NT / 64];
+        __shared__ int w_any[NT / 64];
         uint64_t below = bal & ((1ULL << lane) - 1ULL);
         int src_lane = below ? 63 - __clzll(below) : -1;
-        int p_seq = __shfl(seq, src_lane < 0 ? 0 : src_lane), p_wa = __shfl(wa, src_lane < 0 ? 0 : src_lane);
+        uint64_t gp = (uint64_t)__shfl((long long)ga, src_lane < 0 ? 0 : src_lane);
         if (lane == 0) w_any[wv] = bal != 0;
-        if (bal && lane == 63 - __clzll(bal)) { w_last_seq[wv] = seq; w_last_wa[wv] = wa; }
+        if (bal && lane == 63 - __clzll(bal)) w_last_g[wv] = ga;
         __syncthreads();
         bool has_prev = src_lane >= 0;
         if (!has_prev) {
-          for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[q]) { has_prev = true; p_seq = w_last_seq[q]; p_wa = w_last_wa[q]; }
-          if (!has_prev && sh_has_prev) { has_prev = true; p_seq = sh_prev_seq; p_wa = sh_prev_wa; }
+          for (int q = wv - 1; q >= 0 && !has_prev; q--) if (w_any[q]) { has_prev = true; gp = w_last_g[q]; }
+          if (!has_prev && sh_has_prev) { has_prev = true; gp = sh_prev_g; }
         }
-        bool head = flag && !(has_prev && p_seq == seq && p_wa >= start);
+        bool head = flag && !(has_prev && gb - gp < len64);
         uint64_t hb = __ballot(head);
         __shared__ uint32_t w_heads[NT / 64];
         if (lane == 0) w_heads[wv] = __popcll(hb);
@@ -1121,8 +1333,8 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
           const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
           const uint32_t li = loci0 + slot - 1;
           if (li < LC) {
-            if (head) { S_seq[li] = seq; S_start[li] = start; S_rfirst[li] = (int32_t)ra; }
-            if (last_here) { atomicMax(&S_end[li], wa); atomicMax(&S_rlast[li], (int32_t)ra); }
+            if (head) { S_rfirst[li] = (int32_t)ra; S_rpart[li] = (int32_t)rb; }
+            if (last_here) atomicMax(&S_rlast[li], (int32_t)ra);
           } else sh_fail = 1;                                           // more loci than the scratch holds
         }
         __syncthreads();
@@ -1130,7 +1342,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
           uint32_t tot = 0;
           for (int q = 0; q < NT / 64; q++) tot += w_heads[q];
           sh_run += tot;
-          for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_seq = w_last_seq[q]; sh_prev_wa = w_last_wa[q]; break; }
+          for (int q = NT / 64 - 1; q >= 0; q--) if (w_any[q]) { sh_has_prev = 1; sh_prev_g = w_last_g[q]; break; }
         }
         __syncthreads();
       }
@@ -1157,8 +1369,9 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   const uint32_t nl = sh_cnt, base = sh_base;
   for (uint32_t q = tid; q < nl; q += NT) {
     const uint32_t li = base + q;
-    a.l_frag[li] = f; a.l_seq[li] = S_seq[q]; a.l_start[li] = S_start[q]; a.l_rfirst[li] = S_rfirst[q]; a.l_rpart[li] = -1;
-    a.l_end[li] = S_end[q]; a.l_rlast[li] = S_rlast[q];
+    const int32_t rf = S_rfirst[q], rp = S_rpart[q], rl = S_rlast[q];
+    a.l_frag[li] = f; a.l_seq[li] = a.ix.rec_seq[rf]; a.l_start[li] = max(0, a.ix.rec_wpos[rp] - len + 1); a.l_rfirst[li] = rf; a.l_rpart[li] = rp;
+    a.l_end[li] = a.ix.rec_wpos[rl]; a.l_rlast[li] = rl;
   }
   __threadfence_block();
   __syncthreads();

@@ -1328,20 +1328,62 @@ def test_fused_query_sketch_overflow_falls_back(monkeypatch):
     query = [syn.to_ascii(syn.mutate_codes(g, anc, 0.04))]
     mapper, hits, ohits, det = run_both({}, refs, query)              # fused (the default where it applies)
     assert gpu_mappings(mapper) == oracle_mappings(det) and hit_tuples(hits) == ohits and len(ohits) == 2
-    ms = (C.c_float * 16)()
+    ms = (C.c_float * 24)()
 
     def again():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             h = mapper.query_draft(query)
-        lib.fa_mapper_last_timings(mapper._h, ms, 16)
-        return hit_tuples(h), int(ms[9])
+        lib.fa_mapper_last_timings(mapper._h, ms, 24)
+        return hit_tuples(h), int(ms[9]), (int(ms[17]), int(ms[18]))   # hits, void attempts, parts accepted (fused, two kernels)
 
-    assert again() == (ohits, 0)                                      # (the first call had sized the workspace)
+    assert again() == (ohits, 0, (1, 0))                              # (the first call had sized the workspace)
     monkeypatch.setenv("FA_QF_CAP", "100")
-    h, repeats = again()
-    assert repeats >= 1, "the fused launch should have been voided"
+    h, repeats, how = again()
+    assert repeats >= 1 and how == (0, 1), "the fused launch should have been voided and its range repeated through the two kernels"
     assert h == ohits and gpu_mappings(mapper) == oracle_mappings(det)
-    assert again() == (ohits, 0)                                      # the mapper remembers: straight through the two kernels
+    # ONE overflow is no verdict on the mapper: the next query -- an ordinary one -- runs k_query_fused again
     monkeypatch.delenv("FA_QF_CAP")
-    assert again() == (ohits, 0)
+    assert again() == (ohits, 0, (1, 0))
+    # overflows in a row back off: the second one makes the mapper skip the fused form for one pass, ...
+    monkeypatch.setenv("FA_QF_CAP", "100")
+    assert again() == (ohits, 1, (0, 1))
+    assert again() == (ohits, 1, (0, 1))
+    assert again() == (ohits, 0, (0, 1))                              # (served: straight through the two kernels, nothing void)
+    assert again() == (ohits, 1, (0, 1))                              # tried again, overflowed again: three passes to skip now
+    for _ in range(3):
+        assert again() == (ohits, 0, (0, 1))
+    # ... and a fused pass that is accepted clears the record
+    monkeypatch.delenv("FA_QF_CAP")
+    assert again() == (ohits, 0, (1, 0))
+    monkeypatch.setenv("FA_QF_CAP", "100")
+    assert again() == (ohits, 1, (0, 1))
+    monkeypatch.delenv("FA_QF_CAP")
+    assert again() == (ohits, 0, (1, 0))
+
+
+def test_batches_of_tiny_genomes_keep_the_identity_workgroup_order():
+    # The offset-major workgroup order of k_l2_events deals groups of equal fragment offset to the eight XCDs.  A batch of
+    # plasmid-sized genomes (one to three fragments each) has fewer groups than XCDs: the order would put every real workgroup
+    # on one or two XCDs behind a grid that is mostly padding, so such passes keep the identity order (slot [19] of the
+    # timings counts the parts that ran ordered); a batch of larger genomes (16 fragments each) is ordered.  Rows equal the oracle's either way.
+    g = syn.rng(4242)
+    anc = [syn.random_codes(g, 12_500) for _ in range(6)]
+    refs = [[syn.to_ascii(syn.mutate_codes(g, a, 0.03))] for a in anc]
+    tiny = [[syn.to_ascii(syn.mutate_codes(g, anc[i % 6], 0.05)[: 3_100 + 3_000 * (i % 3)])] for i in range(90)]
+    big = [[syn.to_ascii(syn.mutate_codes(g, anc[i % 6], 0.05))] + [syn.to_ascii(syn.mutate_codes(g, anc[(i + 1) % 6], 0.02))] * 3 for i in range(8)]
+    sk, osk = quiet_sketch(pf.Sketch), OracleSketch()
+    for i, r in enumerate(refs):
+        sk.add_draft(i, r); osk.add_draft(i, r)
+    mapper = sk.index(); osk.index()
+    ms = (C.c_float * 24)()
+    for genomes, ordered in ((tiny, 0), (big, 1)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            batch = mapper.upload_genomes(genomes)
+            assert int(batch.total_fragments.sum()) >= 64
+            hits = [hit_tuples(hs) for hs in batch.query()]
+            lib.fa_mapper_last_timings(mapper._h, ms, 24)
+            want = [osk.query_draft(c, threads=8) for c in genomes]
+        assert hits == want
+        assert int(ms[19]) == ordered, (ordered, list(ms)[17:20])
