@@ -3,20 +3,11 @@
 
 #include <hip/hip_runtime.h>
 
-#include <cstdint>
-#include <cstdio>
-#include <stdexcept>
-#include <string>
-#include <vector>
+#include <algorithm>
 
-#include "../../include/fastani_hip.h"
+#include "fa_error.h"
 
 namespace fa {
-
-struct Error : std::runtime_error {
-  int code;
-  Error(int c, const std::string &msg) : std::runtime_error(msg), code(c) {}
-};
 
 inline void hip_check(hipError_t e, const char *what, const char *file, int line) {
   if (e != hipSuccess) {
@@ -28,7 +19,6 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
   }
 }
 #define FA_HIP(x) ::fa::hip_check((x), #x, __FILE__, __LINE__)
-#define FA_REQUIRE(cond, code, msg) do { if (!(cond)) throw ::fa::Error((code), (msg)); } while (0)
 
 // Owning device array with geometric growth; contents are preserved on growth only when asked.
 template <typename T>
@@ -69,12 +59,5 @@ struct DevBuf {
     if (n) FA_HIP(hipMemcpyAsync(dst, p, n * sizeof(T), hipMemcpyDeviceToHost, stream));
   }
 };
-
-inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
-inline uint32_t next_pow2(uint32_t v) {
-  uint32_t p = 1;
-  while (p < v) p <<= 1;
-  return p;
-}
 
 }  // namespace fa

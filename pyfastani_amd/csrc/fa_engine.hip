@@ -22,6 +22,7 @@
 
 #include "fa_common.h"
 #include "fa_fasta.h"
+#include "fa_lease.h"
 #include "fa_map.hip.h"
 #include "fa_sketch.hip.h"
 #include "fa_sketch_fast.hip.h"
@@ -383,14 +384,7 @@ static uint32_t ev_regions_for(int64_t F) {
 // host side of k_publish_status: polls for FA_SPIN_US microseconds (default 20 000), then sleeps on the stream
 static void wait_published(const PassStatus *h, uint32_t seq, hipStream_t st) {
   static const uint64_t spin_us = env_u64("FA_SPIN_US", 20000);
-  const auto t0 = std::chrono::steady_clock::now();
-  for (uint64_t it = 0; spin_us; it++) {
-    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return;
-#if defined(__x86_64__)
-    __builtin_ia32_pause();
-#endif
-    if ((it & 255) == 255 && (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() >= spin_us) break;
-  }
+  if (spin_for_seq(&h->seq, seq, spin_us)) return;
   FA_HIP(hipStreamSynchronize(st));
   FA_REQUIRE(__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq, FA_ERR_INTERNAL, "the status of the pass was not published");
 }
@@ -660,12 +654,16 @@ static void build_index(fa_mapper &m) {
       // padded global coordinate of every record (k_rec_gpos): spans of the contigs, their prefix sums, the low words
       DevBuf<unsigned long long> span, base;
       DevBuf<int32_t> d_wraps;
-      span.ensure((size_t)m.C + 2); base.ensure((size_t)m.C + 2); d_wraps.ensure(1);
+      span.ensure((size_t)m.C + 2); d_wraps.ensure(1);
       hipLaunchKernelGGL(k_contig_span, dim3(ceil_div(m.C + 1, 256)), dim3(256), 0, st, m.contig_rec.p, m.rec_wpos.p, m.C, m.P.fragment_length, span.p);
-      bytes = 0;
-      FA_HIP(rocprim::exclusive_scan(nullptr, bytes, span.p, base.p, 0ULL, (size_t)m.C + 1, rocprim::plus<unsigned long long>(), st));
-      temp.ensure(bytes + 16);
-      FA_HIP(rocprim::exclusive_scan(temp.p, bytes, span.p, base.p, 0ULL, (size_t)m.C + 1, rocprim::plus<unsigned long long>(), st));
+      // (the prefix sums on the host: a contig list is small next to the records, and a 64-bit device scan would be the one
+      // kernel of the library that needs scratch memory, which the runtime keeps per stream for good)
+      std::vector<unsigned long long> h_span((size_t)m.C + 1), h_base((size_t)m.C + 1);
+      span.download(h_span.data(), (size_t)m.C + 1, st);
+      FA_HIP(hipStreamSynchronize(st));
+      unsigned long long run = 0;
+      for (int c = 0; c <= m.C; c++) { h_base[(size_t)c] = run; run += h_span[(size_t)c]; }
+      base.upload(h_base, st);
       m.rec_gpos.ensure((size_t)N + 4);
       m.wrap_rec.ensure(GPOS_MAX_WRAPS);
       hipLaunchKernelGGL(k_rec_gpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, base.p, N, m.rec_gpos.p, m.wrap_rec.p, d_wraps.p);
@@ -1380,7 +1378,7 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       const double nf = (double)(h_counters[5] + h_counters[6]);
       fprintf(stderr, "[fa] k_l1 phases, shader-clock ticks per fragment (thread 0):");
       for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", (double)ln.h_status->dbg[i] / nf);
-      fprintf(stderr, "  (%u block-sorted, %u merged)\n", h_counters[5], h_counters[6]);
+      fprintf(stderr, "  (%u block-sorted, %u merged; one workgroup in 64 sampled)\n", h_counters[5], h_counters[6]);
     }
     return true;
   };
@@ -1470,34 +1468,16 @@ static int64_t run_query(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_
   return nrows;
 }
 
-// A query call borrows one workspace of the mapper for its duration (blocks while all are busy).
-struct WorkspaceLease {
-  fa_mapper &m;
-  Workspace *w = nullptr;
-  int index = -1;
-  explicit WorkspaceLease(fa_mapper &mm) : m(mm) {
-    bind_device(m.device);
-    std::unique_lock<std::mutex> lock(m.mtx);
-    for (;;) {
-      for (int i = 0; i < fa_mapper::NWS; i++) if (!m.ws[i].in_use) { index = i; break; }
-      if (index >= 0) break;
-      m.ws_free.wait(lock);
-    }
-    w = &m.ws[index];
-    w->in_use = true;
-    lock.unlock();
-    if (!w->stream && hipStreamCreate(&w->stream) != hipSuccess) {
-      (void)hipGetLastError();
-      w->stream = nullptr;
-      { std::lock_guard<std::mutex> relock(m.mtx); w->in_use = false; }
-      m.ws_free.notify_one();
-      throw Error(FA_ERR_NO_DEVICE, "hipStreamCreate failed");
-    }
-  }
-  ~WorkspaceLease() {
-    { std::lock_guard<std::mutex> lock(m.mtx); w->in_use = false; m.last_ws = index; }
-    m.ws_free.notify_one();
-  }
+// A query call borrows one workspace of the mapper for its duration (blocks while all are busy): fa_lease.h.
+struct WorkspaceLease : Lease<fa_mapper, Workspace> {
+  explicit WorkspaceLease(fa_mapper &mm)
+      : Lease<fa_mapper, Workspace>((bind_device(mm.device), mm), [](Workspace &w) {
+          if (!w.stream && hipStreamCreate(&w.stream) != hipSuccess) {
+            (void)hipGetLastError();
+            w.stream = nullptr;
+            throw Error(FA_ERR_NO_DEVICE, "hipStreamCreate failed");
+          }
+        }) {}
 };
 
 // pack + cut into fragments + tiles + upload.  `reuse` (a batch object whose device buffers are recycled, contents

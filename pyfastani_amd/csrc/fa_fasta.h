@@ -20,8 +20,8 @@
 #include <thread>
 #include <vector>
 
-#include "fa_common.h"
-#include "fa_sketch.hip.h"   // HostPool
+#include "fa_error.h"
+#include "fa_host.h"   // HostPool
 
 namespace fa {
 

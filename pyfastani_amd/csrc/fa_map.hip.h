@@ -631,24 +631,90 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, 
 // hits fall into some 450 blocks of 32 consecutive records.  So the hits are not sorted, their blocks are:
 //   1. every hit sets its bit in an open-addressing LDS table {block number + 1, 32-bit bitmap} (one returning and one
 //      plain LDS atomic per hit; a record sits in one position list only, so no bit is set twice);
-//   2. the occupied entries are compacted in place (through registers) and bitonic-sorted by block number -- a few hundred
-//      8-byte entries, most stages local to a wave;
-//   3. a prefix sum over the bitmaps' population counts gives every entry its place, and the bits are expanded into the
-//      sorted array of record numbers -- the array the merge produces, bit for bit, for about a fifth of the instructions
-//      (eight merge levels cost ~330 vector instructions per thread and level at 8-9 hits per thread).
-// Table, compacted entries and the sorted hits share the LDS of the seed slots (table = half as many entries as slots).
+//   2. the block numbers of the occupied entries -- a few hundred -- are bitonic-sorted in REGISTERS (lane exchanges by DPP /
+//      swizzle, no LDS round trip per stage; bs_sizes);
+//   3. every sorted block number fetches its bitmap back from the table, a prefix sum over the population counts gives it
+//      its place, and the bits are expanded into the sorted array of record numbers -- the array the merge produces, bit
+//      for bit, for a fraction of the instructions and, what counts more in this kernel, of the dependent LDS round trips
+//      (eight merge levels: two binary searches and 8-9 sequential merge steps per thread and level).
+// The table and the sorted hits share the LDS of the seed slots (table = half as many entries as slots); the keys pass through
+// the bytes behind them (list offsets + locus stage).
 // Returns false -- the caller then gathers and merges as before -- when the hits are too scattered for the table (a probe
 // sequence longer than BS_MAX_PROBES) or the counts do not add up.  The verdict is uniform over the workgroup.
+// lane exchange across a power-of-two distance below 64 (the value of lane ^ X)
+template <int X>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+  if constexpr (X == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);        // quad_perm [1,0,3,2]
+  else if constexpr (X == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2,3,0,1]
+  else if constexpr (X < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (X << 10) | 0x1F);           // bit mode: lane ^ X inside 32 lanes
+  else return (uint32_t)__shfl_xor((int)v, 32);
+}
+// one stage (SIZE, STRIDE) of the bitonic network over keys in registers: KPL keys per lane, key j of lane l of wave w at
+// position pos0 + 64 j with pos0 = w x 64 KPL + l
+template <int NT, int KPL, int SIZE, int STRIDE>
+__device__ __forceinline__ void bs_strides(uint32_t (&k)[KPL], uint32_t pos0, bool active, uint32_t *Kk) {
+  if constexpr (STRIDE >= 64 * KPL) {
+    // across wave segments: through the key buffer
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < KPL; j++) Kk[pos0 + (uint32_t)j * 64u] = k[j];
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < KPL; j++) {
+        const uint32_t pos = pos0 + (uint32_t)j * 64u;
+        const uint32_t p = Kk[pos ^ (uint32_t)STRIDE];
+        const bool up = (pos & (uint32_t)SIZE) == 0, lower = (pos & (uint32_t)STRIDE) == 0;
+        k[j] = (up == lower) ? min(k[j], p) : max(k[j], p);
+      }
+    }
+    __syncthreads();
+  } else if constexpr (STRIDE >= 64) {
+    if (active) {
+      constexpr int dj = STRIDE / 64;
+#pragma unroll
+      for (int j = 0; j < KPL; j++) {
+        if ((j & dj) == 0) {
+          const bool up = ((pos0 + (uint32_t)j * 64u) & (uint32_t)SIZE) == 0;
+          const uint32_t x = k[j], y = k[j | dj];
+          const uint32_t lo = min(x, y), hi = max(x, y);
+          k[j] = up ? lo : hi; k[j | dj] = up ? hi : lo;
+        }
+      }
+    }
+  } else {
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < KPL; j++) {
+        const uint32_t pos = pos0 + (uint32_t)j * 64u;
+        const uint32_t p = lane_xor<STRIDE>(k[j]);
+        const bool up = (pos & (uint32_t)SIZE) == 0, lower = (pos & (uint32_t)STRIDE) == 0;
+        k[j] = (up == lower) ? min(k[j], p) : max(k[j], p);
+      }
+    }
+  }
+  if constexpr (STRIDE > 1) bs_strides<NT, KPL, SIZE, STRIDE / 2>(k, pos0, active, Kk);
+}
+template <int NT, int KPL, int SIZE>
+__device__ __forceinline__ void bs_sizes(uint32_t (&k)[KPL], uint32_t pos0, bool active, uint32_t nb32, uint32_t *Kk) {
+  if ((uint32_t)SIZE <= nb32) {                                          // (uniform over the workgroup)
+    bs_strides<NT, KPL, SIZE, SIZE / 2>(k, pos0, active, Kk);
+    if constexpr (SIZE < 64 * KPL * (NT / 64)) bs_sizes<NT, KPL, SIZE * 2>(k, pos0, active, nb32, Kk);
+  }
+}
+
 constexpr uint32_t BS_MAX_PROBES = 48;
-template <int NT, int SPT>
-__device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n, uint32_t cap, uint32_t *A, const uint32_t *off, const uint32_t *qo) {
+template <int NT, int SPT, int KPL>
+__device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n, uint32_t cap, uint32_t *A, const uint32_t *off, const uint32_t *qo,
+                                              uint32_t *Kk, uint32_t kl) {
   __shared__ uint32_t bs_fail, bs_total;
   __shared__ uint32_t bs_wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t lg = 31u - (uint32_t)__clz((int)(cap >> 1));            // table entries: the largest power of two <= cap / 2
   const uint32_t capT = 1u << lg, mask = capT - 1u;
   uint2 *T = (uint2 *)A;
-  const bool dbg = (a.block_sort & 2) && tid == 0;
+  const bool dbg = (a.block_sort & 2) && tid == 0 && (blockIdx.x & 63) == 0;
   long long tk = dbg ? clock64() : 0;
   auto phase = [&](int k) __attribute__((always_inline)) {
     if (dbg) { const long long now = clock64(); atomicAdd(&a.dbg[k], (unsigned long long)(now - tk)); tk = now; }
@@ -691,14 +757,14 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   __syncthreads();
   phase(5);
   if (bs_fail) { __syncthreads(); return false; }
-  // ---- 2. compaction in place (the table's entries pass through registers), then the sort by block number ----
-  uint2 ent[SPT];
+  // ---- 2. the keys of the occupied entries, compacted into the key buffer (the table stays where it is) ----
+  uint32_t keys1[SPT];
   uint32_t mine = 0;
 #pragma unroll
   for (int q = 0; q < SPT; q++) {
     const uint32_t slot = (uint32_t)q * NT + tid;
-    ent[q] = slot < capT ? T[slot] : make_uint2(0u, 0u);
-    mine += ent[q].x != 0u ? 1u : 0u;
+    keys1[q] = slot < capT ? T[slot].x : 0u;
+    mine += keys1[q] != 0u ? 1u : 0u;
   }
   auto block_exclusive = [&](uint32_t v, uint32_t &total) __attribute__((always_inline)) {
     uint32_t incl = v;
@@ -712,48 +778,54 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
     return base;
   };
   uint32_t nb = 0;
-  uint32_t at = block_exclusive(mine, nb);                               // (its barriers also end the reads of the table)
-  uint32_t nb32 = 64; while (nb32 < nb) nb32 <<= 1;                      // (nb <= capT, a power of two >= 512)
-  uint2 *K = T;
+  uint32_t at = block_exclusive(mine, nb);
+  uint32_t nb32 = 64u * KPL; while (nb32 < nb) nb32 <<= 1;               // (whole wave segments of 64 x KPL keys)
+  if (nb32 > kl || nb32 > 64u * KPL * (NT / 64)) return false;           // more blocks than the registers of the sort hold
 #pragma unroll
-  for (int q = 0; q < SPT; q++) if (ent[q].x != 0u) K[at++] = ent[q];
-  for (uint32_t i = nb + tid; i < nb32; i += NT) K[i] = make_uint2(0xFFFFFFFFu, 0u);
+  for (int q = 0; q < SPT; q++) if (keys1[q] != 0u) Kk[at++] = keys1[q];
+  for (uint32_t i = nb + tid; i < nb32; i += NT) Kk[i] = 0xFFFFFFFFu;
   __syncthreads();
   phase(6);
-  for (uint32_t size = 2; size <= nb32; size <<= 1) {
-    for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-      for (uint32_t t = tid; t < nb32 / 2; t += NT) {
-        const uint32_t lo = 2 * t - (t & (stride - 1)), hi = lo + stride;
-        const bool up = (lo & size) == 0;
-        const uint2 x = K[lo], y = K[hi];
-        if ((x.x > y.x) == up) { K[lo] = y; K[hi] = x; }
-      }
-      // comparators 64 w .. 64 w + 63 work inside entries 128 w .. 128 w + 127 while the stride is <= 64: those stages only
-      // need the wave's own LDS order; a stage with a longer stride is fenced off by workgroup barriers on both sides
-      const uint32_t next = stride > 1 ? stride >> 1 : size;              // stride of the stage that follows
-      if (stride > 64 || next > 64) __syncthreads();
-      else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
-    }
-  }
-  __syncthreads();
-  phase(7);
-  // ---- 3. places from the population counts, bits expanded into the sorted record numbers ----
-  const uint32_t ept = nb32 >= (uint32_t)NT ? nb32 / NT : 1u;            // entries per thread, consecutive (<= SPT)
-  uint32_t bits_mine = 0;
+  // ---- 3. bitonic sort of the keys IN REGISTERS: wave w holds keys [w x 64 KPL, (w+1) x 64 KPL), lane l the keys l, 64 + l, ...
+  //      of that segment; strides below 64 are lane exchanges (DPP / swizzle: no LDS memory, no barrier), 64 and up to the
+  //      segment are compare-exchanges between a lane's own registers, and only strides that cross segments go through the
+  //      key buffer (two barriers each: one stage for 512 keys on two waves, none for 256).  The same network stage by
+  //      stage through LDS took a third of this kernel: every stage was an LDS round trip under load ----
+  const uint32_t pos0 = (uint32_t)wv * 64u * KPL + (uint32_t)lane;
+  const bool active = pos0 < nb32;                                       // (uniform per wave)
+  uint32_t k[KPL];
 #pragma unroll
-  for (int q = 0; q < SPT; q++) {
-    const uint32_t e = (uint32_t)tid * ept + q;
-    ent[q] = ((uint32_t)q < ept && e < nb) ? K[e] : make_uint2(0u, 0u);
-    bits_mine += __popc(ent[q].y);
+  for (int j = 0; j < KPL; j++) k[j] = active ? Kk[pos0 + (uint32_t)j * 64u] : 0xFFFFFFFFu;
+  bs_sizes<NT, KPL, 2>(k, pos0, active, nb32, Kk);
+  phase(7);
+  // ---- 4. the bitmap of every sorted key (one more probe of the table), places from the population counts, bits expanded
+  //      into the sorted record numbers ----
+  uint32_t bits[KPL], cnt[KPL], place_of[KPL];
+  uint32_t wave_total = 0;
+#pragma unroll
+  for (int j = 0; j < KPL; j++) {
+    bits[j] = 0;
+    if (active && k[j] != 0xFFFFFFFFu) {
+      uint32_t h = ((k[j] - 1u) * 0x9E3779B1u) >> (32u - lg);
+      while (T[h].x != k[j]) h = (h + 1u) & mask;
+      bits[j] = T[h].y;
+    }
+    cnt[j] = (uint32_t)__popc(bits[j]);
+    uint32_t incl = cnt[j];
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    place_of[j] = wave_total + incl - cnt[j];
+    wave_total += (uint32_t)__shfl((int)incl, 63);
   }
-  uint32_t total = 0;
-  uint32_t o = block_exclusive(bits_mine, total);                        // (barriers: every entry is in registers now)
+  if (lane == 0) bs_wsum[wv] = wave_total;
+  __syncthreads();                                                       // (also: every probe of the table is done)
+  uint32_t base = 0, total = 0;
+  for (int q = 0; q < NT / 64; q++) { const uint32_t w = bs_wsum[q]; base += q < wv ? w : 0u; total += w; }
   if (total != n) return false;                                          // (cannot happen: a record sits in one list only)
 #pragma unroll
-  for (int q = 0; q < SPT; q++) {
-    uint32_t bits = ent[q].y;
-    const uint32_t first = (ent[q].x - 1u) << 5;
-    while (bits) { A[o++] = first | (uint32_t)(__ffs((int)bits) - 1); bits &= bits - 1u; }
+  for (int j = 0; j < KPL; j++) {
+    uint32_t b = bits[j], o = base + place_of[j];
+    const uint32_t first = (k[j] - 1u) << 5;
+    while (b) { A[o++] = first | (uint32_t)(__ffs((int)b) - 1); b &= b - 1u; }
   }
   __syncthreads();
   return true;
@@ -791,7 +863,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   const bool in_lds = n <= a.lds_seed_cap;                               // (the host keeps lds_seed_cap <= E x NT)
   if (!in_lds && (uint64_t)a.ovf_off[f] + n32 > a.scratch_words) return;   // SPEC_SCRATCH, same
   uint32_t *seeds;
-  const bool l1_dbg = (a.block_sort & 2) && tid == 0;
+  const bool l1_dbg = (a.block_sort & 2) && tid == 0 && (f & 63) == 0;     // (one workgroup in 64: the atomics below must not become the workload)
   long long tk = l1_dbg ? clock64() : 0;
   auto phase = [&](int k) __attribute__((always_inline)) {
     if (l1_dbg) { const long long now = clock64(); atomicAdd(&a.dbg[k], (unsigned long long)(now - tk)); tk = now; }
@@ -804,28 +876,37 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     uint32_t *A = (uint32_t *)lds;
     uint32_t *off = (uint32_t *)(lds + l1_off_offset(cap));             // [s + 1] first seed of every list
     uint32_t *qo = off + a.lut_smax + 2;                                 // [s] where every list starts in the index
-    if (tid == 0) sh_run = 0;
-    __syncthreads();
-    for (int j0 = 0; j0 < s; j0 += NT) {
-      const int j = j0 + tid;
-      const uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
-      uint32_t incl = cnt;
-      for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-      if (lane == 63) sh_scan[wv] = incl;
+    auto list_offsets = [&]() __attribute__((always_inline)) {
+      if (tid == 0) sh_run = 0;
       __syncthreads();
-      uint32_t o = sh_run + incl - cnt;
-      for (int q = 0; q < wv; q++) o += sh_scan[q];
-      if (j < s) { off[j] = o; qo[j] = cnt ? a.q_off[(size_t)f * a.qcap + j] : 0u; }
+      for (int j0 = 0; j0 < s; j0 += NT) {
+        const int j = j0 + tid;
+        const uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
+        uint32_t incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63) sh_scan[wv] = incl;
+        __syncthreads();
+        uint32_t o = sh_run + incl - cnt;
+        for (int q = 0; q < wv; q++) o += sh_scan[q];
+        if (j < s) { off[j] = o; qo[j] = cnt ? a.q_off[(size_t)f * a.qcap + j] : 0u; }
+        __syncthreads();
+        if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
+        __syncthreads();
+      }
+      if (tid == 0) off[s] = n;
       __syncthreads();
-      if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
-      __syncthreads();
-    }
-    if (tid == 0) off[s] = n;
-    __syncthreads();
+    };
+    list_offsets();
     phase(0);
-    // hits that cluster in stretches of the index (the usual case) are sorted block-wise: l1_block_sort
-    const bool block_sorted = (a.block_sort & 1) && cap >= 1024u && l1_block_sort<NT, E / 2>(a, s, n, cap, A, off, qo);
-    if ((a.block_sort & 2) && tid == 0) atomicAdd(&a.counters[block_sorted ? 5 : 6], 1u);   // FA_L1_STATS=1: which road the fragments took
+    // hits that cluster in stretches of the index (the usual case) are sorted block-wise: l1_block_sort (its key buffer is
+    // everything behind the seed slots -- the list offsets, which it has used by then, and the locus stage)
+    bool block_sorted = false;
+    if ((a.block_sort & 1) && cap >= 1024u) {
+      const uint32_t kl = (uint32_t)((l1_lds_bytes(cap, a.lut_smax, NT) - l1_off_offset(cap)) / 4);
+      block_sorted = l1_block_sort<NT, E / 2, 4>(a, s, n, cap, A, off, qo, off, kl);
+      if (!block_sorted) list_offsets();                                // (the key buffer may have overwritten them)
+    }
+    if (l1_dbg) atomicAdd(&a.counters[block_sorted ? 5 : 6], 1u);   // FA_L1_STATS=1: which road the fragments took
     phase(1);
     if (!block_sorted) {
     // flat gather, two elements per thread and trip so that two index reads are in flight
@@ -948,8 +1029,175 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   int32_t *st_start = st_seq + L1_STAGE, *st_rfirst = st_start + L1_STAGE, *st_end = st_rfirst + L1_STAGE, *st_rlast = st_end + L1_STAGE;
   int32_t *st_rpart = st_rlast + L1_STAGE;
   for (int i = tid; i < L1_STAGE; i += NT) st_rlast[i] = 0;
-  uint64_t *g_trip = (uint64_t *)(lds + l1_off_offset(a.lds_seed_cap));  // [NT] (the list offsets are no longer needed)
   const uint64_t len64 = (uint64_t)len;
+  // the loci of a fragment that fit the LDS stage (the common case): (contig, start, end) from their three records, groups,
+  // ONE reservation, out.  Ends the workgroup's work.
+  auto staged_epilogue = [&](const uint32_t cnt0) __attribute__((always_inline)) {
+    // The common case: the loci are in LDS.  Their groups (consecutive loci on the same reference genome) are
+    // counted from the staged copy first, so that loci and groups are reserved with ONE returning atomic on the
+    // adjacent counters -- thousands of workgroups queue up on that address for ~12 ns each, and two reservations
+    // per workgroup cost k_l1 11 of its 96 us.
+    uint32_t *st_grp = (uint32_t *)(lds + l1_off_offset(a.lds_seed_cap));   // (the list offsets are no longer needed)
+    // (contig, start, end) of every locus from its three records
+    for (uint32_t q = tid; q < cnt0; q += NT) {
+      st_seq[q] = a.ix.rec_seq[st_rfirst[q]];
+      st_start[q] = max(0, a.ix.rec_wpos[st_rpart[q]] - len + 1);
+      st_end[q] = a.ix.rec_wpos[st_rlast[q]];
+    }
+    __syncthreads();
+    if (wv == 0) {
+      uint32_t run = 0;
+      for (uint32_t i0 = 0; i0 < cnt0; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool gh = false;
+        if (i < cnt0) gh = (i == 0) || a.ix.contig_genome[st_seq[i]] != a.ix.contig_genome[st_seq[i - 1]];
+        const uint64_t gb = __ballot(gh);
+        if (i < cnt0) st_grp[i] = run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1;
+        run += __popcll(gb);
+      }
+      if (lane == 0) {
+        const unsigned long long old = atomicAdd((unsigned long long *)&a.counters[0], (unsigned long long)cnt0 | ((unsigned long long)run << 32));
+        uint32_t base = (uint32_t)old, cnt = cnt0;
+        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+        sh_base = base;
+        sh_gbase = cnt;
+        sh_grp = (uint32_t)(old >> 32);
+        a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
+      }
+    }
+    __syncthreads();
+    if (sh_gbase == 0) return;
+    for (uint32_t q = tid; q < sh_gbase; q += NT) {
+      const uint32_t li = sh_base + q;
+      a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
+      a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q]; a.l_rpart[li] = st_rpart[q];
+      a.l_group[li] = (int32_t)(sh_grp + st_grp[q]);
+    }
+    phase(4);
+  };
+  if (in_lds) {
+    // ---- Candidate pass for hits sorted in LDS: every wave takes a CONTIGUOUS run of 64-candidate steps and carries the
+    //      state of the scan (last flagged seed, heads so far) in registers from step to step -- no barrier and no LDS
+    //      round trip between steps.  The coordinates of six steps are fetched at once (one memory round trip per batch
+    //      instead of one per step: the kernel is a chain of latencies, not of instructions); the partner seed i+m-1 and
+    //      the previous flagged seed are other lanes of this step or the next, read by lane exchange.  The first flagged
+    //      candidate of a wave's run is a head *provisionally*: after ONE barrier every wave reads the other waves'
+    //      summaries, learns whether that candidate continues the previous wave's last locus and where its own loci
+    //      start, and a second sweep over the saved ballots (no coordinates needed) writes the loci. ----
+    constexpr int NW = NT / 64;
+    __shared__ uint64_t cw_last_g[NW], cw_first_gb[NW];
+    __shared__ uint32_t cw_heads[NW], cw_any[NW];
+    uint4 *step_bits = (uint4 *)(lds + l1_off_offset(a.lds_seed_cap));    // [steps] {flag ballot, head ballot} (the list offsets are no longer needed)
+    const uint32_t S = (ncand + 63u) / 64u, T = (S + NW - 1) / NW;
+    const uint32_t s0 = min(S, (uint32_t)wv * T), s1 = min(S, s0 + T);
+    const int mp = m - 1;                                                  // distance to the partner seed
+    auto coord = [&](uint32_t step) __attribute__((always_inline)) {
+      const uint32_t idx = step * 64u + (uint32_t)lane;
+      return (step <= s1 && idx < n) ? gpos_of(a.ix, seeds[idx]) : 0ULL;
+    };
+    auto lane_u64 = [&](uint64_t v, int l) __attribute__((always_inline)) {   // v of lane l, l uniform
+      return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    };
+    uint64_t carry_g = 0, first_gb = 0;
+    bool has_carry = false, any = false;
+    uint32_t heads = 0;
+    uint64_t g_next = s0 < s1 ? coord(s0) : 0ULL;
+    constexpr int CB = 6;                                                  // steps per batch (registers: two per step)
+    for (uint32_t sb = s0; sb < s1; sb += CB) {
+      uint64_t g[CB + 1];
+      g[0] = g_next;
+#pragma unroll
+      for (int u = 1; u <= CB; u++) g[u] = coord(sb + (uint32_t)u);
+#pragma unroll
+      for (int u = 0; u < CB; u++) {
+        const uint32_t step = sb + (uint32_t)u;
+        if (step < s1) {
+          const uint32_t i = step * 64u + (uint32_t)lane;
+          const uint64_t ga = g[u];
+          uint64_t gb;
+          if (mp < 64) {
+            const uint64_t x = (uint64_t)__shfl((long long)g[u], (lane + mp) & 63), y = (uint64_t)__shfl((long long)g[u + 1], (lane + mp) & 63);
+            gb = lane + mp < 64 ? x : y;
+          } else gb = i < ncand ? gpos_of(a.ix, seeds[i + mp]) : 0ULL;    // (huge sketches only)
+          const bool flag = i < ncand && gb - ga < len64;
+          const uint64_t bal = __ballot(flag);
+          const uint64_t below = bal & ((1ULL << lane) - 1ULL);
+          const int src_lane = below ? 63 - __clzll(below) : -1;
+          uint64_t gp = (uint64_t)__shfl((long long)ga, max(src_lane, 0));
+          const bool has_prev = src_lane >= 0 || has_carry;
+          if (src_lane < 0) gp = carry_g;
+          const bool head = flag && !(has_prev && gb - gp < len64);
+          const uint64_t hb = __ballot(head);
+          if (lane == 0) step_bits[step] = make_uint4((uint32_t)bal, (uint32_t)(bal >> 32), (uint32_t)hb, (uint32_t)(hb >> 32));
+          if (bal) {
+            if (!any) { first_gb = lane_u64(gb, __ffsll((long long)bal) - 1); any = true; }
+            carry_g = lane_u64(ga, 63 - __clzll(bal)); has_carry = true;
+          }
+          heads += (uint32_t)__popcll(hb);
+        }
+      }
+      g_next = g[CB];
+    }
+    if (lane == 0) { cw_heads[wv] = heads; cw_any[wv] = any ? 1u : 0u; cw_last_g[wv] = carry_g; cw_first_gb[wv] = first_gb; }
+    __syncthreads();
+    // every wave resolves the chain of summaries for itself: loci before its run, and whether its first flagged candidate
+    // continues the last locus of the waves before it
+    uint32_t my_base = 0, my_cont = 0, total = 0;
+    {
+      bool hp = false;
+      uint64_t pg = 0;
+      for (int q = 0; q < NW; q++) {
+        const uint32_t aq = cw_any[q];
+        const uint32_t cont = (aq && hp && cw_first_gb[q] - pg < len64) ? 1u : 0u;
+        if (q == wv) { my_base = total; my_cont = cont; }
+        total += cw_heads[q] - cont;
+        if (aq) { hp = true; pg = cw_last_g[q]; }
+      }
+    }
+    phase(3);
+    if (total == 0) return;
+    const bool staged = total <= (uint32_t)L1_STAGE;
+    if (!staged) {
+      // more loci than the stage holds: reserve, and write them straight to HBM
+      if (tid == 0) {
+        uint32_t cnt = total;
+        uint32_t base = atomicAdd(&a.counters[0], cnt);
+        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+        sh_base = base;
+        sh_gbase = cnt;
+        a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
+      }
+      __syncthreads();
+      if (sh_gbase == 0) return;
+    }
+    {
+      uint32_t hcount = 0;
+      for (uint32_t step = s0; step < s1; step++) {
+        const uint4 sbits = step_bits[step];
+        const uint64_t bal = ((uint64_t)sbits.y << 32) | sbits.x, hb = ((uint64_t)sbits.w << 32) | sbits.z;
+        const uint32_t local = hcount + (uint32_t)__popcll(hb & ((2ULL << lane) - 1ULL));   // provisional heads of this run up to this lane
+        if ((bal >> lane) & 1ULL) {
+          const uint32_t i = step * 64u + (uint32_t)lane;
+          const bool head = ((hb >> lane) & 1ULL) && !(my_cont && local == 1u);
+          const uint32_t slot = my_base + local - my_cont;                  // 1-based locus number inside the fragment
+          const uint64_t above = (lane == 63) ? 0ULL : (bal & ~((2ULL << lane) - 1ULL));
+          const bool last_here = above == 0 || ((hb >> (__ffsll((long long)above) - 1)) & 1ULL);
+          if (staged) {
+            if (head) { st_rfirst[slot - 1] = (int32_t)seeds[i]; st_rpart[slot - 1] = (int32_t)seeds[i + mp]; }
+            if (last_here) atomicMax(&st_rlast[slot - 1], (int32_t)seeds[i]);
+          } else {
+            const uint32_t li = sh_base + slot - 1;
+            if (head) { a.l_frag[li] = f; a.l_rfirst[li] = (int32_t)seeds[i]; a.l_rpart[li] = (int32_t)seeds[i + mp]; }
+            if (last_here) atomicMax(&a.l_rlast[li], (int32_t)seeds[i]);
+          }
+        }
+        hcount += (uint32_t)__popcll(hb);
+      }
+    }
+    __syncthreads();
+    if (staged) { staged_epilogue(total); return; }
+  } else {
+  uint64_t *g_trip = (uint64_t *)(lds + l1_off_offset(a.lds_seed_cap));  // [NT] (the list offsets are no longer needed)
   for (int pass = 0; pass < 2; pass++) {
     if (tid == 0) { sh_heads[0] = 0; sh_has_prev[0] = 0; sh_prev_g[0] = 0; }
     __syncthreads();
@@ -1034,47 +1282,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     if (pass == 0) {
       const uint32_t cnt0 = sh_heads[par];
       if (cnt0 > 0 && cnt0 <= (uint32_t)L1_STAGE) {
-        // The common case: the loci are in LDS.  Their groups (consecutive loci on the same reference genome) are
-        // counted from the staged copy first, so that loci and groups are reserved with ONE returning atomic on the
-        // adjacent counters -- thousands of workgroups queue up on that address for ~12 ns each, and two reservations
-        // per workgroup cost k_l1 11 of its 96 us.
-        uint32_t *st_grp = (uint32_t *)(lds + l1_off_offset(a.lds_seed_cap));   // (the list offsets are no longer needed)
-        // (contig, start, end) of every locus from its three records
-        for (uint32_t q = tid; q < cnt0; q += NT) {
-          st_seq[q] = a.ix.rec_seq[st_rfirst[q]];
-          st_start[q] = max(0, a.ix.rec_wpos[st_rpart[q]] - len + 1);
-          st_end[q] = a.ix.rec_wpos[st_rlast[q]];
-        }
-        __syncthreads();
-        if (wv == 0) {
-          uint32_t run = 0;
-          for (uint32_t i0 = 0; i0 < cnt0; i0 += 64) {
-            const uint32_t i = i0 + lane;
-            bool gh = false;
-            if (i < cnt0) gh = (i == 0) || a.ix.contig_genome[st_seq[i]] != a.ix.contig_genome[st_seq[i - 1]];
-            const uint64_t gb = __ballot(gh);
-            if (i < cnt0) st_grp[i] = run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1;
-            run += __popcll(gb);
-          }
-          if (lane == 0) {
-            const unsigned long long old = atomicAdd((unsigned long long *)&a.counters[0], (unsigned long long)cnt0 | ((unsigned long long)run << 32));
-            uint32_t base = (uint32_t)old, cnt = cnt0;
-            if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
-            sh_base = base;
-            sh_gbase = cnt;
-            sh_grp = (uint32_t)(old >> 32);
-            a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
-          }
-        }
-        __syncthreads();
-        if (sh_gbase == 0) return;
-        for (uint32_t q = tid; q < sh_gbase; q += NT) {
-          const uint32_t li = sh_base + q;
-          a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
-          a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q]; a.l_rpart[li] = st_rpart[q];
-          a.l_group[li] = (int32_t)(sh_grp + st_grp[q]);
-        }
-        phase(4);
+        staged_epilogue(cnt0);
         return;
       }
       // more loci than the stage holds (or none): reserve, then a second pass writes them straight to HBM
@@ -1089,6 +1297,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       __syncthreads();
       if (sh_gbase == 0) return;
     }
+  }
   }
   // ---- (contig, start, end) of the loci written by pass 1, then the groups: consecutive loci of this fragment on the same
   //      reference genome ----
