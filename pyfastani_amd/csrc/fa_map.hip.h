@@ -641,6 +641,18 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, 
 // the bytes behind them (list offsets + locus stage).
 // Returns false -- the caller then gathers and merges as before -- when the hits are too scattered for the table (a probe
 // sequence longer than BS_MAX_PROBES) or the counts do not add up.  The verdict is uniform over the workgroup.
+// inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16 lanes, then the row totals
+// broadcast into the rows behind them): six vector instructions, no LDS crossbar -- `__shfl_up` is a ds_bpermute each
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1 (lanes without a source add 0)
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // lane exchange across a power-of-two distance below 64 (the value of lane ^ X)
 template <int X>
 __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
@@ -723,14 +735,9 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   if (tid == 0) bs_fail = 0;
   __syncthreads();
   // ---- 1. the hits, flat: hit i of the fragment is entry i - off[j] of list j (off = prefix sums of the list lengths, qo = where
-  //      every list starts in the index; the caller left both in LDS).  Four hits per thread and trip, so that four index
+  //      every list starts in the index; the caller left both in LDS).  Eight hits per thread and trip, so that eight index
   //      reads are in flight: the workgroup's time is a chain of memory round trips, not instructions ----
   {
-    auto locate = [&](uint32_t i) __attribute__((always_inline)) {
-      int lo = 0, hi = s - 1;                                              // the list j with off[j] <= i < off[j + 1]
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (off[mid + 1] <= i) lo = mid + 1; else hi = mid; }
-      return lo;
-    };
     auto place = [&](uint32_t r) __attribute__((always_inline)) {
       const uint32_t key1 = (r >> 5) + 1u, bit = 1u << (r & 31u);
       uint32_t h = ((r >> 5) * 0x9E3779B1u) >> (32u - lg);
@@ -741,16 +748,30 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
         h = (h + 1u) & mask;
       }
     };
-    for (uint32_t i0 = tid; i0 < n; i0 += 4 * NT) {
-      uint32_t r[4];
+    constexpr int IB = 8;
+    uint32_t top = 1;                                                    // largest power of two below s (0 steps when s == 1)
+    while (top * 2u < (uint32_t)s) top <<= 1;
+    if (s < 2) top = 0;
+    for (uint32_t i0 = tid; i0 < n; i0 += IB * NT) {
+      // the list of every hit: the last j with off[j] <= i, found for all eight hits in LOCK STEP -- a fixed number of probes, so
+      // that eight LDS reads are in flight per probe instead of eight searches one behind the other
+      uint32_t jj[IB], r[IB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t i = i0 + (uint32_t)u * NT;
-        r[u] = 0;
-        if (i < n) { const int j = locate(i); r[u] = a.ix.pos_ridx[qo[j] + (i - off[j])]; }
+      for (int u = 0; u < IB; u++) jj[u] = 0;
+      for (uint32_t step = top; step; step >>= 1) {
+        uint32_t v[IB];
+#pragma unroll
+        for (int u = 0; u < IB; u++) v[u] = off[min(jj[u] + step, (uint32_t)s)];   // (unconditional reads, one block: all eight in flight; off[s] = n > i)
+#pragma unroll
+        for (int u = 0; u < IB; u++) jj[u] += v[u] <= i0 + (uint32_t)u * NT ? step : 0u;
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) if (i0 + (uint32_t)u * NT < n) place(r[u]);
+      for (int u = 0; u < IB; u++) {
+        const uint32_t i = i0 + (uint32_t)u * NT;
+        r[u] = i < n ? a.ix.pos_ridx[qo[jj[u]] + (i - off[jj[u]])] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < IB; u++) if (i0 + (uint32_t)u * NT < n) place(r[u]);
       if (*(volatile uint32_t *)&bs_fail) break;
     }
   }
@@ -767,8 +788,7 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
     mine += keys1[q] != 0u ? 1u : 0u;
   }
   auto block_exclusive = [&](uint32_t v, uint32_t &total) __attribute__((always_inline)) {
-    uint32_t incl = v;
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const uint32_t incl = wave_incl_scan(v);
     if (lane == 63) bs_wsum[wv] = incl;
     __syncthreads();
     uint32_t base = incl - v, tot = 0;
@@ -799,28 +819,47 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   bs_sizes<NT, KPL, 2>(k, pos0, active, nb32, Kk);
   phase(7);
   // ---- 4. the bitmap of every sorted key (one more probe of the table), places from the population counts, bits expanded
-  //      into the sorted record numbers ----
-  uint32_t bits[KPL], cnt[KPL], place_of[KPL];
+  //      into the sorted record numbers.  The sort leaves the keys on a few waves (256 per wave); where the key buffer has
+  //      room the (key, place) pairs go back through it so that EVERY thread expands its share of the entries ----
+  auto bitmap_of = [&](uint32_t key1) __attribute__((always_inline)) {
+    uint32_t h = ((key1 - 1u) * 0x9E3779B1u) >> (32u - lg);
+    uint2 e = T[h];
+    while (e.x != key1) { h = (h + 1u) & mask; e = T[h]; }
+    return e.y;
+  };
+  uint32_t bits[KPL], place_of[KPL];
   uint32_t wave_total = 0;
 #pragma unroll
   for (int j = 0; j < KPL; j++) {
-    bits[j] = 0;
-    if (active && k[j] != 0xFFFFFFFFu) {
-      uint32_t h = ((k[j] - 1u) * 0x9E3779B1u) >> (32u - lg);
-      while (T[h].x != k[j]) h = (h + 1u) & mask;
-      bits[j] = T[h].y;
-    }
-    cnt[j] = (uint32_t)__popc(bits[j]);
-    uint32_t incl = cnt[j];
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
-    place_of[j] = wave_total + incl - cnt[j];
-    wave_total += (uint32_t)__shfl((int)incl, 63);
+    bits[j] = (active && k[j] != 0xFFFFFFFFu) ? bitmap_of(k[j]) : 0u;
+    const uint32_t c = (uint32_t)__popc(bits[j]);
+    const uint32_t incl = wave_incl_scan(c);
+    place_of[j] = wave_total + incl - c;
+    wave_total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   }
   if (lane == 0) bs_wsum[wv] = wave_total;
-  __syncthreads();                                                       // (also: every probe of the table is done)
+  __syncthreads();                                                       // (also: these probes of the table are done)
   uint32_t base = 0, total = 0;
   for (int q = 0; q < NT / 64; q++) { const uint32_t w = bs_wsum[q]; base += q < wv ? w : 0u; total += w; }
   if (total != n) return false;                                          // (cannot happen: a record sits in one list only)
+  const bool spread = 2u * nb32 <= kl && nb32 <= (uint32_t)(KPL * NT);   // room for the pairs, and at most KPL entries per thread
+  if (spread) {
+    uint2 *KP = (uint2 *)Kk;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < KPL; j++) KP[pos0 + (uint32_t)j * 64u] = make_uint2(k[j], base + place_of[j]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KPL; j++) {
+      const uint32_t e = (uint32_t)j * NT + tid;
+      const uint2 kp = e < nb ? KP[e] : make_uint2(0xFFFFFFFFu, 0u);
+      k[j] = kp.x; place_of[j] = kp.y;
+      bits[j] = kp.x != 0xFFFFFFFFu ? bitmap_of(kp.x) : 0u;
+    }
+    base = 0;
+    __syncthreads();                                                     // (every probe of the table is done)
+  }
 #pragma unroll
   for (int j = 0; j < KPL; j++) {
     uint32_t b = bits[j], o = base + place_of[j];
@@ -882,13 +921,13 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       for (int j0 = 0; j0 < s; j0 += NT) {
         const int j = j0 + tid;
         const uint32_t cnt = j < s ? a.q_cnt[(size_t)f * a.qcap + j] : 0;
-        uint32_t incl = cnt;
-        for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        const uint32_t src = (j < s && cnt) ? a.q_off[(size_t)f * a.qcap + j] : 0u;
+        const uint32_t incl = wave_incl_scan(cnt);
         if (lane == 63) sh_scan[wv] = incl;
         __syncthreads();
         uint32_t o = sh_run + incl - cnt;
         for (int q = 0; q < wv; q++) o += sh_scan[q];
-        if (j < s) { off[j] = o; qo[j] = cnt ? a.q_off[(size_t)f * a.qcap + j] : 0u; }
+        if (j < s) { off[j] = o; qo[j] = src; }
         __syncthreads();
         if (tid == 0) { uint32_t tot = 0; for (int q = 0; q < NT / 64; q++) tot += sh_scan[q]; sh_run += tot; }
         __syncthreads();
@@ -1078,7 +1117,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   if (in_lds) {
     // ---- Candidate pass for hits sorted in LDS: every wave takes a CONTIGUOUS run of 64-candidate steps and carries the
     //      state of the scan (last flagged seed, heads so far) in registers from step to step -- no barrier and no LDS
-    //      round trip between steps.  The coordinates of six steps are fetched at once (one memory round trip per batch
+    //      round trip between steps.  The coordinates of a batch of steps are fetched at once (one memory round trip per batch
     //      instead of one per step: the kernel is a chain of latencies, not of instructions); the partner seed i+m-1 and
     //      the previous flagged seed are other lanes of this step or the next, read by lane exchange.  The first flagged
     //      candidate of a wave's run is a head *provisionally*: after ONE barrier every wave reads the other waves'
@@ -1091,53 +1130,70 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     const uint32_t S = (ncand + 63u) / 64u, T = (S + NW - 1) / NW;
     const uint32_t s0 = min(S, (uint32_t)wv * T), s1 = min(S, s0 + T);
     const int mp = m - 1;                                                  // distance to the partner seed
-    auto coord = [&](uint32_t step) __attribute__((always_inline)) {
-      const uint32_t idx = step * 64u + (uint32_t)lane;
-      return (step <= s1 && idx < n) ? gpos_of(a.ix, seeds[idx]) : 0ULL;
-    };
-    auto lane_u64 = [&](uint64_t v, int l) __attribute__((always_inline)) {   // v of lane l, l uniform
-      return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
-    };
     uint64_t carry_g = 0, first_gb = 0;
     bool has_carry = false, any = false;
     uint32_t heads = 0;
-    uint64_t g_next = s0 < s1 ? coord(s0) : 0ULL;
-    constexpr int CB = 6;                                                  // steps per batch (registers: two per step)
-    for (uint32_t sb = s0; sb < s1; sb += CB) {
-      uint64_t g[CB + 1];
-      g[0] = g_next;
+    // (the scan proper, on 32-bit coordinates while the index spans less than 2^32 padded bases -- twice the steps per batch
+    // in the same registers, half the lane exchanges -- and on 64-bit ones beyond)
+    auto scan_run = [&](auto tag) __attribute__((always_inline)) {
+      using G = decltype(tag);
+      constexpr bool NARROW = sizeof(G) == 4;
+      constexpr int CB = NARROW ? 9 : 6;                                     // steps per batch (registers: one or two per step)
+      auto coord = [&](uint32_t step) __attribute__((always_inline)) -> G {
+        const uint32_t idx = step * 64u + (uint32_t)lane;
+        if (!(step <= s1 && idx < n)) return (G)0;
+        if constexpr (NARROW) return (G)a.ix.rec_gpos[seeds[idx]]; else return (G)gpos_of(a.ix, seeds[idx]);
+      };
+      auto from_lane = [&](G v, int l) __attribute__((always_inline)) -> G {       // v of lane l (any l)
+        if constexpr (NARROW) return (G)__shfl((int)v, l); else return (G)__shfl((long long)v, l);
+      };
+      auto uniform_lane = [&](G v, int l) __attribute__((always_inline)) -> uint64_t {   // v of lane l, l uniform
+        if constexpr (NARROW) return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, l);
+        else return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)((uint64_t)v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+      };
+      const G lenG = (G)len;
+      G carry = 0;
+      G g_next = s0 < s1 ? coord(s0) : (G)0;
+      for (uint32_t sb = s0; sb < s1; sb += CB) {
+        G g[CB + 1];
+        g[0] = g_next;
 #pragma unroll
-      for (int u = 1; u <= CB; u++) g[u] = coord(sb + (uint32_t)u);
+        for (int u = 1; u <= CB; u++) g[u] = coord(sb + (uint32_t)u);
 #pragma unroll
-      for (int u = 0; u < CB; u++) {
-        const uint32_t step = sb + (uint32_t)u;
-        if (step < s1) {
-          const uint32_t i = step * 64u + (uint32_t)lane;
-          const uint64_t ga = g[u];
-          uint64_t gb;
-          if (mp < 64) {
-            const uint64_t x = (uint64_t)__shfl((long long)g[u], (lane + mp) & 63), y = (uint64_t)__shfl((long long)g[u + 1], (lane + mp) & 63);
-            gb = lane + mp < 64 ? x : y;
-          } else gb = i < ncand ? gpos_of(a.ix, seeds[i + mp]) : 0ULL;    // (huge sketches only)
-          const bool flag = i < ncand && gb - ga < len64;
-          const uint64_t bal = __ballot(flag);
-          const uint64_t below = bal & ((1ULL << lane) - 1ULL);
-          const int src_lane = below ? 63 - __clzll(below) : -1;
-          uint64_t gp = (uint64_t)__shfl((long long)ga, max(src_lane, 0));
-          const bool has_prev = src_lane >= 0 || has_carry;
-          if (src_lane < 0) gp = carry_g;
-          const bool head = flag && !(has_prev && gb - gp < len64);
-          const uint64_t hb = __ballot(head);
-          if (lane == 0) step_bits[step] = make_uint4((uint32_t)bal, (uint32_t)(bal >> 32), (uint32_t)hb, (uint32_t)(hb >> 32));
-          if (bal) {
-            if (!any) { first_gb = lane_u64(gb, __ffsll((long long)bal) - 1); any = true; }
-            carry_g = lane_u64(ga, 63 - __clzll(bal)); has_carry = true;
+        for (int u = 0; u < CB; u++) {
+          const uint32_t step = sb + (uint32_t)u;
+          if (step < s1) {
+            const uint32_t i = step * 64u + (uint32_t)lane;
+            const G ga = g[u];
+            G gb;
+            if (mp < 64) {
+              const G x = from_lane(g[u], (lane + mp) & 63), y = from_lane(g[u + 1], (lane + mp) & 63);
+              gb = lane + mp < 64 ? x : y;
+            } else {                                                       // (huge sketches only)
+              gb = 0;
+              if (i < ncand) { if constexpr (NARROW) gb = (G)a.ix.rec_gpos[seeds[i + mp]]; else gb = (G)gpos_of(a.ix, seeds[i + mp]); }
+            }
+            const bool flag = i < ncand && (G)(gb - ga) < lenG;
+            const uint64_t bal = __ballot(flag);
+            const uint64_t below = bal & ((1ULL << lane) - 1ULL);
+            const int src_lane = below ? 63 - __clzll(below) : -1;
+            G gp = from_lane(ga, max(src_lane, 0));
+            const bool has_prev = src_lane >= 0 || has_carry;
+            if (src_lane < 0) gp = carry;
+            const bool head = flag && !(has_prev && (G)(gb - gp) < lenG);
+            const uint64_t hb = __ballot(head);
+            if (lane == 0) step_bits[step] = make_uint4((uint32_t)bal, (uint32_t)(bal >> 32), (uint32_t)hb, (uint32_t)(hb >> 32));
+            if (bal) {
+              if (!any) { first_gb = uniform_lane(gb, __ffsll((long long)bal) - 1); any = true; }
+              carry_g = uniform_lane(ga, 63 - __clzll(bal)); carry = (G)carry_g; has_carry = true;
+            }
+            heads += (uint32_t)__popcll(hb);
           }
-          heads += (uint32_t)__popcll(hb);
         }
+        g_next = g[CB];
       }
-      g_next = g[CB];
-    }
+    };
+    if (a.ix.n_wraps == 0) scan_run((uint32_t)0); else scan_run((uint64_t)0);
     if (lane == 0) { cw_heads[wv] = heads; cw_any[wv] = any ? 1u : 0u; cw_last_g[wv] = carry_g; cw_first_gb[wv] = first_gb; }
     __syncthreads();
     // every wave resolves the chain of summaries for itself: loci before its run, and whether its first flagged candidate
