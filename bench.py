@@ -66,6 +66,9 @@ def parse_args():
     ap.add_argument("--no-boundary", action="store_true", help="N=1: skip the `boundary_call` leg (profiling: the last launches stay those of the timed step)")
     ap.add_argument("--no-saturated", action="store_true", help="N=1: skip the `saturated` legs (16 queries per launch; config 3 at N=1)")
     ap.add_argument("--saturated-steps", type=int, default=3, help="steps of the config-3 leg of `saturated` (its batch-16 leg runs 10)")
+    ap.add_argument("--no-config45", action="store_true", help="N=1: skip BASELINE configs 4 (500 drafts all-vs-all) and 5 (nine (k, fragment_length) cells)")
+    ap.add_argument("--config4", type=str, default="10x50", help="families x members of the config-4 leg (tests shrink it)")
+    ap.add_argument("--config5", type=str, default="10x20", help="families x members of the config-5 leg (tests shrink it)")
     return ap.parse_args()
 
 
@@ -343,6 +346,9 @@ def weak_scaling(ctx):
             result["concurrent_clients"] = concurrent_clients(args, batch, cap_rows, n_pairs_step)
         if not args.no_saturated and args.batch == 1:
             result["saturated"] = saturated_legs(ctx, mapper, anc)
+            if not args.no_config45:
+                result["saturated"]["config4"] = config4_leg(ctx)
+                result["config5_cells"] = config5_leg(ctx)
         if not args.no_cpu_baseline:              # the CPU oracle legs are an N=1 measurement (rank 0 only)
             result.update(oracle_legs(args, anc, names, refs, mapper, [qs[0] for qs in rot_queries], timed_rows))
     return result
@@ -523,6 +529,97 @@ def saturated_legs(ctx, mapper, anc, batch16_steps=10):
         if r is not None:
             out["config3"] = r
     return out
+
+
+def resident_all_vs_all(ctx, genomes, fam, params, steps, warmup=1):
+    """Index `genomes`, keep them resident as queries and map all of them against the index `steps` times, device-resident
+    (`sharding.ResidentHitTable`, as the config-3 leg does); the rows of the last step are checked through the oracle-free
+    properties of `workloads.row_properties`.  Returns (measurements, mapper)."""
+    import warnings
+    import pyfastani_amd as pf
+    from pyfastani_amd import sharding, workloads
+    from pyfastani_amd._lib import lib
+    torch = ctx["torch"]
+    n = len(genomes)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                  # (short contigs of the drafts: the reference warns too)
+        t0 = time.time()
+        sk = pf.Sketch(**params)
+        for i, contigs in enumerate(genomes):
+            sk.add_draft(i, contigs)
+        t_pack = time.time() - t0
+        t0 = time.time()
+        mapper = sk.index()
+        t_index = time.time() - t0
+        batch = mapper.upload_genomes(genomes)
+    table = sharding.ResidentHitTable(list(range(n)), n * n, 1)
+    for _ in range(max(warmup, 1)):
+        tables = table.step(batch)
+    ph = np.zeros(24)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tables = table.step(batch)
+        ms = (C.c_float * 24)()
+        lib.fa_mapper_last_timings(mapper._h, ms, 24)
+        ph += np.array(list(ms))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ph /= max(steps, 1)
+    rows = sharding.ResidentHitTable.rows_of(tables)
+    props = workloads.row_properties(rows, batch, mapper, genomes, fam)
+    fused, apart = ph[17], ph[18]
+    out = {"value": n * n * steps / dt, "unit": "pairs/s", "steps": steps, "ms_per_step": dt / steps * 1e3, "us_per_pair": dt / steps / (n * n) * 1e6,
+           "phases_ms": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in ph[:5]])),
+           "sketch_stage": "k_query_fused (one launch)" if fused > 0 and apart == 0 else ("K1 + k_query_sketch (two launches)" if fused == 0 else "mixed"),
+           "repeated_attempts_per_step": float(ph[9]), "l2_records_per_step": float(ph[5]), "host_pack_s": t_pack, "index_build_s": t_index,
+           "table_sha256": _sha256_rows(rows), **props}
+    return out, mapper
+
+
+def config4_leg(ctx):
+    """BASELINE configs[3]: draft assemblies (50 log-normal contigs each, ~5 Mb) all-vs-all through the add_draft path
+    (src/pyfastani/_fastani.pyx:610-690 contig counters, :1061-1105 draft query), one MI355X, device-resident steps."""
+    args = ctx["args"]
+    from pyfastani_amd import workloads
+    f, m = (int(x) for x in args.config4.split("x"))
+    t0 = time.time()
+    genomes, fam = workloads.config4(f, m, args.length)
+    t_gen = time.time() - t0
+    r, mapper = resident_all_vs_all(ctx, genomes, fam, {}, max(args.saturated_steps, 1))
+    ok = r["self_hits_exact"] and r["hits_within_family"] and r["asymmetric_pairs"] == 0
+    if not ok:
+        raise SystemExit(f"CONFIG 4 FAILURE: the oracle-free properties do not hold: {r}")
+    n = len(genomes)
+    return {"workload": f"{n} x {n} draft assemblies all-vs-all ({f} families x {m}), 50 contigs each, {args.length / 1e6:g} Mb, k=16 frag=3000 w={r['window_size']}",
+            "generate_s": t_gen, "contigs": int(sum(len(c) for c in genomes)),
+            "roofline": stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"], None, None), **r}
+
+
+def config5_leg(ctx):
+    """BASELINE configs[4]: the (k, fragment_length) sweep -- k in {14, 16, 21} x fragment in {1000, 3000, 5000} -- on genomes
+    all-vs-all, one MI355X, device-resident steps; (21, 1000) is the degenerate cell (no window fits a fragment: nothing
+    maps).  What the reference's benches/mapping/bench.py:34-54 would sweep."""
+    args = ctx["args"]
+    from pyfastani_amd import workloads
+    f, m = (int(x) for x in args.config5.split("x"))
+    t0 = time.time()
+    genomes, fam = workloads.config5(f, m, args.length)
+    t_gen = time.time() - t0
+    cells = []
+    for k, frag in workloads.CONFIG5_CELLS:
+        r, mapper = resident_all_vs_all(ctx, genomes, fam, {"k": k, "fragment_length": frag}, 2)
+        degenerate = r["window_size"] >= frag
+        # (1 kb fragments carry ~80 minimizers: unrelated genomes pass the 80 % cut-off by chance there -- the oracle shows the
+        # same rows at reduced size -- so family containment is a property of the cells with longer fragments and k <= 16 only)
+        ok = (r["rows"] == 0) if degenerate else (r["self_hits_exact"] and (r["hits_within_family"] or not (frag >= 3000 and k <= 16)))
+        if not ok:
+            raise SystemExit(f"CONFIG 5 FAILURE in cell k={k} fragment_length={frag}: {r}")
+        cells.append({"k": k, "fragment_length": frag, "degenerate": degenerate, **r})
+        del mapper
+    n = len(genomes)
+    return {"workload": f"{n} x {n} all-vs-all ({f} families x {m}) of {args.length / 1e6:g} Mb genomes per (k, fragment_length) cell", "generate_s": t_gen,
+            "pairs_per_cell": n * n, "cells": cells}
 
 
 def oracle_legs(args, anc, names, refs, mapper, rot_queries, timed_rows):

@@ -65,6 +65,36 @@ def config5(n_families=10, n_members=20, length=5_000_000):
     return families(4000, n_families, n_members, length)
 
 
+def row_properties(rows, batch, mapper, genomes, fam):
+    """What must hold for the hit rows of an all-vs-all run without an oracle (see `all_vs_all`): counts and verdicts."""
+    n = len(genomes)
+    frag = mapper.fragment_length
+    qlen = batch.total_length.astype(np.float64)
+    rlen = np.array([sum((len(c) // frag) * frag for c in contigs) for contigs in genomes], dtype=np.float64)
+    # the reference's minimum_fraction filter (_fastani.pyx:1121-1132), float32 like the product path
+    min_len = np.minimum(qlen[rows["query_id"]], rlen[rows["ref_genome_id"]]).astype(np.float32)
+    keep = (rows["count_seq"].astype(np.float32) * np.float32(frag)) >= min_len * np.float32(mapper.minimum_fraction)
+    hits = rows[keep]
+    fam = np.asarray(fam)
+    self_rows = rows[rows["query_id"] == rows["ref_genome_id"]]
+    with_frags = int((batch.total_fragments > 0).sum())
+    single = all(len(c) == 1 for c in genomes)
+    ident_ok = bool(np.all(self_rows["identity"] == 100.0)) if single else bool(np.all(self_rows["identity"] >= 99.999))
+    ok_self = (len(self_rows) == with_frags and bool(np.all(self_rows["identity"] >= 99.999))
+               and bool(np.all(self_rows["count_seq"] >= 0.98 * self_rows["total_query_fragments"])))
+    ok_family = bool(np.all(fam[hits["query_id"]] == fam[hits["ref_genome_id"]]))
+    pairs = set(zip(hits["query_id"].tolist(), hits["ref_genome_id"].tolist()))
+    asym = sum((b, a) not in pairs for a, b in pairs)
+    return {
+        "window_size": mapper.window_size, "pairs": n * n, "rows": int(len(rows)), "hits_after_min_fraction": int(len(hits)),
+        "index_minimizers": len(mapper.minimizers), "threshold": mapper.occurences_threshold,
+        "self_rows": int(len(self_rows)), "self_identity_min": float(self_rows["identity"].min()) if len(self_rows) else None,
+        "self_identity_all_exact": ident_ok,
+        "self_fraction_min": float((self_rows["count_seq"] / np.maximum(self_rows["total_query_fragments"], 1)).min()) if len(self_rows) else None,
+        "self_hits_exact": ok_self, "hits_within_family": ok_family, "asymmetric_pairs": asym,
+    }
+
+
 def all_vs_all(genomes, fam, params=None, chunk=24, timings=True):
     """Index `genomes`, map every genome against the index and check what must hold without an oracle:
 
@@ -103,31 +133,8 @@ def all_vs_all(genomes, fam, params=None, chunk=24, timings=True):
             phase += np.array(list(ms)[:5])
         t_map = time.time() - t0
     rows = np.concatenate(rows)
-    frag = mapper.fragment_length
-    qlen = batch.total_length.astype(np.float64)
-    rlen = np.array([sum((len(c) // frag) * frag for c in contigs) for contigs in genomes], dtype=np.float64)
-    # the reference's minimum_fraction filter (_fastani.pyx:1121-1132), float32 like the product path
-    min_len = np.minimum(qlen[rows["query_id"]], rlen[rows["ref_genome_id"]]).astype(np.float32)
-    keep = (rows["count_seq"].astype(np.float32) * np.float32(frag)) >= min_len * np.float32(mapper.minimum_fraction)
-    hits = rows[keep]
-    fam = np.asarray(fam)
-    self_rows = rows[rows["query_id"] == rows["ref_genome_id"]]
-    with_frags = int((batch.total_fragments > 0).sum())
-    single = all(len(c) == 1 for c in genomes)
-    ident_ok = bool(np.all(self_rows["identity"] == 100.0)) if single else bool(np.all(self_rows["identity"] >= 99.999))
-    ok_self = (len(self_rows) == with_frags and bool(np.all(self_rows["identity"] >= 99.999))
-               and bool(np.all(self_rows["count_seq"] >= 0.98 * self_rows["total_query_fragments"])))
-    ok_family = bool(np.all(fam[hits["query_id"]] == fam[hits["ref_genome_id"]]))
-    pairs = set(zip(hits["query_id"].tolist(), hits["ref_genome_id"].tolist()))
-    asym = sum((b, a) not in pairs for a, b in pairs)
-    out = {
-        "window_size": mapper.window_size, "pairs": n * n, "rows": int(len(rows)), "hits_after_min_fraction": int(len(hits)),
-        "index_minimizers": len(mapper.minimizers), "threshold": mapper.occurences_threshold,
-        "self_rows": int(len(self_rows)), "self_identity_min": float(self_rows["identity"].min()) if len(self_rows) else None,
-        "self_identity_all_exact": ident_ok,
-        "self_fraction_min": float((self_rows["count_seq"] / np.maximum(self_rows["total_query_fragments"], 1)).min()) if len(self_rows) else None,
-        "self_hits_exact": ok_self, "hits_within_family": ok_family, "asymmetric_pairs": asym, "repeated_attempts": retries,
-    }
+    out = row_properties(rows, batch, mapper, genomes, fam)
+    out["repeated_attempts"] = retries
     if timings:
         out.update({"host_pack_s": t_pack, "sketch_index_s": t_index, "upload_queries_s": t_upload, "map_s": t_map,
                     "pairs_per_s_map_only": n * n / t_map if t_map > 0 else None,

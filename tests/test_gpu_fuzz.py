@@ -5,7 +5,8 @@ frequency threshold and every hit must match.  A 10 000-case campaign (seeds 2-5
 
 The seed is NOT fixed: it is derived from the kernel and oracle sources, so every change of either draws a fresh set of
 cases (the same sources always replay the same set; the seed is printed on failure and `scripts/fuzz_parity.py <cases>
-<seed>` replays it), and the run is a time box rather than a case count."""
+<seed>` replays it).  The run is a fixed number of cases -- about 100 s on an idle box -- so that a loaded machine makes the
+test slower, not red."""
 import hashlib
 import os
 import subprocess
@@ -29,8 +30,9 @@ def source_seed():
 
 def test_fuzz_against_oracle():
     seed = source_seed()
-    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "100000", str(seed), "150"],
-                         capture_output=True, text=True, timeout=1500)
+    cases = 400
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), str(cases), str(seed)],
+                         capture_output=True, text=True, timeout=2400)
     assert res.returncode == 0, f"seed {seed}\n" + res.stdout[-3000:] + res.stderr[-3000:]
     assert "0 mismatches" in res.stdout and f"seed {seed}" in res.stdout
-    assert int(res.stdout.strip().splitlines()[-1].split()[0]) >= 200, res.stdout[-500:]      # the box holds ~600 cases
+    assert int(res.stdout.strip().splitlines()[-1].split()[0]) == cases, res.stdout[-500:]

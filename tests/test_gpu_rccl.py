@@ -108,6 +108,23 @@ def test_bench_launches_its_own_ranks_and_carries_the_strong_leg():
     assert s["exchange_ms"] > 0 and s["ms_per_step"] > 0
 
 
+def test_bench_line_carries_configs_4_and_5():
+    """The N = 1 line at reduced size: `saturated.config4` (draft assemblies all-vs-all) and `config5_cells` (the nine
+    (k, fragment_length) cells) ride in it with pairs/s, per-stage ms, the sketch-stage form and the oracle-free properties."""
+    args = ["--refs", "6", "--length", "300000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--clients", "0", "--no-boundary",
+            "--families", "2", "--members", "4", "--saturated-steps", "1", "--config4", "2x4", "--config5", "2x3"]
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    c4 = line["saturated"]["config4"]
+    assert c4["pairs"] == 64 and c4["value"] > 0 and c4["self_hits_exact"] and c4["contigs"] == 8 * 50 and c4["phases_ms"]["l2_ms"] > 0
+    cells = line["config5_cells"]["cells"]
+    assert [(c["k"], c["fragment_length"]) for c in cells] == [(k, f) for k in (14, 16, 21) for f in (1000, 3000, 5000)]
+    assert sum(c["degenerate"] for c in cells) == 1 and all(c["value"] > 0 and "sketch_stage" in c for c in cells)
+    default = [c for c in cells if (c["k"], c["fragment_length"]) == (16, 3000)][0]
+    assert default["window_size"] == 24 and default["sketch_stage"].startswith("k_query_fused")
+
+
 def test_bench_refuses_a_world_size_that_is_not_gpus():
     res = _run_ranks([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--no-cpu-baseline"], 2, env={"FA_BENCH_SHARE_GPU": "1"})
     assert res.returncode != 0 and "WORLD_SIZE" in (res.stdout + res.stderr)
