@@ -166,23 +166,37 @@ static bool launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
   if (!a.protein && !k1_general && P.window_size >= SKF_MIN_W && P.window_size <= SKF_MAX_W) {
     // the hot form (fa_sketch_fast.hip.h): 13 KB of LDS, eight workgroups per CU; k = 14 / 16 / 21 hash from the premix tables
     const size_t flds = skf_layout(P.kmer_size, P.window_size).total;
-    // fused with the per-fragment sketch: no other bytes anywhere in the batch (their tiles go through k_sketch_tiles<0, true>
-    // and the staging arrays), and fragments whose records fit QF_CAP with room to spare (a denser one voids the pass)
+    // The (k, w) cells of the default identity cut-off over the usual fragment lengths -- BASELINE config 5's grid: k in
+    // {14, 16, 21} x fragment in {1000, 3000, 5000}, windows from recommendedWindowSize -- are built with BOTH parameters at
+    // compile time (the window loop unrolled, 42 registers instead of 61 in k_sketch_fast); any other window takes the
+    // run-time form of its k.
+#define FA_KW_CELLS(X) X(14, 12) X(14, 37) X(14, 50) X(16, 13) X(16, 24) X(16, 40) X(21, 15) X(21, 25)
+    // fused with the per-fragment sketch (k_query_fused, one of those cells): no other bytes anywhere in the batch (their tiles
+    // go through k_sketch_tiles<0, true> and the staging arrays), and fragments whose records fit QF_CAP with room to spare
+    // (a denser one voids the pass).  The run-time-w forms of the fused kernel do not fit the registers of seven waves per
+    // SIMD -- a few words would go to scratch memory, which the runtime then keeps per stream for good -- and are not built.
     static const bool fuse_on = !(getenv("FA_QUERY_FUSED") && atoi(getenv("FA_QUERY_FUSED")) == 0);
-    // (the default cell only, k = 16 / w = 24: its instantiation fits the registers of seven waves per SIMD; the run-time-w
-    // and k = 14 / 21 forms spill a few words to scratch memory, which the runtime then keeps per stream for good)
-    if (fuse && fuse_on && store.n_exc == 0 && P.kmer_size == 16 && P.window_size == 24 &&
-        (int64_t)5 * P.fragment_length / (P.window_size + 1) <= QF_CAP) {
-      const size_t qlds = flds + (size_t)QF_CAP * 4;
-      hipLaunchKernelGGL((k_query_fused<16, 24>), dim3((unsigned)F + extra), dim3(SK_THREADS), qlds + lds_pad, st, a, *fuse, (int)F);
-      FA_HIP(hipGetLastError());
-      return true;
-    }
+    const bool may_fuse = fuse && fuse_on && store.n_exc == 0 && (int64_t)5 * P.fragment_length / (P.window_size + 1) <= QF_CAP;
     auto launch_fast = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), flds + lds_pad, st, a);
       extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;
     };
-    if (P.kmer_size == 16 && P.window_size == 24) launch_fast(k_sketch_fast<16, 24>);
+    bool served = false;
+#define FA_TRY_CELL(K, W)                                                                                                        \
+    if (!served && P.kmer_size == K && P.window_size == W) {                                                                      \
+      served = true;                                                                                                              \
+      if (may_fuse) {                                                                                                             \
+        const size_t qlds = flds + (size_t)QF_CAP * 4;                                                                            \
+        hipLaunchKernelGGL((k_query_fused<K, W>), dim3((unsigned)F + extra), dim3(SK_THREADS), qlds + lds_pad, st, a, *fuse, (int)F); \
+        FA_HIP(hipGetLastError());                                                                                                \
+        return true;                                                                                                              \
+      }                                                                                                                           \
+      launch_fast(k_sketch_fast<K, W>);                                                                                           \
+    }
+    FA_KW_CELLS(FA_TRY_CELL)
+#undef FA_TRY_CELL
+#undef FA_KW_CELLS
+    if (served) {}
     else if (P.kmer_size == 16) launch_fast(k_sketch_fast<16, 0>);
     else if (P.kmer_size == 14) launch_fast(k_sketch_fast<14, 0>);
     else if (P.kmer_size == 21) launch_fast(k_sketch_fast<21, 0>);

@@ -449,8 +449,10 @@ constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS =
 // write nothing into the status block -- the zeroing workgroups of this very launch are clearing it.
 // ----------------------------------------------------------------------------------------------------------
 constexpr int QF_CAP = 1024;        // records of one fragment held in LDS (a power of two: the bitonic fallback sorts in place)
+// (waves per SIMD: seven, except the two cells whose window loop needs a 73rd register -- k = 14 with w = 37 / 50 -- at six)
+#define QF_WAVES(K, W) (((K) == 14 && (W) > 32) ? 6 : 7)
 template <int KT, int WT>
-__global__ __launch_bounds__(SK_THREADS, 7) void k_query_fused(SketchArgs a, QuerySketchArgs q, int F) {
+__global__ __launch_bounds__(SK_THREADS, QF_WAVES(KT, WT)) void k_query_fused(SketchArgs a, QuerySketchArgs q, int F) {
   extern __shared__ __align__(16) unsigned char lds[];
   static_assert(SK_THREADS == MAP_THREADS, "one workgroup runs both halves");
   const int tid = threadIdx.x;

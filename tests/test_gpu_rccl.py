@@ -111,7 +111,7 @@ def test_bench_launches_its_own_ranks_and_carries_the_strong_leg():
 def test_bench_line_carries_configs_4_and_5():
     """The N = 1 line at reduced size: `saturated.config4` (draft assemblies all-vs-all) and `config5_cells` (the nine
     (k, fragment_length) cells) ride in it with pairs/s, per-stage ms, the sketch-stage form and the oracle-free properties."""
-    args = ["--refs", "6", "--length", "300000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--clients", "0", "--no-boundary",
+    args = ["--refs", "6", "--length", "1500000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--clients", "0", "--no-boundary",
             "--families", "2", "--members", "4", "--saturated-steps", "1", "--config4", "2x4", "--config5", "2x3"]
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
