@@ -370,7 +370,7 @@ struct PassStatus {
   uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
-  unsigned long long dbg[8];        // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the workgroups (thread 0's view)
+  unsigned long long dbg[12];       // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the sampled workgroups (thread 0's view); [8..10] why block sorts gave up
   unsigned long long stamp[6];      // stage_stamp: pass start, lookup, L2, CGI, end (100 MHz ticks); not cleared with the rest
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
@@ -1392,7 +1392,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       const double nf = (double)(h_counters[5] + h_counters[6]);
       fprintf(stderr, "[fa] k_l1 phases, shader-clock ticks per fragment (thread 0):");
       for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", (double)ln.h_status->dbg[i] / nf);
-      fprintf(stderr, "  (%u block-sorted, %u merged; one workgroup in 64 sampled)\n", h_counters[5], h_counters[6]);
+      fprintf(stderr, "  (%u block-sorted, %u merged; one workgroup in 64 sampled; gave up on probes / blocks / counts: %llu %llu %llu)\n", h_counters[5], h_counters[6],
+              ln.h_status->dbg[8], ln.h_status->dbg[9], ln.h_status->dbg[10]);
     }
     return true;
   };

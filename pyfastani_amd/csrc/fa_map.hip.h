@@ -630,8 +630,8 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, 
 // Sorting the seed hits of a fragment WITHOUT merging them, for the regime the workloads live in: the hits of a fragment are
 // record numbers, records are ordered by (contig, window), and a query fragment that has relatives in the index finds them in
 // a few dozen STRETCHES of consecutive records (one per related genome, about a fragment's worth of records each) -- 4 000
-// hits fall into some 450 blocks of 32 consecutive records.  So the hits are not sorted, their blocks are:
-//   1. every hit sets its bit in an open-addressing LDS table {block number + 1, 32-bit bitmap} (one returning and one
+// hits fall into some 250 blocks of 64 consecutive records.  So the hits are not sorted, their blocks are:
+//   1. every hit sets its bit in an open-addressing LDS table {block number + 1, 64-bit bitmap} (one returning and one
 //      plain LDS atomic per hit; a record sits in one position list only, so no bit is set twice);
 //   2. the block numbers of the occupied entries -- a few hundred -- are bitonic-sorted in REGISTERS (lane exchanges by DPP /
 //      swizzle, no LDS round trip per stage; bs_sizes);
@@ -639,7 +639,7 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, 
 //      its place, and the bits are expanded into the sorted array of record numbers -- the array the merge produces, bit
 //      for bit, for a fraction of the instructions and, what counts more in this kernel, of the dependent LDS round trips
 //      (eight merge levels: two binary searches and 8-9 sequential merge steps per thread and level).
-// The table and the sorted hits share the LDS of the seed slots (table = half as many entries as slots); the keys pass through
+// The table and the sorted hits share the LDS of the seed slots (table = a third as many entries as slots, a power of two); the keys pass through
 // the bytes behind them (list offsets + locus stage).
 // Returns false -- the caller then gathers and merges as before -- when the hits are too scattered for the table (a probe
 // sequence longer than BS_MAX_PROBES) or the counts do not add up.  The verdict is uniform over the workgroup.
@@ -725,15 +725,19 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   __shared__ uint32_t bs_fail, bs_total;
   __shared__ uint32_t bs_wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t lg = 31u - (uint32_t)__clz((int)(cap >> 1));            // table entries: the largest power of two <= cap / 2
+  const uint32_t lg = 31u - (uint32_t)__clz((int)(cap / 3u));           // table entries (12 bytes each): the largest power of two <= cap / 3
   const uint32_t capT = 1u << lg, mask = capT - 1u;
-  uint2 *T = (uint2 *)A;
+  unsigned long long *Tb = (unsigned long long *)A;                      // [capT] bitmaps of 64 consecutive records
+  uint32_t *Tk = (uint32_t *)(Tb + capT);                                // [capT] block number + 1 (0 = empty)
+  // the key buffer: what the table leaves of the seed slots (a quarter of them when cap / 3 is not a power of two), or the
+  // caller's bytes behind them, whichever holds more
+  if (cap - 3u * capT > kl) { Kk = Tk + capT; kl = cap - 3u * capT; }
   const bool dbg = (a.block_sort & 2) && tid == 0 && (blockIdx.x & 63) == 0;
   long long tk = dbg ? clock64() : 0;
   auto phase = [&](int k) __attribute__((always_inline)) {
     if (dbg) { const long long now = clock64(); atomicAdd(&a.dbg[k], (unsigned long long)(now - tk)); tk = now; }
   };
-  for (uint32_t i = tid; i < capT; i += NT) T[i] = make_uint2(0u, 0u);
+  for (uint32_t i = tid; i < capT; i += NT) { Tb[i] = 0ULL; Tk[i] = 0u; }
   if (tid == 0) bs_fail = 0;
   __syncthreads();
   // ---- 1. the hits, flat: hit i of the fragment is entry i - off[j] of list j (off = prefix sums of the list lengths, qo = where
@@ -741,11 +745,12 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   //      reads are in flight: the workgroup's time is a chain of memory round trips, not instructions ----
   {
     auto place = [&](uint32_t r) __attribute__((always_inline)) {
-      const uint32_t key1 = (r >> 5) + 1u, bit = 1u << (r & 31u);
-      uint32_t h = ((r >> 5) * 0x9E3779B1u) >> (32u - lg);
+      const uint32_t key1 = (r >> 6) + 1u;
+      const unsigned long long bit = 1ULL << (r & 63u);
+      uint32_t h = ((r >> 6) * 0x9E3779B1u) >> (32u - lg);
       for (uint32_t probes = 0;; probes++) {
-        const uint32_t old = atomicCAS(&T[h].x, 0u, key1);
-        if (old == 0u || old == key1) { atomicOr(&T[h].y, bit); break; }
+        const uint32_t old = atomicCAS(&Tk[h], 0u, key1);
+        if (old == 0u || old == key1) { atomicOr(&Tb[h], bit); break; }
         if (probes >= BS_MAX_PROBES) { bs_fail = 1; break; }
         h = (h + 1u) & mask;
       }
@@ -779,32 +784,36 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   }
   __syncthreads();
   phase(5);
-  if (bs_fail) { __syncthreads(); return false; }
+  if (bs_fail) { if (dbg) atomicAdd(&a.dbg[8], 1ULL); __syncthreads(); return false; }
   // ---- 2. the keys of the occupied entries, compacted into the key buffer (the table stays where it is) ----
-  uint32_t keys1[SPT];
-  uint32_t mine = 0;
-#pragma unroll
+  uint32_t mine = 0;                                                     // (counted now, read again for the copy: eight keys held across
+#pragma unroll                                                           //  the scan below were the registers this kernel was short of)
   for (int q = 0; q < SPT; q++) {
     const uint32_t slot = (uint32_t)q * NT + tid;
-    keys1[q] = slot < capT ? T[slot].x : 0u;
-    mine += keys1[q] != 0u ? 1u : 0u;
+    mine += (slot < capT && Tk[slot] != 0u) ? 1u : 0u;
   }
   auto block_exclusive = [&](uint32_t v, uint32_t &total) __attribute__((always_inline)) {
     const uint32_t incl = wave_incl_scan(v);
     if (lane == 63) bs_wsum[wv] = incl;
     __syncthreads();
-    uint32_t base = incl - v, tot = 0;
-    for (int q = 0; q < NT / 64; q++) { const uint32_t w = bs_wsum[q]; base += q < wv ? w : 0u; tot += w; }
-    total = tot;
+    // the waves' totals: one read per lane and a scan (a loop over the waves kept all of them in registers at once)
+    const uint32_t wt = lane < NT / 64 ? bs_wsum[lane] : 0u;
+    const uint32_t wincl = wave_incl_scan(wt);
+    const uint32_t base = incl - v + (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wv);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
     __syncthreads();
     return base;
   };
   uint32_t nb = 0;
   uint32_t at = block_exclusive(mine, nb);
   uint32_t nb32 = 64u * KPL; while (nb32 < nb) nb32 <<= 1;               // (whole wave segments of 64 x KPL keys)
-  if (nb32 > kl || nb32 > 64u * KPL * (NT / 64)) return false;           // more blocks than the registers of the sort hold
+  if (nb32 > kl || nb32 > 64u * KPL * (NT / 64)) { if (dbg) atomicAdd(&a.dbg[9], 1ULL); return false; }   // more blocks than the registers of the sort hold
 #pragma unroll
-  for (int q = 0; q < SPT; q++) if (keys1[q] != 0u) Kk[at++] = keys1[q];
+  for (int q = 0; q < SPT; q++) {
+    const uint32_t slot = (uint32_t)q * NT + tid;
+    const uint32_t key1 = slot < capT ? Tk[slot] : 0u;
+    if (key1 != 0u) Kk[at++] = key1;
+  }
   for (uint32_t i = nb + tid; i < nb32; i += NT) Kk[i] = 0xFFFFFFFFu;
   __syncthreads();
   phase(6);
@@ -825,26 +834,31 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   //      room the (key, place) pairs go back through it so that EVERY thread expands its share of the entries ----
   auto bitmap_of = [&](uint32_t key1) __attribute__((always_inline)) {
     uint32_t h = ((key1 - 1u) * 0x9E3779B1u) >> (32u - lg);
-    uint2 e = T[h];
-    while (e.x != key1) { h = (h + 1u) & mask; e = T[h]; }
-    return e.y;
+    while (Tk[h] != key1) h = (h + 1u) & mask;
+    return Tb[h];
   };
-  uint32_t bits[KPL], place_of[KPL];
+  uint32_t place_of[KPL];
   uint32_t wave_total = 0;
 #pragma unroll
   for (int j = 0; j < KPL; j++) {
-    bits[j] = (active && k[j] != 0xFFFFFFFFu) ? bitmap_of(k[j]) : 0u;
-    const uint32_t c = (uint32_t)__popc(bits[j]);
+    const uint32_t c = (active && k[j] != 0xFFFFFFFFu) ? (uint32_t)__popcll(bitmap_of(k[j])) : 0u;   // (the bitmap itself is fetched again where it is expanded)
     const uint32_t incl = wave_incl_scan(c);
     place_of[j] = wave_total + incl - c;
     wave_total += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   }
   if (lane == 0) bs_wsum[wv] = wave_total;
   __syncthreads();                                                       // (also: these probes of the table are done)
-  uint32_t base = 0, total = 0;
-  for (int q = 0; q < NT / 64; q++) { const uint32_t w = bs_wsum[q]; base += q < wv ? w : 0u; total += w; }
-  if (total != n) return false;                                          // (cannot happen: a record sits in one list only)
-  const bool spread = 2u * nb32 <= kl && nb32 <= (uint32_t)(KPL * NT);   // room for the pairs, and at most KPL entries per thread
+  const uint32_t wt = lane < NT / 64 ? bs_wsum[lane] : 0u;
+  const uint32_t wincl = wave_incl_scan(wt);
+  uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wv);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
+  if (total != n) { if (dbg) atomicAdd(&a.dbg[10], 1ULL); return false; }   // (cannot happen: a record sits in one list only)
+  // (an entry is expanded as two 32-bit halves: a 64-bit lowest-set-bit loop costs twice the instructions per hit)
+  auto expand = [&](uint32_t half, uint32_t first, uint32_t o) __attribute__((always_inline)) {
+    while (half) { A[o++] = first | (uint32_t)(__ffs((int)half) - 1); half &= half - 1u; }
+  };
+  constexpr int HPT = NT >= 512 ? 2 : 4;                                 // halves per thread at most (registers)
+  const bool spread = 2u * nb32 <= kl && 2u * nb32 <= (uint32_t)(HPT * NT);  // room for the pairs, and at most HPT halves per thread
   if (spread) {
     uint2 *KP = (uint2 *)Kk;
     if (active) {
@@ -852,21 +866,31 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
       for (int j = 0; j < KPL; j++) KP[pos0 + (uint32_t)j * 64u] = make_uint2(k[j], base + place_of[j]);
     }
     __syncthreads();
+    uint32_t half[HPT], first[HPT], at[HPT];
+#pragma unroll
+    for (int j = 0; j < HPT; j++) {
+      const uint32_t e = (uint32_t)j * NT + tid;                         // half e & 1 of entry e >> 1
+      const uint2 kp = (e >> 1) < nb ? KP[e >> 1] : make_uint2(0xFFFFFFFFu, 0u);
+      const unsigned long long b = kp.x != 0xFFFFFFFFu ? bitmap_of(kp.x) : 0ULL;
+      const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+      half[j] = (e & 1u) ? hi : lo;
+      first[j] = ((kp.x - 1u) << 6) | ((e & 1u) << 5);
+      at[j] = kp.y + ((e & 1u) ? (uint32_t)__popc(lo) : 0u);
+    }
+    __syncthreads();                                                     // (every probe of the table is done)
+#pragma unroll
+    for (int j = 0; j < HPT; j++) expand(half[j], first[j], at[j]);
+  } else {
+    unsigned long long bits[KPL];
+#pragma unroll
+    for (int j = 0; j < KPL; j++) bits[j] = (active && k[j] != 0xFFFFFFFFu) ? bitmap_of(k[j]) : 0ULL;
+    __syncthreads();                                                     // (every probe of the table is done)
 #pragma unroll
     for (int j = 0; j < KPL; j++) {
-      const uint32_t e = (uint32_t)j * NT + tid;
-      const uint2 kp = e < nb ? KP[e] : make_uint2(0xFFFFFFFFu, 0u);
-      k[j] = kp.x; place_of[j] = kp.y;
-      bits[j] = kp.x != 0xFFFFFFFFu ? bitmap_of(kp.x) : 0u;
+      const uint32_t lo = (uint32_t)bits[j], hi = (uint32_t)(bits[j] >> 32), f0 = (k[j] - 1u) << 6, o = base + place_of[j];
+      expand(lo, f0, o);
+      expand(hi, f0 | 32u, o + (uint32_t)__popc(lo));
     }
-    base = 0;
-    __syncthreads();                                                     // (every probe of the table is done)
-  }
-#pragma unroll
-  for (int j = 0; j < KPL; j++) {
-    uint32_t b = bits[j], o = base + place_of[j];
-    const uint32_t first = (k[j] - 1u) << 5;
-    while (b) { A[o++] = first | (uint32_t)(__ffs((int)b) - 1); b &= b - 1u; }
   }
   __syncthreads();
   return true;
@@ -1140,7 +1164,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     auto scan_run = [&](auto tag) __attribute__((always_inline)) {
       using G = decltype(tag);
       constexpr bool NARROW = sizeof(G) == 4;
-      constexpr int CB = NARROW ? 9 : 6;                                     // steps per batch (registers: one or two per step)
+      constexpr int CB = NARROW ? 9 : 7;                                     // steps per batch (registers: one or two per step)
       auto coord = [&](uint32_t step) __attribute__((always_inline)) -> G {
         const uint32_t idx = step * 64u + (uint32_t)lane;
         if (!(step <= s1 && idx < n)) return (G)0;
@@ -2141,6 +2165,54 @@ struct Slide {
     rl = rstar * LNB + lbase;                                     // address of slot r* (= state of rank r*-1)
     best = shared;
   }
+#ifdef FA_SCAN_BCACHE
+  // EXPERIMENT (scripts/ubench/slide_chain.hip -DFA_SCAN_BCACHE; profiles/EXPERIMENTS.md, round 4): the two boundary slots
+  // (ranks r*-1 and r*) cached in registers and patched by the events that touch them, the touched slot of the NEXT event
+  // requested one event ahead (forwarded when this event writes it), the far side of the cache refilled right behind a
+  // pivot move and consumed by the next event -- 2 reads + 1 write per event as in `step`, none of them between two pivot
+  // decisions.
+  uint32_t b0, b1, vnext, nv_prev, rf;
+  int addr_prev, dprev;
+  __device__ __forceinline__ void bc_begin(uint32_t first_word_addr_value, int first_addr) {
+    b0 = ld(rl); b1 = ld(rl + LNB); vnext = first_word_addr_value; addr_prev = -1; nv_prev = 0; rf = 0; dprev = 0; (void)first_addr;
+  }
+  template <int SH, int SHN> __device__ __forceinline__ void step_bc(uint32_t word, uint32_t word_next) {
+    const int dM = __builtin_amdgcn_sbfe(word, SH + EV_DM, 2), dW = __builtin_amdgcn_sbfe(word, SH + EV_DW, 2);
+    const int drp = (int)__builtin_amdgcn_ubfe(word, SH + EV_DROP, 1);
+    const int addr = slot_addr<SH>(word);
+    const uint32_t v = (addr == addr_prev) ? nv_prev : vnext;     // (the request for this slot went out before the last event's write)
+    vnext = ld(slot_addr<SHN>(word_next));                        // the next event's slot, before this event's write
+    const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
+    overflow |= nv;
+    sto(addr, nv);
+    addr_prev = addr; nv_prev = nv;
+    // the cache as the last pivot move left it: the far side comes from the refill requested then
+    const uint32_t c0 = dprev > 0 ? b1 : (dprev < 0 ? rf : b0);
+    const uint32_t c1r = dprev > 0 ? rf : (dprev < 0 ? b0 : b1);
+    b0 = (addr == rl) ? nv : c0;
+    b1 = (addr == rl + LNB) ? nv : c1r;
+    const bool below = addr <= rl;
+    const int dWb = below ? dW : 0;
+    shared += below ? dM : 0;
+    g += dWb;
+    const uint32_t vb = drp ? b1 : b0;
+    const int c1 = (int)(vb >> 1), mbm = __builtin_amdgcn_sbfe(vb, 0, 1);
+    const bool up = ((dW & (g + c1 - 1)) < 0);
+    const bool down = dWb > 0 && g > 0;
+    const int delta = up ? 1 : (down ? -1 : 0);
+    g += __mul24(delta, c1);
+    shared += delta & mbm;
+    rl += __mul24(delta, LNB);
+    rf = ld(rl + (delta > 0 ? LNB : 0));                          // behind this event's write; consumed by the next event
+    dprev = delta;
+    beg += drp;
+    const int sh_e = (int)((uint32_t)shared | ((word << ((32 - SH - 8 * (int)sizeof(T)) & 31)) & 0x80000000u));
+    const bool gt = sh_e > best, ge = sh_e >= best;
+    best = max(best, sh_e);
+    opt_s = gt ? beg : opt_s;
+    opt_e = ge ? beg : opt_e;
+  }
+#endif
   // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
   template <int SH> __device__ __forceinline__ void step(uint32_t word) {
     const int dM = __builtin_amdgcn_sbfe(word, SH + EV_DM, 2), dW = __builtin_amdgcn_sbfe(word, SH + EV_DW, 2);
@@ -2221,6 +2293,21 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   }
   sl.read_pivot();
   if (!fill_groups) sl.best = -1;
+#ifdef FA_SCAN_BCACHE
+  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "event width");
+  if (fill_groups < ngroups) sl.bc_begin(Slide<T, ST, LNT, true>::ld(sl.template slot_addr<0>(word_of(cur, 0))), 0);
+  for (uint32_t g = fill_groups; g < ngroups; g++) {
+    const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+      const uint32_t wn = q + 1 < PER ? word_of(cur, q + 1) : nxt.x;     // (the padding word 0 addresses slot 0: harmless)
+      if (sizeof(T) == 2) {
+        if (q & 1) sl.template step_bc<16, 0>(word_of(cur, q), wn); else sl.template step_bc<0, 16>(word_of(cur, q), wn);
+      } else sl.template step_bc<0, 0>(word_of(cur, q), wn);
+    }
+    cur = nxt;
+  }
+#else
   for (uint32_t g = fill_groups; g < ngroups; g++) {
     const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);   // prefetch: the load is off the chain
 #pragma unroll
@@ -2229,6 +2316,7 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
     }
     cur = nxt;
   }
+#endif
   if (sl.overflow >> Slide<T, ST, LNT, true>::SBITS) {
     if (!REDO) { a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u); return; }
   }

@@ -122,6 +122,15 @@ int main(int argc, char **argv) {
     const double us = best * 1e3, per_ev_ns = us * 1e3 / EV;
     printf("  %-34s %9d %9.1f %12.0f %14.1f %16.1f\n", c.name, c.waves, us, f, per_ev_ns, per_ev_ns * f * 1e-3);
   }
+  {
+    // (results of the last launch: the same checksum from every variant of the slide built into this binary's kernel)
+    std::vector<int32_t> hs(4096), hp(4096);
+    CHECK(hipMemcpy(hs.data(), a.l_shared, hs.size() * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(hp.data(), a.l_pos, hp.size() * 4, hipMemcpyDeviceToHost));
+    unsigned long long sum = 0;
+    for (size_t i = 0; i < hs.size(); i++) sum = sum * 1000003ULL + (unsigned long long)(uint32_t)hs[i] * 31ULL + (unsigned long long)(uint32_t)hp[i];
+    printf("# checksum of l_shared / l_pos over the first 4096 loci: %016llx\n", sum);
+  }
   printf("# ns / cycles per event divide the launch time by the %d pivot events of a lane (the %d bulk admits and the pivot read-off ride along: ~15 %% of the time);\n", EV, FILL);
   printf("# at two waves per SIMD a SIMD executes two events in that time.\n");
   return 0;

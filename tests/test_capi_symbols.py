@@ -83,3 +83,22 @@ def test_compute_fails_loudly_without_device():
         len(sk.minimizers)
     with pytest.raises(RuntimeError, match="no HIP device"):
         sk.index()
+
+
+def test_no_kernel_of_the_library_needs_scratch_memory():
+    """The HIP runtime keeps a scratch allocation per stream for good once any kernel has asked for one (a mapper life cycle
+    then leaks a few MB of HBM: scripts/check_leaks.py); register spills also cost the hot kernels their occupancy targets.
+    The build keeps the compiler's resource remarks (`__graft_entry__._write_kernel_resources`): every `fa::` kernel must
+    report zero scratch (rocPRIM's radix sort at index time is the one exception, on the sketch's own stream)."""
+    import json
+    path = os.path.join(ROOT, "pyfastani_amd", "lib", "libfastani_hip.so.kernels.json")
+    if not os.path.exists(path):
+        import __graft_entry__ as entry
+        entry.build(force=True)
+    kernels = json.load(open(path))
+    ours = {k: v for k, v in kernels.items() if k.startswith("_ZN2fa")}
+    assert len(ours) > 40, len(ours)
+    spilled = {k: v["scratch_bytes_per_lane"] for k, v in ours.items() if v["scratch_bytes_per_lane"]}
+    assert not spilled, spilled
+    hot = [v for k, v in ours.items() if "k_l1ILi" in k and "ELi16E" in k]
+    assert hot and all(v["occupancy_waves_per_simd"] == 8 for v in hot), hot
