@@ -835,22 +835,53 @@ static uint32_t build_frag_order(const fa_genomes &g, int32_t g0, int64_t f0, in
 // alone holds more fragments than pass_fragments(), or when the loci / seeds / slide events of the range exceed what
 // the 32-bit offsets of the workspace can address: the parts share the CGI bin table (step 2 of computeCGI is an
 // atomicMax, so it simply accumulates) and the rows are formed after the last part.
-static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
-                              int64_t row_base, fa_cgi_row *host_rows = nullptr) {
-  hipStream_t st = w.stream;
-  const int64_t range_f0 = g.genome_frag_lo[g0], range_f1 = g.genome_frag_lo[g1];
-  const int NQ = g1 - g0;
-  w.last_F = 0; w.last_f0 = range_f0; w.last_loci = 0; w.last_genomes = &g;
-  for (int i = 0; i < 6; i++) if (!w.ev[i]) FA_HIP(hipEventCreate(&w.ev[i]));
-  if (range_f1 == range_f0) return 0;
-  FA_REQUIRE(m.P.fragment_length > 20, FA_ERR_UNSUPPORTED, "fragment_length must exceed 20 (the reference bins by fragment_length - 20)");
-  const int qcap = m.qcap;
-  const IndexView ix = m.view();
-  const int64_t npairs = (int64_t)NQ * m.G;
+//
+// The pass as an object: what the stages share are its members, and the seams are its methods -- speculation (fetch_spec /
+// publish_spec / scan_occupancy), the plan of the pass (plan: buffers, lanes, the bin table), the launches of one part
+// (launch_part, launch_rows) and the verdict on a finished part (judge_part); run() queues the parts.
+struct QueryPass {
+  struct Range { int64_t f0, f1; bool unfused; };     // unfused: the repeat of a range that overflowed k_query_fused
+  struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; bool fused = false, forced_unfused = false, ordered = false; };
+  // ---- what the caller gave ----
+  fa_mapper &m;
+  Workspace &w;
+  const fa_genomes &g;
+  const int32_t g0, g1;
+  fa_cgi_row *const rows_dev;
+  const int64_t cap, row_base;
+  fa_cgi_row *const host_rows;
+  // ---- constants of the pass ----
+  hipStream_t st;
+  const int64_t range_f0, range_f1;
+  const int NQ, qcap;
+  const IndexView ix;
+  const int64_t npairs;
+  uint64_t items_max = 0;
+  size_t qs_lds = 0;
+  int64_t F_total = 0, auto_part = 0;
+  Workspace *lanes[3];
+  int n_lanes = 1;
+  // ---- state of the run ----
   // the speculated bounds are shared by all workspaces: every attempt works on a copy taken under the lock and
   // publishes what it learnt (bounds only ever grow, except the LDS seed slots, which follow the latest pass)
   fa_mapper::Spec sp;
-  auto fetch_spec = [&] {
+  bool bins_cleared = false;
+  std::deque<Range> todo;
+  std::deque<Run> flight;
+  bool busy[3] = {false, false, false}, ran[3] = {false, false, false};
+  bool rows_valid = false;
+  int rows_lane = -1;
+  unsigned long long t_begin = ~0ULL, t_end = 0;
+  int attempts = 0;
+
+  QueryPass(fa_mapper &m_, Workspace &w_, const fa_genomes &g_, int32_t g0_, int32_t g1_, fa_cgi_row *rows_dev_, int64_t cap_, int64_t row_base_, fa_cgi_row *host_rows_)
+      : m(m_), w(w_), g(g_), g0(g0_), g1(g1_), rows_dev(rows_dev_), cap(cap_), row_base(row_base_), host_rows(host_rows_), st(w_.stream),
+        range_f0(g_.genome_frag_lo[g0_]), range_f1(g_.genome_frag_lo[g1_]), NQ(g1_ - g0_), qcap(m_.qcap), ix(m_.view()), npairs((int64_t)(g1_ - g0_) * m_.G) {
+    lanes[0] = &w; lanes[1] = lanes[2] = nullptr;
+  }
+
+  // ================================================ speculation ================================================
+  void fetch_spec() {
     std::lock_guard<std::mutex> lock(m.mtx);
     fa_mapper::Spec &ms = m.spec;
     if (!ms.init) {
@@ -867,8 +898,8 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     FA_REQUIRE(sp.smax < 32768, FA_ERR_UNSUPPORTED, "query sketch larger than 32767 minimizers");
     ensure_luts(m, sp.smax);
     w.lut_min_hits = m.d_min_hits.p; w.lut_pass = m.d_pass.p; w.lut_ident = m.d_ident.p;
-  };
-  auto publish_spec = [&](const fa_mapper::Spec &sp) {
+  }
+  void publish_spec(const fa_mapper::Spec &sp) {
     std::lock_guard<std::mutex> lock(m.mtx);
     fa_mapper::Spec &ms = m.spec;
     ms.smax = std::max(ms.smax, sp.smax);
@@ -879,71 +910,83 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
     ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
-  };
-  fetch_spec();
-  // event offsets are 32-bit: at most this many slide events per part (FA_EVENTS_CAP_MAX: the tests force the split)
-  const uint64_t items_max = env_u64("FA_EVENTS_CAP_MAX", (1ULL << 32) - 64);
-  w.bins.ensure((size_t)NQ * std::max(m.total_bins, 1) + 2);
-  w.row_count.ensure((size_t)npairs + 1); w.row_ident.ensure((size_t)npairs + 1);
-  w.row_flag.ensure((size_t)npairs + 1); w.row_off.ensure((size_t)npairs + 1);
-  const size_t qs_lds = (size_t)next_pow2((uint32_t)std::max(qcap, 2)) * 4;
-  FA_REQUIRE(qs_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
-
-  // ---- the parts of the pass; optionally (FA_QUERY_LANES = 2 or 3) pipelined over *lanes*: sub-workspaces with their own
-  // stream and buffers, so that part n + 1 is sketched and looked up while part n slides.  The parts share the CGI bin
-  // table (atomicMax); the rows are formed on the lane of the last part, behind the bins of all lanes.  Every part keeps
-  // its own speculation verdict: a void part is queued again (and the rows, if they were formed already, are formed
-  // again after it).  Measured: no gain (bench step 0.623 / 0.622 / 0.641 ms with 1 / 2 / 3 lanes, 16 queries per
-  // launch 237 k / 240 k pairs/s, config 3 2.59 M / 2.55 M) -- every kernel of the path runs its workgroups in one or a
-  // few resident rounds, so a third of the fragments takes nearly as long as all of them, and what the lanes add in
-  // overlap they lose in occupancy.  Hence one lane by default; profiles/EXPERIMENTS.md.
-  static const int lanes_wanted = (int)std::min<uint64_t>(3, std::max<uint64_t>(1, env_u64("FA_QUERY_LANES", 1)));
-  static const int64_t lane_min_frags = (int64_t)env_u64("FA_LANE_MIN_FRAGMENTS", 256);
-  const int64_t F_total = range_f1 - range_f0;
-  int64_t auto_part = F_total;
-  if (lanes_wanted > 1 && F_total >= 2 * lane_min_frags) {
-    const int64_t parts = std::min<int64_t>(lanes_wanted, F_total / lane_min_frags);
-    auto_part = (F_total + parts - 1) / parts;
   }
-  Workspace *lanes[3] = {&w, nullptr, nullptr};
-  int n_lanes = 1;
-  if (lanes_wanted > 1 && std::min<int64_t>(auto_part, sp.part_frags) < F_total) {
-    for (int i = 0; i + 1 < lanes_wanted; i++) {
-      if (!w.sub[i]) w.sub[i].reset(new Workspace());
-      Workspace &x = *w.sub[i];
-      if (!x.stream) FA_HIP(hipStreamCreate(&x.stream));
-      lanes[n_lanes++] = &x;
+  // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
+  // instantiation (wide events, fewer than 64 loci per scan workgroup) or the runtime does not say
+  int scan_occupancy(int smax) {
+    const int slots = smax + 1;
+    if (slots + 1 >= (1 << EvBits<uint16_t>::RANK) || !m.packed_geo) return 0;
+    const size_t lds_scan = ((size_t)(slots + 1) * L2_THREADS + 15) / 16 * 16;
+    if (lds_scan > 64 * 1024) return 0;
+    const int per_window = std::max(1, 2 * m.P.fragment_length / (m.P.window_size + 1));
+    const int ev_stage = std::min(2048, std::max(512, (per_window * 11 / 2 + 127) & ~127));
+    const size_t lds_ev = ev_sketch_bytes(slots) + (size_t)ev_stage * 2 * (EV_THREADS / 64) + 16;
+    if (lds_ev > 64 * 1024) return 0;
+    int n_scan = 0, n_ev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_scan, (const void *)k_l2_scan<uint16_t, uint8_t, 64>, L2_THREADS, lds_scan) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_ev, (const void *)k_l2_events<uint16_t, true>, EV_THREADS, lds_ev) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
     }
-  }
-  w.serial++;
-  w.pass_f0 = range_f0; w.pass_F = range_f1 - range_f0;
-  for (int i = 0; i < n_lanes; i++) for (int e = 0; e < 6; e++) if (!lanes[i]->ev[e]) FA_HIP(hipEventCreate(&lanes[i]->ev[e]));
-  if (!w.ev_bins) FA_HIP(hipEventCreate(&w.ev_bins));
-  // the CGI bin table is cleared once per pass: with one lane by the k_clear of the first part launched (a void first
-  // part cleared it all the same), with several lanes up front on the first lane's stream, which the others wait for
-  bool bins_cleared = npairs == 0;
-  if (n_lanes > 1) {
-    if (npairs > 0) FA_HIP(hipMemsetAsync(w.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
-    bins_cleared = true;
-    FA_HIP(hipEventRecord(w.ev_bins, st));
+    return n_scan > 0 && n_ev > 0 ? n_scan * 64 + n_ev : 0;
   }
 
-  struct Range { int64_t f0, f1; bool unfused; };     // unfused: the repeat of a range that overflowed k_query_fused
-  struct Run { int lane; int64_t f0, f1; fa_mapper::Spec sp; bool with_rows; bool fused = false, forced_unfused = false, ordered = false; };
-  std::deque<Range> todo;
-  todo.push_back(Range{range_f0, range_f1, false});
-  std::deque<Run> flight;
-  bool busy[3] = {false, false, false}, ran[3] = {false, false, false};
-  bool rows_valid = false;
-  int rows_lane = -1;
-  unsigned long long t_begin = ~0ULL, t_end = 0;
-  int attempts = 0;
+  // ================================================ the plan of the pass =======================================
+  void plan() {
+    // event offsets are 32-bit: at most this many slide events per part (FA_EVENTS_CAP_MAX: the tests force the split)
+    items_max = env_u64("FA_EVENTS_CAP_MAX", (1ULL << 32) - 64);
+    w.bins.ensure((size_t)NQ * std::max(m.total_bins, 1) + 2);
+    w.row_count.ensure((size_t)npairs + 1); w.row_ident.ensure((size_t)npairs + 1);
+    w.row_flag.ensure((size_t)npairs + 1); w.row_off.ensure((size_t)npairs + 1);
+    qs_lds = (size_t)next_pow2((uint32_t)std::max(qcap, 2)) * 4;
+    FA_REQUIRE(qs_lds <= 150 * 1024, FA_ERR_UNSUPPORTED, "fragment_length too large for the LDS fragment sort");
+
+    // ---- the parts of the pass; optionally (FA_QUERY_LANES = 2 or 3) pipelined over *lanes*: sub-workspaces with their own
+    // stream and buffers, so that part n + 1 is sketched and looked up while part n slides.  The parts share the CGI bin
+    // table (atomicMax); the rows are formed on the lane of the last part, behind the bins of all lanes.  Every part keeps
+    // its own speculation verdict: a void part is queued again (and the rows, if they were formed already, are formed
+    // again after it).  Measured: no gain (bench step 0.623 / 0.622 / 0.641 ms with 1 / 2 / 3 lanes, 16 queries per
+    // launch 237 k / 240 k pairs/s, config 3 2.59 M / 2.55 M) -- every kernel of the path runs its workgroups in one or a
+    // few resident rounds, so a third of the fragments takes nearly as long as all of them, and what the lanes add in
+    // overlap they lose in occupancy.  Hence one lane by default; profiles/EXPERIMENTS.md.
+    static const int lanes_wanted = (int)std::min<uint64_t>(3, std::max<uint64_t>(1, env_u64("FA_QUERY_LANES", 1)));
+    static const int64_t lane_min_frags = (int64_t)env_u64("FA_LANE_MIN_FRAGMENTS", 256);
+    F_total = range_f1 - range_f0;
+    auto_part = F_total;
+    if (lanes_wanted > 1 && F_total >= 2 * lane_min_frags) {
+      const int64_t parts = std::min<int64_t>(lanes_wanted, F_total / lane_min_frags);
+      auto_part = (F_total + parts - 1) / parts;
+    }
+    if (lanes_wanted > 1 && std::min<int64_t>(auto_part, sp.part_frags) < F_total) {
+      for (int i = 0; i + 1 < lanes_wanted; i++) {
+        if (!w.sub[i]) w.sub[i].reset(new Workspace());
+        Workspace &x = *w.sub[i];
+        if (!x.stream) FA_HIP(hipStreamCreate(&x.stream));
+        lanes[n_lanes++] = &x;
+      }
+    }
+    w.serial++;
+    w.pass_f0 = range_f0; w.pass_F = range_f1 - range_f0;
+    for (int i = 0; i < n_lanes; i++) for (int e = 0; e < 6; e++) if (!lanes[i]->ev[e]) FA_HIP(hipEventCreate(&lanes[i]->ev[e]));
+    if (!w.ev_bins) FA_HIP(hipEventCreate(&w.ev_bins));
+    // the CGI bin table is cleared once per pass: with one lane by the k_clear of the first part launched (a void first
+    // part cleared it all the same), with several lanes up front on the first lane's stream, which the others wait for
+    bins_cleared = npairs == 0;
+    if (n_lanes > 1) {
+      if (npairs > 0) FA_HIP(hipMemsetAsync(w.bins.p, 0, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long), st));
+      bins_cleared = true;
+      FA_HIP(hipEventRecord(w.ev_bins, st));
+    }
+
+  }
+
+  // ================================================ launches ===================================================
   // the lane that forms the rows waits for the bins of the parts launched on the other lanes
-  auto join_lanes = [&](int me) {
+  void join_lanes(int me) {
     for (int i = 0; i < n_lanes; i++) if (i != me && ran[i]) FA_HIP(hipStreamWaitEvent(lanes[me]->stream, lanes[i]->ev[4], 0));
-  };
+  }
   // forms the rows; returns true if the kernel also hands the pass over to the host (small passes: its last workgroup does)
-  auto launch_rows = [&](Workspace &ln, const PublishArgs &pub) -> bool {
+  bool launch_rows(Workspace &ln, const PublishArgs &pub) {
     hipStream_t st = ln.stream;
     uint32_t *const d_counters = ln.status.p->counters;
     int32_t *const d_total_rows = &ln.status.p->total_rows;
@@ -966,17 +1009,35 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
                          npairs, g.d_total_frag + g0, g0, rows_dev + row_base, cap - row_base);
     }
     return ra.emit != 0;
+  }
+  // what the stage launches of one part share (sized by size_part)
+  struct Part {
+    Workspace &ln;
+    hipStream_t st;
+    const fa_mapper::Spec &sp;
+    const int64_t f0, f1, F;
+    const int t0, ntiles;
+    const int smax;
+    const int64_t l_cap;
+    int l1_threads = 256, l1_nt = 256;
+    uint32_t seed_slots = 0;
+    bool wide = false;
+    Part(QueryPass &q, Run &r)
+        : ln(*q.lanes[r.lane]), st(ln.stream), sp(r.sp), f0(r.f0), f1(r.f1), F(r.f1 - r.f0), t0(q.g.frag_tile_lo[r.f0]),
+          ntiles(q.g.frag_tile_lo[r.f1] - q.g.frag_tile_lo[r.f0]), smax(r.sp.smax), l_cap(r.sp.l_cap) {}
   };
-  auto launch_part = [&](Run &r) {
-    Workspace &ln = *lanes[r.lane];
-    hipStream_t st = ln.stream;
-    const fa_mapper::Spec &sp = r.sp;
-    const int64_t f0 = r.f0, f1 = r.f1, F = f1 - f0;
+
+  // one part: its buffers, then the stages in order, then the hand-over -- all asynchronous on the lane's stream
+  void launch_part(Run &r) {
+    Part p(*this, r);
+    Workspace &ln = p.ln;
+    hipStream_t st = p.st;
+    const fa_mapper::Spec &sp = p.sp;
+    const int64_t f0 = p.f0, f1 = p.f1, F = p.F;
     ln.serial = w.serial;
     if (&ln != &w) FA_HIP(hipStreamWaitEvent(st, w.ev_bins, 0));     // (the bin table is cleared on the first lane's stream)
     ln.last_F = 0; ln.last_f0 = f0; ln.last_loci = 0;                 // (filled in when the part is accepted)
-    const int t0 = g.frag_tile_lo[f0], t1 = g.frag_tile_lo[f1];
-    const int ntiles = t1 - t0;
+    const int ntiles = p.ntiles;
     // buffers whose size depends only on the geometry of the part
     ln.sk.stage_hash.ensure((size_t)std::max(ntiles, 1) * TILE);
     ln.sk.stage_wpos.ensure((size_t)std::max(ntiles, 1) * TILE);
@@ -989,20 +1050,19 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       FA_HIP(hipHostMalloc((void **)&ln.h_status, sizeof(PassStatus), hipHostMallocMapped | hipHostMallocCoherent));
       memset(ln.h_status, 0, sizeof(PassStatus));
     }
-    int32_t *const d_stats = ln.status.p->stats;
-    uint64_t *const d_totals = ln.status.p->totals;
-    uint32_t *const d_counters = ln.status.p->counters;
-    unsigned long long *const d_pinfo = ln.status.p->pinfo;
     // ---- buffers and tables sized by the speculated bounds ----
-    const int smax = sp.smax;
-    const int64_t l_cap = sp.l_cap;
+    const int smax = p.smax;
+    const int64_t l_cap = p.l_cap;
     // LDS also holds smax list offsets; the in-place merge keeps at most 32 seeds per thread in registers
     // threads per fragment in k_l1: 256 while 16 seeds per thread suffice (4-wave workgroups, eight per CU: a 5 Mb query
     // is one round of workgroups), else 512; FA_L1_THREADS = 256 / 512 / 1024 forces one
     static const int l1_forced = (int)exp_u64("FA_L1_THREADS", 0);
-    const int l1_threads = l1_forced ? l1_forced : (std::min(sp.seed_slots, lds_seed_cap_max(sp.smax)) <= 16 * 256 ? 256 : 512);
-    const int l1_nt = l1_threads >= 1024 ? 1024 : (l1_threads >= 512 ? 512 : 256);
-    const uint32_t seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * l1_nt));
+    p.l1_threads = l1_forced ? l1_forced : (std::min(sp.seed_slots, lds_seed_cap_max(sp.smax)) <= 16 * 256 ? 256 : 512);
+    p.l1_nt = p.l1_threads >= 1024 ? 1024 : (p.l1_threads >= 512 ? 512 : 256);
+    p.seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * p.l1_nt));
+    // (a 512-thread workgroup is eight waves: four of them fill a CU whatever their LDS up to 39 KB, so the block table of
+    // l1_block_sort -- a third as many entries as seed slots -- gets all the slots the 16-per-thread form can address)
+    if (p.l1_nt == 512 && p.seed_slots <= 16u * 512u) p.seed_slots = std::min<uint32_t>(16u * 512u, lds_seed_cap_max(smax));
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
     ln.l_rfirst.ensure((size_t)l_cap); ln.l_rlast.ensure((size_t)l_cap + 4); ln.l_rpart.ensure((size_t)l_cap);
     ln.l_group.ensure((size_t)l_cap); ln.l_shared.ensure((size_t)l_cap); ln.l_pos.ensure((size_t)l_cap);
@@ -1010,9 +1070,30 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     ln.l_beg.ensure((size_t)l_cap); ln.l_end0.ensure((size_t)l_cap); ln.l_last.ensure((size_t)l_cap); ln.l_ndrop.ensure((size_t)l_cap);
     ln.l_nev.ensure((size_t)l_cap); ln.l_ioff.ensure((size_t)l_cap); ln.l_redo.ensure((size_t)l_cap + 4);
     ln.ovf_buf.ensure((size_t)sp.scratch_words + 4);
-    const bool wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
-    ln.items.ensure(((size_t)sp.items_cap + 8) * (wide ? 4 : 2));
+    p.wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
+    ln.items.ensure(((size_t)sp.items_cap + 8) * (p.wide ? 4 : 2));
 
+    launch_sketch_stage(r, p);
+    launch_l1_stage(p);
+    launch_l2_stage(r, p);
+    launch_cgi_stage_and_hand_over(r, p);
+    ran[r.lane] = true;
+  }
+
+  // K1 (its extra workgroups zero the tables of the part) + per-fragment sort / unique / index lookup
+  void launch_sketch_stage(Run &r, Part &p) {
+    Workspace &ln = p.ln;
+    hipStream_t st = p.st;
+    const fa_mapper::Spec &sp = p.sp;
+    const int64_t f0 = p.f0, F = p.F;
+    const int smax = p.smax;
+    const int64_t l_cap = p.l_cap;
+    int32_t *const d_stats = ln.status.p->stats;
+    uint64_t *const d_totals = ln.status.p->totals;
+    uint32_t *const d_counters = ln.status.p->counters;
+    unsigned long long *const d_pinfo = ln.status.p->pinfo;
+    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
+    const int t0 = p.t0, ntiles = p.ntiles;
     {
       ClearList cl;
       cl.add(ln.status.p, offsetof(PassStatus, stamp));
@@ -1039,6 +1120,23 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       }
     }
     debug_sync(st, "sketch");
+  }
+
+  // seed totals, then the candidate regions
+  void launch_l1_stage(Part &p) {
+    Workspace &ln = p.ln;
+    hipStream_t st = p.st;
+    const fa_mapper::Spec &sp = p.sp;
+    const int64_t f0 = p.f0, F = p.F;
+    const int smax = p.smax;
+    const int64_t l_cap = p.l_cap;
+    int32_t *const d_stats = ln.status.p->stats;
+    uint64_t *const d_totals = ln.status.p->totals;
+    uint32_t *const d_counters = ln.status.p->counters;
+    unsigned long long *const d_pinfo = ln.status.p->pinfo;
+    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
+    const uint32_t seed_slots = p.seed_slots;
+    const int l1_threads = p.l1_threads, l1_nt = p.l1_nt;
     // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch).  A kernel of its own
     //      only where k_l1 / k_l1_big need the scratch offsets it produces; else workgroup F of k_l1's launch ----
     const bool fold_totals = sp.scratch_words == 0;
@@ -1096,6 +1194,23 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
       else go(std::integral_constant<int, 256>());
     }
     debug_sync(st, "l1");
+  }
+
+  // event streams, then the sequential slide
+  void launch_l2_stage(Run &r, Part &p) {
+    Workspace &ln = p.ln;
+    hipStream_t st = p.st;
+    const fa_mapper::Spec &sp = p.sp;
+    const int64_t f0 = p.f0, F = p.F;
+    const int smax = p.smax;
+    const int64_t l_cap = p.l_cap;
+    int32_t *const d_stats = ln.status.p->stats;
+    uint64_t *const d_totals = ln.status.p->totals;
+    uint32_t *const d_counters = ln.status.p->counters;
+    unsigned long long *const d_pinfo = ln.status.p->pinfo;
+    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
+    const int64_t f1 = p.f1;
+    const bool wide = p.wide;
     // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
     {
       if (m.stage_events) FA_HIP(hipEventRecord(ln.ev[2], st));
@@ -1248,6 +1363,21 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     }
     debug_sync(st, "l2 scan");
     if (m.stage_events) FA_HIP(hipEventRecord(ln.ev[3], st));
+  }
+
+  // core-genome identity and the one hand-over of the part
+  void launch_cgi_stage_and_hand_over(Run &r, Part &p) {
+    Workspace &ln = p.ln;
+    hipStream_t st = p.st;
+    const fa_mapper::Spec &sp = p.sp;
+    const int64_t f0 = p.f0, F = p.F;
+    const int smax = p.smax;
+    const int64_t l_cap = p.l_cap;
+    int32_t *const d_stats = ln.status.p->stats;
+    uint64_t *const d_totals = ln.status.p->totals;
+    uint32_t *const d_counters = ln.status.p->counters;
+    unsigned long long *const d_pinfo = ln.status.p->pinfo;
+    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
     // ---- core-genome identity ----
     if (npairs > 0) {
       CgiArgs a;
@@ -1271,29 +1401,11 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
     debug_sync(st, "cgi");
     if (n_lanes > 1) FA_HIP(hipEventRecord(ln.ev[4], st));         // (join_lanes: the bins of this part)
     if (!published) hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, st, pub);
-    ran[r.lane] = true;
-  };
-  // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
-  // instantiation (wide events, fewer than 64 loci per scan workgroup) or the runtime does not say
-  auto scan_occupancy = [&](int smax) -> int {
-    const int slots = smax + 1;
-    if (slots + 1 >= (1 << EvBits<uint16_t>::RANK) || !m.packed_geo) return 0;
-    const size_t lds_scan = ((size_t)(slots + 1) * L2_THREADS + 15) / 16 * 16;
-    if (lds_scan > 64 * 1024) return 0;
-    const int per_window = std::max(1, 2 * m.P.fragment_length / (m.P.window_size + 1));
-    const int ev_stage = std::min(2048, std::max(512, (per_window * 11 / 2 + 127) & ~127));
-    const size_t lds_ev = ev_sketch_bytes(slots) + (size_t)ev_stage * 2 * (EV_THREADS / 64) + 16;
-    if (lds_ev > 64 * 1024) return 0;
-    int n_scan = 0, n_ev = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_scan, (const void *)k_l2_scan<uint16_t, uint8_t, 64>, L2_THREADS, lds_scan) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_ev, (const void *)k_l2_events<uint16_t, true>, EV_THREADS, lds_ev) != hipSuccess) {
-      (void)hipGetLastError();
-      return 0;
-    }
-    return n_scan > 0 && n_ev > 0 ? n_scan * 64 + n_ev : 0;
-  };
+  }
+
+  // ================================================ the verdict on a part ======================================
   // waits for a part and reads its verdict: true = accepted, false = void (its range has to run again)
-  auto finish_part = [&](Run &r) -> bool {
+  bool judge_part(Run &r) {
     Workspace &ln = *lanes[r.lane];
     fa_mapper::Spec &sp = r.sp;
     const int64_t F = r.f1 - r.f0;
@@ -1396,55 +1508,71 @@ static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, i
               ln.h_status->dbg[8], ln.h_status->dbg[9], ln.h_status->dbg[10]);
     }
     return true;
-  };
+  }
 
-  while (!todo.empty() || !flight.empty()) {
-    // launch on every free lane
-    for (int i = 0; i < n_lanes && !todo.empty(); i++) {
-      if (busy[i]) continue;
-      FA_REQUIRE(attempts < 40 + 4 * (int)(F_total / std::max<int64_t>(1, std::min(auto_part, sp.part_frags)) + 1), FA_ERR_INTERNAL,
-                 "query pass did not converge on its buffer sizes");
-      attempts++;
-      fetch_spec();
-      const Range range = todo.front(); todo.pop_front();
-      const int64_t f1 = std::min(range.f1, range.f0 + std::max<int64_t>(1, std::min(auto_part, sp.part_frags)));
-      if (f1 < range.f1) todo.push_front(Range{f1, range.f1, range.unfused});
-      Run r{i, range.f0, f1, sp, todo.empty() && npairs > 0};
-      r.forced_unfused = range.unfused;
-      if (r.with_rows) rows_valid = false;
-      launch_part(r);
-      busy[i] = true;
-      flight.push_back(r);
+
+  // ================================================ the pass ===================================================
+  int64_t run() {
+    w.last_F = 0; w.last_f0 = range_f0; w.last_loci = 0; w.last_genomes = &g;
+    for (int i = 0; i < 6; i++) if (!w.ev[i]) FA_HIP(hipEventCreate(&w.ev[i]));
+    if (range_f1 == range_f0) return 0;
+    FA_REQUIRE(m.P.fragment_length > 20, FA_ERR_UNSUPPORTED, "fragment_length must exceed 20 (the reference bins by fragment_length - 20)");
+    fetch_spec();
+    plan();
+    todo.push_back(Range{range_f0, range_f1, false});
+    while (!todo.empty() || !flight.empty()) {
+      // launch on every free lane
+      for (int i = 0; i < n_lanes && !todo.empty(); i++) {
+        if (busy[i]) continue;
+        FA_REQUIRE(attempts < 40 + 4 * (int)(F_total / std::max<int64_t>(1, std::min(auto_part, sp.part_frags)) + 1), FA_ERR_INTERNAL,
+                   "query pass did not converge on its buffer sizes");
+        attempts++;
+        fetch_spec();
+        const Range range = todo.front(); todo.pop_front();
+        const int64_t f1 = std::min(range.f1, range.f0 + std::max<int64_t>(1, std::min(auto_part, sp.part_frags)));
+        if (f1 < range.f1) todo.push_front(Range{f1, range.f1, range.unfused});
+        Run r{i, range.f0, f1, sp, todo.empty() && npairs > 0};
+        r.forced_unfused = range.unfused;
+        if (r.with_rows) rows_valid = false;
+        launch_part(r);
+        busy[i] = true;
+        flight.push_back(r);
+      }
+      // the oldest part in flight
+      Run r = flight.front(); flight.pop_front();
+      const bool ok = judge_part(r);
+      busy[r.lane] = false;
+      if (!ok) {
+        todo.push_front(Range{r.f0, r.f1, r.forced_unfused});
+        rows_valid = false;                     // (rows formed meanwhile lack this part)
+      }
     }
-    // the oldest part in flight
-    Run r = flight.front(); flight.pop_front();
-    const bool ok = finish_part(r);
-    busy[r.lane] = false;
-    if (!ok) {
-      todo.push_front(Range{r.f0, r.f1, r.forced_unfused});
-      rows_valid = false;                     // (rows formed meanwhile lack this part)
+    int64_t nrows = 0;
+    if (npairs > 0) {
+      if (!rows_valid) {
+        // a part was repeated after the rows had been formed: form them again, behind everything
+        Workspace &ln = w;
+        join_lanes(0);
+        FA_HIP(hipMemsetAsync(&ln.status.p->counters[4], 0, sizeof(uint32_t), ln.stream));
+        FA_HIP(hipMemsetAsync(&ln.status.p->total_rows, 0, sizeof(int32_t), ln.stream));
+        PassStatus *h_dev = nullptr;
+        FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
+        const PublishArgs pub = publish_args(ln.status.p, h_dev, ++ln.seq, rows_dev + row_base, host_rows ? host_rows + row_base : nullptr, cap - row_base);
+        if (!launch_rows(ln, pub)) hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, ln.stream, pub);
+        wait_published(ln.h_status, ln.seq, ln.stream);
+        rows_lane = 0;
+      }
+      nrows = lanes[rows_lane]->h_status->total_rows;
     }
+    if (t_end > t_begin) w.last_ms[4] += (float)((double)(t_end - t_begin) * 1e-5);   // device wall time of the pass
+    FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
+    return nrows;
   }
-  int64_t nrows = 0;
-  if (npairs > 0) {
-    if (!rows_valid) {
-      // a part was repeated after the rows had been formed: form them again, behind everything
-      Workspace &ln = w;
-      join_lanes(0);
-      FA_HIP(hipMemsetAsync(&ln.status.p->counters[4], 0, sizeof(uint32_t), ln.stream));
-      FA_HIP(hipMemsetAsync(&ln.status.p->total_rows, 0, sizeof(int32_t), ln.stream));
-      PassStatus *h_dev = nullptr;
-      FA_HIP(hipHostGetDevicePointer((void **)&h_dev, ln.h_status, 0));
-      const PublishArgs pub = publish_args(ln.status.p, h_dev, ++ln.seq, rows_dev + row_base, host_rows ? host_rows + row_base : nullptr, cap - row_base);
-      if (!launch_rows(ln, pub)) hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(256), 0, ln.stream, pub);
-      wait_published(ln.h_status, ln.seq, ln.stream);
-      rows_lane = 0;
-    }
-    nrows = lanes[rows_lane]->h_status->total_rows;
-  }
-  if (t_end > t_begin) w.last_ms[4] += (float)((double)(t_end - t_begin) * 1e-5);   // device wall time of the pass
-  FA_REQUIRE(nrows <= cap - row_base, FA_ERR_INVALID, "row buffer too small");
-  return nrows;
+};
+
+static int64_t run_query_pass(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_t g0, int32_t g1, fa_cgi_row *rows_dev, int64_t cap,
+                              int64_t row_base, fa_cgi_row *host_rows = nullptr) {
+  return QueryPass(m, w, g, g0, g1, rows_dev, cap, row_base, host_rows).run();
 }
 
 static int64_t run_query(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_t first, int32_t count, fa_cgi_row *rows, int64_t cap, bool rows_device) {

@@ -725,13 +725,11 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   __shared__ uint32_t bs_fail, bs_total;
   __shared__ uint32_t bs_wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t lg = 31u - (uint32_t)__clz((int)(cap / 3u));           // table entries (12 bytes each): the largest power of two <= cap / 3
-  const uint32_t capT = 1u << lg, mask = capT - 1u;
+  const uint32_t capT = cap / 3u;                                        // table entries (12 bytes each; any number: slots are picked by multiply-high)
   unsigned long long *Tb = (unsigned long long *)A;                      // [capT] bitmaps of 64 consecutive records
   uint32_t *Tk = (uint32_t *)(Tb + capT);                                // [capT] block number + 1 (0 = empty)
-  // the key buffer: what the table leaves of the seed slots (a quarter of them when cap / 3 is not a power of two), or the
-  // caller's bytes behind them, whichever holds more
-  if (cap - 3u * capT > kl) { Kk = Tk + capT; kl = cap - 3u * capT; }
+  auto slot_of = [&](uint32_t key) __attribute__((always_inline)) { return __umulhi(key * 0x9E3779B1u, capT); };
+  auto next_slot = [&](uint32_t h) __attribute__((always_inline)) { return h + 1u == capT ? 0u : h + 1u; };
   const bool dbg = (a.block_sort & 2) && tid == 0 && (blockIdx.x & 63) == 0;
   long long tk = dbg ? clock64() : 0;
   auto phase = [&](int k) __attribute__((always_inline)) {
@@ -747,12 +745,12 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
     auto place = [&](uint32_t r) __attribute__((always_inline)) {
       const uint32_t key1 = (r >> 6) + 1u;
       const unsigned long long bit = 1ULL << (r & 63u);
-      uint32_t h = ((r >> 6) * 0x9E3779B1u) >> (32u - lg);
+      uint32_t h = slot_of(r >> 6);
       for (uint32_t probes = 0;; probes++) {
         const uint32_t old = atomicCAS(&Tk[h], 0u, key1);
         if (old == 0u || old == key1) { atomicOr(&Tb[h], bit); break; }
         if (probes >= BS_MAX_PROBES) { bs_fail = 1; break; }
-        h = (h + 1u) & mask;
+        h = next_slot(h);
       }
     };
     constexpr int IB = 8;
@@ -833,8 +831,8 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   //      into the sorted record numbers.  The sort leaves the keys on a few waves (256 per wave); where the key buffer has
   //      room the (key, place) pairs go back through it so that EVERY thread expands its share of the entries ----
   auto bitmap_of = [&](uint32_t key1) __attribute__((always_inline)) {
-    uint32_t h = ((key1 - 1u) * 0x9E3779B1u) >> (32u - lg);
-    while (Tk[h] != key1) h = (h + 1u) & mask;
+    uint32_t h = slot_of(key1 - 1u);
+    while (Tk[h] != key1) h = next_slot(h);
     return Tb[h];
   };
   uint32_t place_of[KPL];
