@@ -2163,54 +2163,6 @@ struct Slide {
     rl = rstar * LNB + lbase;                                     // address of slot r* (= state of rank r*-1)
     best = shared;
   }
-#ifdef FA_SCAN_BCACHE
-  // EXPERIMENT (scripts/ubench/slide_chain.hip -DFA_SCAN_BCACHE; profiles/EXPERIMENTS.md, round 4): the two boundary slots
-  // (ranks r*-1 and r*) cached in registers and patched by the events that touch them, the touched slot of the NEXT event
-  // requested one event ahead (forwarded when this event writes it), the far side of the cache refilled right behind a
-  // pivot move and consumed by the next event -- 2 reads + 1 write per event as in `step`, none of them between two pivot
-  // decisions.
-  uint32_t b0, b1, vnext, nv_prev, rf;
-  int addr_prev, dprev;
-  __device__ __forceinline__ void bc_begin(uint32_t first_word_addr_value, int first_addr) {
-    b0 = ld(rl); b1 = ld(rl + LNB); vnext = first_word_addr_value; addr_prev = -1; nv_prev = 0; rf = 0; dprev = 0; (void)first_addr;
-  }
-  template <int SH, int SHN> __device__ __forceinline__ void step_bc(uint32_t word, uint32_t word_next) {
-    const int dM = __builtin_amdgcn_sbfe(word, SH + EV_DM, 2), dW = __builtin_amdgcn_sbfe(word, SH + EV_DW, 2);
-    const int drp = (int)__builtin_amdgcn_ubfe(word, SH + EV_DROP, 1);
-    const int addr = slot_addr<SH>(word);
-    const uint32_t v = (addr == addr_prev) ? nv_prev : vnext;     // (the request for this slot went out before the last event's write)
-    vnext = ld(slot_addr<SHN>(word_next));                        // the next event's slot, before this event's write
-    const uint32_t nv = (v + (uint32_t)(dW << 1)) ^ ((uint32_t)dM & 1u);
-    overflow |= nv;
-    sto(addr, nv);
-    addr_prev = addr; nv_prev = nv;
-    // the cache as the last pivot move left it: the far side comes from the refill requested then
-    const uint32_t c0 = dprev > 0 ? b1 : (dprev < 0 ? rf : b0);
-    const uint32_t c1r = dprev > 0 ? rf : (dprev < 0 ? b0 : b1);
-    b0 = (addr == rl) ? nv : c0;
-    b1 = (addr == rl + LNB) ? nv : c1r;
-    const bool below = addr <= rl;
-    const int dWb = below ? dW : 0;
-    shared += below ? dM : 0;
-    g += dWb;
-    const uint32_t vb = drp ? b1 : b0;
-    const int c1 = (int)(vb >> 1), mbm = __builtin_amdgcn_sbfe(vb, 0, 1);
-    const bool up = ((dW & (g + c1 - 1)) < 0);
-    const bool down = dWb > 0 && g > 0;
-    const int delta = up ? 1 : (down ? -1 : 0);
-    g += __mul24(delta, c1);
-    shared += delta & mbm;
-    rl += __mul24(delta, LNB);
-    rf = ld(rl + (delta > 0 ? LNB : 0));                          // behind this event's write; consumed by the next event
-    dprev = delta;
-    beg += drp;
-    const int sh_e = (int)((uint32_t)shared | ((word << ((32 - SH - 8 * (int)sizeof(T)) & 31)) & 0x80000000u));
-    const bool gt = sh_e > best, ge = sh_e >= best;
-    best = max(best, sh_e);
-    opt_s = gt ? beg : opt_s;
-    opt_e = ge ? beg : opt_e;
-  }
-#endif
   // straight-line selects only: the 64 lanes of a wave follow 64 different loci, any branch would serialise them
   template <int SH> __device__ __forceinline__ void step(uint32_t word) {
     const int dM = __builtin_amdgcn_sbfe(word, SH + EV_DM, 2), dW = __builtin_amdgcn_sbfe(word, SH + EV_DW, 2);
@@ -2291,21 +2243,6 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   }
   sl.read_pivot();
   if (!fill_groups) sl.best = -1;
-#ifdef FA_SCAN_BCACHE
-  static_assert(sizeof(T) == 2 || sizeof(T) == 4, "event width");
-  if (fill_groups < ngroups) sl.bc_begin(Slide<T, ST, LNT, true>::ld(sl.template slot_addr<0>(word_of(cur, 0))), 0);
-  for (uint32_t g = fill_groups; g < ngroups; g++) {
-    const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < PER; q++) {
-      const uint32_t wn = q + 1 < PER ? word_of(cur, q + 1) : nxt.x;     // (the padding word 0 addresses slot 0: harmless)
-      if (sizeof(T) == 2) {
-        if (q & 1) sl.template step_bc<16, 0>(word_of(cur, q), wn); else sl.template step_bc<0, 16>(word_of(cur, q), wn);
-      } else sl.template step_bc<0, 0>(word_of(cur, q), wn);
-    }
-    cur = nxt;
-  }
-#else
   for (uint32_t g = fill_groups; g < ngroups; g++) {
     const uint4 nxt = (g + 1 < ngroups) ? ev[g + 1] : make_uint4(0, 0, 0, 0);   // prefetch: the load is off the chain
 #pragma unroll
@@ -2314,7 +2251,6 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
     }
     cur = nxt;
   }
-#endif
   if (sl.overflow >> Slide<T, ST, LNT, true>::SBITS) {
     if (!REDO) { a.l_redo[l] = 1; atomicAdd(a.redo_count, 1u); return; }
   }
