@@ -39,9 +39,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_PROFILE = "r03_traffic.json"                   # the timed step (1 query per launch)
-TRAFFIC_PROFILE_BATCH16 = "r03_batch16_traffic.json"     # `saturated.batch16`: 16 queries per launch
-TRAFFIC_PROFILE_CONFIG3 = "r03_config3_traffic.json"     # `saturated.config3`: 1000 x 1000, two steps profiled
+TRAFFIC_PROFILE = "r04_traffic.json"                   # the timed step (1 query per launch)
+TRAFFIC_PROFILE_BATCH16 = "r04_batch16_traffic.json"     # `saturated.batch16`: 16 queries per launch
+TRAFFIC_PROFILE_CONFIG3 = "r04_config3_traffic.json"     # `saturated.config3`: 1000 x 1000, two steps profiled
 # digest of the config-3 hit table (20 x 50 x 5 Mb) as the driver-run N = 1 benches of rounds 2 and 3 printed it (BENCH_r03.json,
 # profiles/r03_bench_default.json: `saturated.config3.table_sha256`); an N > 1 run must reproduce it
 COMMITTED_CONFIG3_DIGEST = "f3eea1ae46a1386c"
@@ -301,7 +301,7 @@ def weak_scaling(ctx):
     k1_model = valu_model().get("k_sketch_fast", {})
     sketch_extra = ({"issue_floor_gbases_per_s": k1_model["issue_floor_gbases_per_s"],
                      "valu_frac": bases.value / (k1_ms.value * 1e-3) / 1e9 / k1_model["issue_floor_gbases_per_s"],
-                     "issue_floor_source": "profiles/r03_valu_model.json"} if k1_model else {})
+                     "issue_floor_source": "profiles/r04_valu_model.json"} if k1_model else {})
     result = {
         "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
         "value": value,
@@ -433,7 +433,7 @@ def concurrent_clients(args, batch, cap_rows, n_pairs_step):
 
 
 def profiled_traffic(which, profile=None):
-    """HBM bytes per step of the dominant stage from the committed rocprofv3 PMC passes (profiles/r03_*traffic.json,
+    """HBM bytes per step of the dominant stage from the committed rocprofv3 PMC passes (profiles/r04_*traffic.json,
     collected on this exact workload by scripts/collect_profiles.sh): FETCH_SIZE and WRITE_SIZE come from separate
     passes, are in KB, and FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read
     from inside the benchmark, so this is the profiled value, not a live one; (None, None) if the profile is missing."""
@@ -453,13 +453,13 @@ def profiled_traffic(which, profile=None):
 
 def valu_model():
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r03_valu_model.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", "r04_valu_model.json")))
     except (OSError, ValueError):
         return {}
 
 
 def issue_floor(regime, l2_ms):
-    """Vector-issue floor of the L2 stage from profiles/r03_valu_model.json (executed VALU wave-instructions of the two
+    """Vector-issue floor of the L2 stage from profiles/r04_valu_model.json (executed VALU wave-instructions of the two
     kernels x the measured issue-slot cost of their instruction mix / (1024 SIMDs x clock)) and its share of the measured
     stage time: the stage is integer work on the vector pipes, this -- not HBM -- is the roofline it actually sits under."""
     rows = valu_model().get("regimes", {}).get(regime, {})
@@ -467,7 +467,7 @@ def issue_floor(regime, l2_ms):
     if len(floors) < 2 or l2_ms <= 0:
         return {}
     return {"issue_floor_ms": sum(floors.values()), "valu_frac": sum(floors.values()) / l2_ms,
-            "issue_floor_ms_by_kernel": floors, "issue_floor_source": "profiles/r03_valu_model.json (scripts/valu_model.py)"}
+            "issue_floor_ms_by_kernel": floors, "issue_floor_source": "profiles/r04_valu_model.json (scripts/valu_model.py)"}
 
 
 def stage_roofline(l2_records, l2_ms, traffic, traffic_source):

@@ -26,14 +26,15 @@ def load(name):
 
 
 def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"      # whose counters (the instruction mix of the L2 kernels is round 3's: they have not changed since)
     mix = load("r03_isa_mix.json")
     out = {"simds": SIMDS, "clock_mhz": CLOCK_MHZ, "slot_cycles": mix["slot_cycles"],
-           "sources": ["profiles/r03_isa_mix.json", "profiles/r03_map_kernels_pmc.json", "profiles/r03_batch16_map_kernels_pmc.json",
+           "sources": ["profiles/r03_isa_mix.json", f"profiles/{tag}_map_kernels_pmc.json", f"profiles/{tag}_batch16_map_kernels_pmc.json",
                        "profiles/r03_k1_pmc.json", "profiles/r03_valu_rates.txt"], "regimes": {}}
     slot = {k: v["mean_slot_cycles"] for k, v in mix["kernels"].items()}
     alias = {"k_sketch_fast<16, 24>": "k_sketch_fast<16, 24>", "k_l2_scan<unsigned short, unsigned char, 64>": "k_l2_scan<unsigned short, unsigned char, 64>",
              "k_l2_events<unsigned short, true>": "k_l2_events<unsigned short, true>", "k_l1<256, 16>": "k_l1<256, 16>"}
-    for regime, fname in (("step", "r03_map_kernels_pmc.json"), ("batch16", "r03_batch16_map_kernels_pmc.json")):
+    for regime, fname in (("step", f"{tag}_map_kernels_pmc.json"), ("batch16", f"{tag}_batch16_map_kernels_pmc.json")):
         pmc = load(fname)
         if not pmc:
             continue
