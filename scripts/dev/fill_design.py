@@ -3,7 +3,7 @@ profiles/ (bench line, kernel stats, K1 rates):   python3 scripts/dev/fill_desig
 import csv, json, os, re
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 P = os.path.join(ROOT, "profiles")
-b = json.load(open(os.path.join(P, "r03_bench_default.json")))
+b = json.load(open(os.path.join(P, "r04_bench_default.json")))
 sat = b["saturated"]; b16 = sat["batch16"]; c3 = sat["config3"]; r = b["roofline"]
 
 
@@ -15,7 +15,9 @@ def stats(name):
     return out
 
 
-s1, s16 = stats("r03_bench_kernel_stats.csv"), stats("r03_batch16_bench_kernel_stats.csv")
+s1, s16, s3 = stats("r04_bench_kernel_stats.csv"), stats("r04_batch16_bench_kernel_stats.csv"), stats("r04_config3_bench_kernel_stats.csv")
+c4 = sat["config4"]; cells = b["config5_cells"]["cells"]
+tr3 = json.load(open(os.path.join(P, "r04_config3_traffic.json")))
 k = lambda v: f"{v / 1e3:.1f} k" if v < 1e6 else f"{v / 1e6:.2f} M"      # noqa: E731
 pick = lambda d, sub: next(v for n, v in d.items() if n.startswith(sub))    # noqa: E731
 k1 = open(os.path.join(P, "r03_k1.txt")).read().strip().splitlines()
@@ -40,6 +42,12 @@ vals = {
     "SC_US": f"{pick(s1, 'k_l2_scan<unsigned short, unsigned char, 64>'):.0f}", "SC_16": f"{pick(s16, 'k_l2_scan<unsigned short, unsigned char, 64>') / 16:.0f} µs",
     "CGI_US": f"{pick(s1, 'k_cgi_bins') + pick(s1, 'k_cgi_rows'):.0f}", "CGI_16": f"{(pick(s16, 'k_cgi_bins') + pick(s16, 'k_cgi_rows')) / 16:.0f} µs",
 }
+vals.update({
+    "C4_MS": f"{c4['ms_per_step']:.0f}", "C4_VALUE": k(c4["value"]), "C4_L2": f"{c4['phases_ms']['l2_ms']:.0f}", "C4_FRAC": f"{c4['roofline']['frac']:.3f}",
+    "C3_L1": f"{c3['phases_ms_rank0']['lookup_l1_ms']:.0f}", "C3_L1_US": f"{pick(s3, 'k_l1<512, 16>'):.0f}",
+    "C3_L1_FETCH": f"{tr3['kernels']['k_l1<512, 16>']['fetch_size_kb'] * 1024 / 1e9 / tr3['steps_summed']:.0f}",
+    "C5_ROWS": "\n".join(f"| ({c['k']}, {c['fragment_length']}) | {c['window_size']} | {k(c['value'])} | {c['ms_per_step']:.1f} | {c['phases_ms']['sketch_ms']:.1f} / {c['phases_ms']['lookup_l1_ms']:.1f} / {c['phases_ms']['l2_ms']:.1f} / {c['phases_ms']['cgi_ms']:.1f} | {c['sketch_stage'].split(' (')[0]} |" for c in cells),
+})
 vals["EV_TBS"] = f"{0.80e9 / (pick(s1, 'k_l2_events') * 1e-6) / 1e12:.1f}"
 path = os.path.join(ROOT, "DESIGN.md")
 s = open(path).read()
