@@ -470,7 +470,7 @@ struct fa_mapper {
   DevBuf<uint2> rec_hg;           // (hash, packed window geometry + flags) for k_l2_events (empty when cmw >= 8191)
   DevBuf<uint16_t> rec_prev16;
   DevBuf<uint32_t> rec_gpos, wrap_rec;   // padded global coordinate of every record (low word) + its 2^32 boundaries, for k_l1
-  int32_t n_wraps = 0;
+  int32_t n_wraps = 0, gpos_bits = 32;
 #ifdef FA_EXPERIMENTS
   DevBuf<uint32_t> ev_bits;       // merged admit / drop order of the slide (k_event_bits), 2 bits per record
   DevBuf<uint2> rec_hf;           // hash + flags + distance to the previous record of the hash (k_pack_hf), for k_l2_fused
@@ -517,7 +517,7 @@ struct fa_mapper {
   IndexView view() const {
     IndexView v;
     v.rec_hash = rec_hash.p; v.rec_seq = rec_seq.p; v.rec_wpos = rec_wpos.p; v.rec_prev = rec_prev.p; v.rec_fwd = rec_fwd.p; v.rec_bwd = rec_bwd.p; v.rec_flags = rec_flags.p;
-    v.rec_hg = packed_geo ? rec_hg.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_gpos = rec_gpos.p; v.wrap_rec = wrap_rec.p; v.n_wraps = n_wraps;
+    v.rec_hg = packed_geo ? rec_hg.p : nullptr; v.rec_prev16 = packed_geo ? rec_prev16.p : nullptr; v.rec_gpos = rec_gpos.p; v.wrap_rec = wrap_rec.p; v.n_wraps = n_wraps; v.gpos_bits = gpos_bits;
 #ifdef FA_EXPERIMENTS
     v.ev_bits = ev_bits.p; v.rec_hf = rec_hf.p;
 #endif
@@ -680,10 +680,14 @@ static void build_index(fa_mapper &m) {
       base.upload(h_base, st);
       m.rec_gpos.ensure((size_t)N + 4);
       m.wrap_rec.ensure(GPOS_MAX_WRAPS);
-      hipLaunchKernelGGL(k_rec_gpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, base.p, N, m.rec_gpos.p, m.wrap_rec.p, d_wraps.p);
+      // (FA_GPOS_BITS: the tests shrink the low word so that a small index crosses many of its boundaries)
+      m.gpos_bits = (int)std::min<uint64_t>(32, std::max<uint64_t>(12, env_u64("FA_GPOS_BITS", 32)));
+      FA_REQUIRE(m.gpos_bits == 32 || (1LL << m.gpos_bits) > 2 * (int64_t)m.P.fragment_length, FA_ERR_INVALID, "FA_GPOS_BITS too small for the fragment length");
+      hipLaunchKernelGGL(k_rec_gpos, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, base.p, N, m.gpos_bits, m.rec_gpos.p, m.wrap_rec.p, d_wraps.p);
       d_wraps.download(&m.n_wraps, 1, st);
       FA_HIP(hipStreamSynchronize(st));
-      FA_REQUIRE(m.n_wraps <= GPOS_MAX_WRAPS, FA_ERR_UNSUPPORTED, "the index spans more than 2^40 bases (shard the references)");
+      FA_REQUIRE(m.n_wraps <= GPOS_MAX_WRAPS, FA_ERR_UNSUPPORTED, m.gpos_bits == 32 ? "the index spans more than 2^40 bases (shard the references)"
+                                                                                       : "FA_GPOS_BITS: more than 256 boundaries in this index");
     }
 #ifdef FA_EXPERIMENTS
     if (fused_l2_enabled()) {

@@ -186,14 +186,15 @@ __global__ void k_contig_span(const int32_t *contig_rec, const int32_t *rec_wpos
   }
   span[c] = v;
 }
-__global__ void k_rec_gpos(const int32_t *rec_seq, const int32_t *rec_wpos, const unsigned long long *contig_base, int64_t N,
+// (`bits` = width of the low word: 32, except in the tests, which shrink it so that a small index spans many boundaries)
+__global__ void k_rec_gpos(const int32_t *rec_seq, const int32_t *rec_wpos, const unsigned long long *contig_base, int64_t N, int bits,
                            uint32_t *rec_gpos, uint32_t *wrap_rec, int32_t *n_wraps) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const unsigned long long g = contig_base[rec_seq[i]] + (unsigned long long)rec_wpos[i];
-  rec_gpos[i] = (uint32_t)g;
-  const uint32_t hi = (uint32_t)(g >> 32);
-  const uint32_t hi_prev = i ? (uint32_t)((contig_base[rec_seq[i - 1]] + (unsigned long long)rec_wpos[i - 1]) >> 32) : 0u;
+  rec_gpos[i] = (uint32_t)(g & ((1ULL << bits) - 1ULL));
+  const uint32_t hi = (uint32_t)(g >> bits);
+  const uint32_t hi_prev = i ? (uint32_t)((contig_base[rec_seq[i - 1]] + (unsigned long long)rec_wpos[i - 1]) >> bits) : 0u;
   for (uint32_t h = hi_prev + 1; h <= hi; h++) if (h - 1 < (uint32_t)GPOS_MAX_WRAPS) wrap_rec[h - 1] = (uint32_t)i;
   if (i == N - 1) *n_wraps = (int32_t)hi;
 }
@@ -229,6 +230,7 @@ struct IndexView {
   const uint32_t *rec_gpos;     // low word of the padded global coordinate (k_rec_gpos): one 4-byte gather per seed hit in k_l1
   const uint32_t *wrap_rec;     // [n_wraps] first record behind every 2^32 boundary of that coordinate
   int32_t n_wraps;
+  int32_t gpos_bits;            // width of the low word (32; FA_GPOS_BITS shrinks it for the tests)
 #ifdef FA_EXPERIMENTS
   const uint32_t *ev_bits;      // merged admit / drop order of the L2 slide, one bit per event (k_event_bits)
   const uint2 *rec_hf;          // (hash, flags | distance to the previous record of the hash << 8) for k_l2_fused
@@ -252,7 +254,7 @@ struct IndexView {
 __device__ __forceinline__ uint64_t gpos_make(const IndexView &ix, uint32_t r, uint32_t lo) {
   uint32_t hi = 0;
   for (int w = 0; w < ix.n_wraps; w++) hi += r >= ix.wrap_rec[w] ? 1u : 0u;   // (uniform loop, scalar loads; no trip below 4.29 Gbases)
-  return ((uint64_t)hi << 32) | lo;
+  return ((uint64_t)hi << ix.gpos_bits) | lo;
 }
 __device__ __forceinline__ uint64_t gpos_of(const IndexView &ix, uint32_t r) { return gpos_make(ix, r, ix.rec_gpos[r]); }
 

@@ -1318,6 +1318,32 @@ def test_unpacked_record_geometry(params, env, monkeypatch):
     assert hit_tuples(hits) == ohits
 
 
+@pytest.mark.parametrize("bits,length,contigs", [(14, 300_000, 1), (13, 120_000, 7), (16, 400_000, 3)])
+def test_global_coordinate_across_word_boundaries(bits, length, contigs, monkeypatch):
+    # k_l1 tests "same contig and wb - wa < fragment_length" on a padded global coordinate whose low word is gathered per hit
+    # and whose high word is the number of word boundaries before the record (exact at any index size; BASELINE config 3 spans
+    # 5 x 10^9 padded bases: one boundary).  FA_GPOS_BITS shrinks the low word to 2^13 - 2^16 bases, so that these small indexes
+    # cross dozens of boundaries, candidates and loci straddle them, and the 64-bit form of the candidate scan runs: every
+    # mapping and hit must still be the oracle's.
+    monkeypatch.setenv("FA_GPOS_BITS", str(bits))
+    g = syn.rng(900 + bits)
+    anc = syn.random_codes(g, length)
+    split = (lambda seq: syn.split_contigs(g, seq, contigs)) if contigs > 1 else (lambda seq: [seq])
+    refs = [split(syn.to_ascii(syn.mutate_codes(g, anc, d))) for d in (0.0, 0.02, 0.06, 0.11)]
+    refs.append(split(syn.to_ascii(syn.random_codes(g, length))))
+    dup = syn.mutate_codes(g, anc, 0.03)
+    dup = np.concatenate([dup[: length // 2], dup[length // 4: length // 2], syn.reverse_complement_codes(dup[length // 2:])])
+    refs.append(split(syn.to_ascii(dup)))
+    query = split(syn.to_ascii(syn.mutate_codes(g, anc, 0.04)))
+    mapper, hits, ohits, det = run_both({}, refs, query, threads=4)
+    assert gpu_mappings(mapper) == oracle_mappings(det) and len(oracle_mappings(det)) > 100
+    assert hit_tuples(hits) == ohits and len(ohits) >= 4
+    # the same index with the full 32-bit word (no boundary at this size) gives the same rows
+    monkeypatch.delenv("FA_GPOS_BITS")
+    mapper32, hits32, _, _ = run_both({}, refs, query, threads=4)
+    assert hit_tuples(hits32) == ohits and gpu_mappings(mapper32) == gpu_mappings(mapper)
+
+
 def test_fused_query_sketch_overflow_falls_back(monkeypatch):
     # k_query_fused (K1 + per-fragment sketch in one launch) holds a fragment's records in LDS; one with more than its
     # capacity voids the pass, which then runs through k_sketch_fast + k_query_sketch.  FA_QF_CAP lowers the capacity so
