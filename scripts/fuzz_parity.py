@@ -114,6 +114,11 @@ for case in range(cases):
         if osk.window_size >= frag:      # degenerate cell: nothing maps; covered by the unit tests
             continue
         sk = pf.Sketch(**params)
+        # a third of the cases index with a narrow low word of the global coordinate (FA_GPOS_BITS, read when the index is built):
+        # dozens of word boundaries inside these small indexes, i.e. the 64-bit form of k_l1's candidate scan
+        os.environ.pop("FA_GPOS_BITS", None)
+        if g.random() < 0.33:
+            os.environ["FA_GPOS_BITS"] = str(max(12, int(2 * frag).bit_length() + 1) + int(g.integers(0, 3)))
         length = int(g.integers(max(3 * frag, 8000), 60_000))
         anc = scramble(g, syn.random_codes(g, length))
         n_ref = int(g.integers(1, 6))
