@@ -724,7 +724,7 @@ constexpr uint32_t BS_MAX_PROBES = 48;
 template <int NT, int SPT, int KPL>
 __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n, uint32_t cap, uint32_t *A, const uint32_t *off, const uint32_t *qo,
                                               uint32_t *Kk, uint32_t kl) {
-  __shared__ uint32_t bs_fail, bs_total;
+  __shared__ uint32_t bs_fail;
   __shared__ uint32_t bs_wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t capT = cap / 3u;                                        // table entries (12 bytes each; any number: slots are picked by multiply-high)

@@ -304,6 +304,7 @@ STRONG_WORKER = textwrap.dedent("""
     for _ in range(2):                                                   # a second step reuses the buffers
         tables = table.step(Batch())
     assert tuple(tables.shape) == (world, max_rows + 1, 5) and Batch.calls == 2
+    assert len(table.exchange_marks) == 2 and 0.0 < table.exchange_ms() < 60_000.0 and table.exchange_ms(1) > 0.0   # the collective alone, per step
     res = sharding.ResidentHitTable.rows_of(tables)
     res = res[np.lexsort((res["ref_genome_id"], res["query_id"]))]
     assert res.tobytes() == want.tobytes(), (rank, res.tolist())
