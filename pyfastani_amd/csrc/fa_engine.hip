@@ -171,12 +171,13 @@ static bool launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
     // compile time (the window loop unrolled, 42 registers instead of 61 in k_sketch_fast); any other window takes the
     // run-time form of its k.
 #define FA_KW_CELLS(X) X(14, 12) X(14, 37) X(14, 50) X(16, 13) X(16, 24) X(16, 40) X(21, 15) X(21, 25)
-    // fused with the per-fragment sketch (k_query_fused, one of those cells): no other bytes anywhere in the batch (their tiles
-    // go through k_sketch_tiles<0, true> and the staging arrays), and fragments whose records fit QF_CAP with room to spare
-    // (a denser one voids the pass).  The run-time-w forms of the fused kernel do not fit the registers of seven waves per
+    // fused with the per-fragment sketch (k_query_fused, one of those cells): fragments whose records fit QF_CAP with room to
+    // spare (a denser one voids the pass).  Tiles that touch a byte outside ACGT are sketched by k_sketch_tiles<0, true> into the
+    // staging arrays FIRST (a launch whose other workgroups exit at once, and which carries the zeroing workgroups of the pass);
+    // the fused kernel takes their records from there.  The run-time-w forms of the fused kernel do not fit the registers of seven waves per
     // SIMD -- a few words would go to scratch memory, which the runtime then keeps per stream for good -- and are not built.
     static const bool fuse_on = !(getenv("FA_QUERY_FUSED") && atoi(getenv("FA_QUERY_FUSED")) == 0);
-    const bool may_fuse = fuse && fuse_on && store.n_exc == 0 && (int64_t)5 * P.fragment_length / (P.window_size + 1) <= QF_CAP;
+    const bool may_fuse = fuse && fuse_on && (int64_t)5 * P.fragment_length / (P.window_size + 1) <= QF_CAP;
     auto launch_fast = [&](auto kernel) {
       hipLaunchKernelGGL(kernel, dim3(ntiles + extra), dim3(SK_THREADS), flds + lds_pad, st, a);
       extra = 0; a.clear.count = 0; a.clear.stamp = nullptr;
@@ -186,8 +187,11 @@ static bool launch_sketch_tiles(const fa_params &P, const StoreView &store, cons
     if (!served && P.kmer_size == K && P.window_size == W) {                                                                      \
       served = true;                                                                                                              \
       if (may_fuse) {                                                                                                             \
+        QuerySketchArgs qa = *fuse;                                                                                               \
+        qa.exc_tiles = store.n_exc > 0 ? 1 : 0;                                                                                   \
+        if (store.n_exc > 0) launch(k_sketch_tiles<0, true>);                                                                     \
         const size_t qlds = flds + (size_t)QF_CAP * 4;                                                                            \
-        hipLaunchKernelGGL((k_query_fused<K, W>), dim3((unsigned)F + extra), dim3(SK_THREADS), qlds + lds_pad, st, a, *fuse, (int)F); \
+        hipLaunchKernelGGL((k_query_fused<K, W>), dim3((unsigned)F + extra), dim3(SK_THREADS), qlds + lds_pad, st, a, qa, (int)F);  \
         FA_HIP(hipGetLastError());                                                                                                \
         return true;                                                                                                              \
       }                                                                                                                           \
@@ -1113,6 +1117,7 @@ struct QueryPass {
       a.ix = ix; a.q_off = ln.q_off.p; a.q_cnt = ln.q_cnt.p; a.n_seeds = ln.n_seeds.p;
       a.sort_cap = (int32_t)(qs_lds / 4);
       a.rec_cap = getenv("FA_QF_CAP") ? std::max(0, std::min(QF_CAP, atoi(getenv("FA_QF_CAP")))) : QF_CAP;
+      a.exc_tiles = 0;                                 // (set by launch_sketch_tiles for the fused kernel)
       // ---- K1 (its extra workgroups zero the ranges above beside the hashing) + per-fragment sort / unique / index lookup:
       //      one launch where the pass qualifies (k_query_fused), else k_sketch_fast / k_sketch_tiles, then k_query_sketch ----
       const bool fused = launch_sketch_tiles(m.P, g.store, g.tiles + t0, ntiles, ln.sk.stage_hash.p, ln.sk.stage_wpos.p, ln.sk.tile_count.p, st, &cl.a,

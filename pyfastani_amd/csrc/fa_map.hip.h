@@ -291,6 +291,7 @@ struct QuerySketchArgs {
   uint32_t *q_cnt;              // [F*qcap] list length (0 when absent or too frequent)
   uint32_t *n_seeds;            // [F]
   int32_t rec_cap;              // k_query_fused: most records of a fragment it accepts (<= QF_CAP; FA_QF_CAP lowers it for the tests)
+  int32_t exc_tiles;            // k_query_fused: the batch holds tiles with bytes outside ACGT (their records wait in the staging arrays)
 };
 
 constexpr int QS_TILES = 16;      // tiles of a fragment whose counts k_query_sketch fetches in one go
@@ -446,7 +447,8 @@ constexpr uint32_t SPEC_SMAX = 1, SPEC_SCRATCH = 2, SPEC_LOCI = 4, SPEC_EVENTS =
 // the tiles of fragment f one after the other (skf_tile, fa_sketch_fast.hip.h), collects their records in LDS instead
 // of the staging arrays, and goes on with query_sketch_tail.  On one 5 Mb query this is one resident round of 1666
 // workgroups where k_sketch_fast (2.4 rounds of 4998 tile workgroups) + k_query_sketch (a round of latency chains) were
-// two launches.  A fragment with more than QF_CAP records (low-complexity sequence under a small window) is marked
+// two launches.  Batches with bytes outside ACGT run the byte-path kernel for the tiles that touch them first; this kernel takes
+// their staged records over and hashes the plain tiles itself.  A fragment with more than QF_CAP records (low-complexity sequence under a small window) is marked
 // (q_size = -1, SPEC_QFUSE via seed_totals): the pass is void and runs again through the two kernels.  The workgroups
 // write nothing into the status block -- the zeroing workgroups of this very launch are clearing it.
 // ----------------------------------------------------------------------------------------------------------
@@ -489,11 +491,26 @@ __global__ __launch_bounds__(SK_THREADS, QF_WAVES(KT, WT)) void k_query_fused(Sk
   const uint4 none = make_uint4(0, 0, 0, 0);
   for (int t = t0; t < t1; t++) {
     const Tile tile = a.tiles[t];
+    if (tile.exc_n > 0) continue;                                     // (uniform) a tile with other bytes: taken over from the staging arrays below
     const bool intact = skf_tile<KT, WT>(a, tile, lds, false, none, none, Collected{qbuf, sh_count, &sh_add, &sh_wpos0});
     __syncthreads();
     if (tid == 0) sh_count += sh_add;
     if (!intact) put_tables();                                       // (uniform: a tile with k-mer-less positions used the tables' bytes)
     __syncthreads();
+  }
+  // tiles that touch a byte outside ACGT (an N run, an IUPAC code) were sketched from the byte image by k_sketch_tiles<0, true> in
+  // the launch before this one: their staged records join the fragment's (the order of the records is immaterial from here
+  // on: they are sorted, and the leading-run rule only ever replaces a hash by itself)
+  if (q.exc_tiles) {
+    for (int t = t0; t < t1; t++) {
+      if (a.tiles[t].exc_n <= 0) continue;                            // (uniform)
+      const int cnt = a.tile_count[t], base = sh_count;
+      const uint32_t *sh = a.stage_hash + (size_t)t * TILE;
+      for (int i = tid; i < cnt; i += SK_THREADS) if (base + i < QF_CAP) qbuf[base + i] = sh[i];
+      __syncthreads();
+      if (tid == 0) sh_count = base + cnt;
+      __syncthreads();
+    }
   }
   const int n = sh_count;
   if (n > q.rec_cap) {                                               // (uniform) void pass: seed_totals raises SPEC_QFUSE, the host repeats it unfused

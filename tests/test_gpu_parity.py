@@ -1388,6 +1388,34 @@ def test_fused_query_sketch_overflow_falls_back(monkeypatch):
     assert again() == (ohits, 0, (1, 0))
 
 
+def test_fused_sketch_stage_with_bytes_outside_acgt():
+    # A query with N runs, IUPAC codes and lower case still takes the one-launch sketch stage: the tiles that touch such bytes
+    # are sketched from the byte image by k_sketch_tiles<0, true> first, k_query_fused hashes the plain tiles and takes the
+    # staged records of the others over.  Every mapping and hit as the oracle's; slot [17] of the timings says which form ran.
+    g = syn.rng(515)
+    anc = syn.random_codes(g, 200_000)
+    refs = [[syn.to_ascii(syn.mutate_codes(g, anc, d))] for d in (0.01, 0.05, 0.10)]
+    q = bytearray(syn.to_ascii(syn.mutate_codes(g, anc, 0.03)))
+    q[1_000:1_040] = b"N" * 40                                   # inside the first fragment
+    q[2_995:3_010] = b"N" * 15                                   # across a fragment boundary
+    q[50_000:53_500] = b"N" * 3_500                              # a whole fragment and more
+    q[90_000:90_010] = b"RYKMSWBDHV"                             # IUPAC
+    q[120_000:121_000] = bytes(q[120_000:121_000]).lower()        # lower case (packed as plain bases: no exception)
+    q[199_990:200_000] = b"N" * 10                               # the tail
+    query = [bytes(q)]
+    mapper, hits, ohits, det = run_both({}, refs, query, threads=4)
+    assert gpu_mappings(mapper) == oracle_mappings(det) and hit_tuples(hits) == ohits and len(ohits) == 3
+    ms = (C.c_float * 24)()
+    lib.fa_mapper_last_timings(mapper._h, ms, 24)
+    assert (int(ms[17]), int(ms[18])) == (1, 0), "the query pass should have run k_query_fused"
+    # the resident-batch road, two genomes of which one is clean
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        batch = mapper.upload_genomes([query, [syn.to_ascii(syn.mutate_codes(g, anc, 0.02))]])
+        got = [hit_tuples(h) for h in batch.query()]
+    assert got[0] == ohits and len(got[1]) == 3
+
+
 def test_batches_of_tiny_genomes_keep_the_identity_workgroup_order():
     # The offset-major workgroup order of k_l2_events deals groups of equal fragment offset to the eight XCDs.  A batch of
     # plasmid-sized genomes (one to three fragments each) has fewer groups than XCDs: the order would put every real workgroup
