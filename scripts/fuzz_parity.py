@@ -134,7 +134,8 @@ for case in range(cases):
         queries = []
         for _ in range(int(g.integers(1, 4)) if case % 4 == 0 else 1):
             q = scramble(g, syn.mutate_codes(g, anc, float(g.choice([0.0, 0.02, 0.05, 0.1])))) if g.random() < 0.5 else syn.mutate_codes(g, anc, 0.03)
-            queries.append([(bytes(syn.to_ascii(x)) if default_cell else to_bytes(g, x)) for x in syn.split_contigs(g, q, int(g.integers(1, 4)))])
+            plain = default_cell and g.random() < 0.6          # (default-cell runs: 60 % plain-ACGT queries, the rest with N runs / IUPAC / lower case)
+            queries.append([(bytes(syn.to_ascii(x)) if plain else to_bytes(g, x)) for x in syn.split_contigs(g, q, int(g.integers(1, 4)))])
         if len(queries) > 1:
             # the resident-batch API must give, per genome, what one query_draft call gives
             got = [[(h.name, h.identity, h.matches, h.fragments) for h in hs] for hs in mapper.upload_genomes(queries).query()]
