@@ -1030,6 +1030,8 @@ struct QueryPass {
     int l1_threads = 256, l1_nt = 256;
     uint32_t seed_slots = 0;
     bool wide = false;
+    const int32_t *frag_order = nullptr;      // workgroup order of the part (prepare_order), null = identity
+    uint32_t order_len = 0;
     Part(QueryPass &q, Run &r)
         : ln(*q.lanes[r.lane]), st(ln.stream), sp(r.sp), f0(r.f0), f1(r.f1), F(r.f1 - r.f0), t0(q.g.frag_tile_lo[r.f0]),
           ntiles(q.g.frag_tile_lo[r.f1] - q.g.frag_tile_lo[r.f0]), smax(r.sp.smax), l_cap(r.sp.l_cap) {}
@@ -1082,10 +1084,31 @@ struct QueryPass {
     ln.items.ensure(((size_t)sp.items_cap + 8) * (p.wide ? 4 : 2));
 
     launch_sketch_stage(r, p);
+    prepare_order(p);
     launch_l1_stage(p);
     launch_l2_stage(r, p);
     launch_cgi_stage_and_hand_over(r, p);
     ran[r.lane] = true;
+  }
+
+  // Passes of several genomes run the workgroups of k_l2_events in offset-major, XCD-aware
+  // order (build_frag_order); the order is built on the host, cached per (batch, fragment range) and uploaded behind K1.
+  void prepare_order(Part &p) {
+    Workspace &ln = p.ln;
+    static const bool order_on = !(getenv("FA_FRAG_ORDER") && atoi(getenv("FA_FRAG_ORDER")) == 0);
+    if (!(order_on && NQ >= 2 && p.F >= 64)) return;
+    if (ln.order_batch != g.serial || ln.order_f0 != p.f0 || ln.order_f1 != p.f1) {
+      std::vector<int32_t> ord;
+      ln.order_len = build_frag_order(g, g0, p.f0, p.f1, ord);       // 0: the lists cannot be balanced, identity order
+      if (ln.order_len) {
+        ln.pin_order.ensure(ord.size() * sizeof(int32_t));
+        memcpy(ln.pin_order.p, ord.data(), ord.size() * sizeof(int32_t));
+        ln.frag_order.ensure(ord.size());
+        FA_HIP(hipMemcpyAsync(ln.frag_order.p, ln.pin_order.p, ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, p.st));
+      }
+      ln.order_batch = g.serial; ln.order_f0 = p.f0; ln.order_f1 = p.f1;
+    }
+    if (ln.order_len) { p.frag_order = ln.frag_order.p; p.order_len = ln.order_len; }
   }
 
   // K1 (its extra workgroups zero the tables of the part) + per-fragment sort / unique / index lookup
@@ -1168,6 +1191,7 @@ struct QueryPass {
       static const bool l1_block_sort_on = !(getenv("FA_L1_BLOCK_SORT") && atoi(getenv("FA_L1_BLOCK_SORT")) == 0);
       static const bool l1_stats = getenv("FA_L1_STATS") && atoi(getenv("FA_L1_STATS")) != 0;
       a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0);
+      const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
       // into LDS-sized chunks at contig boundaries by k_l1_big first; what it cannot cut stays with k_l1's HBM path
@@ -1192,10 +1216,10 @@ struct QueryPass {
         if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);
         if (seed_slots <= 16 * (uint32_t)NTT) {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3((unsigned)(F + (fold_totals ? 1 : 0))), dim3(NTT), lds, st, a);
+          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3(l1_grid + (fold_totals ? 1u : 0u)), dim3(NTT), lds, st, a);
         } else {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3((unsigned)(F + (fold_totals ? 1 : 0))), dim3(NTT), lds, st, a);
+          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3(l1_grid + (fold_totals ? 1u : 0u)), dim3(NTT), lds, st, a);
         }
       };
       if (l1_threads >= 1024) go(std::integral_constant<int, 1024>());
@@ -1240,24 +1264,10 @@ struct QueryPass {
       a.l_redo = ln.l_redo.p;
       a.redo_count = d_counters + 3;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
-      // several genomes in the pass: the workgroups of k_l2_events in offset-major order (see build_frag_order)
-      a.frag_order = nullptr;
-      uint32_t ev_grid = (uint32_t)F;
-      static const bool order_on = !(getenv("FA_FRAG_ORDER") && atoi(getenv("FA_FRAG_ORDER")) == 0);
-      if (order_on && NQ >= 2 && F >= 64) {
-        if (ln.order_batch != g.serial || ln.order_f0 != f0 || ln.order_f1 != f1) {
-          std::vector<int32_t> ord;
-          ln.order_len = build_frag_order(g, g0, f0, f1, ord);       // 0: the lists cannot be balanced, identity order
-          if (ln.order_len) {
-            ln.pin_order.ensure(ord.size() * sizeof(int32_t));
-            memcpy(ln.pin_order.p, ord.data(), ord.size() * sizeof(int32_t));
-            ln.frag_order.ensure(ord.size());
-            FA_HIP(hipMemcpyAsync(ln.frag_order.p, ln.pin_order.p, ord.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-          }
-          ln.order_batch = g.serial; ln.order_f0 = f0; ln.order_f1 = f1;
-        }
-        if (ln.order_len) { a.frag_order = ln.frag_order.p; ev_grid = ln.order_len; r.ordered = true; }
-      }
+      // several genomes in the pass: the workgroups of k_l2_events in offset-major order (prepare_order)
+      a.frag_order = p.frag_order;
+      const uint32_t ev_grid = p.frag_order ? p.order_len : (uint32_t)F;
+      if (p.frag_order) r.ordered = true;
 #ifdef FA_EXPERIMENTS
       static const int fused_dbg = (int)env_u64("FA_FUSED_DEBUG", 0);
       a.dbg = fused_dbg;
