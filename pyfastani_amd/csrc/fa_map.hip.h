@@ -658,10 +658,13 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, 
 //      its place, and the bits are expanded into the sorted array of record numbers -- the array the merge produces, bit
 //      for bit, for a fraction of the instructions and, what counts more in this kernel, of the dependent LDS round trips
 //      (eight merge levels: two binary searches and 8-9 sequential merge steps per thread and level).
-// The table and the sorted hits share the LDS of the seed slots (table = a third as many entries as slots, a power of two); the keys pass through
-// the bytes behind them (list offsets + locus stage).
-// Returns false -- the caller then gathers and merges as before -- when the hits are too scattered for the table (a probe
-// sequence longer than BS_MAX_PROBES) or the counts do not add up.  The verdict is uniform over the workgroup.
+// The table and the sorted hits share the LDS of the seed slots (12 bytes per entry: a third as many entries as slots; any
+// number -- slots are picked by multiply-high, not by a mask); the keys pass through the bytes behind them (list offsets +
+// locus stage).
+// Returns false -- the caller then gathers and merges as before -- when the hits are too scattered (a probe sequence longer
+// than BS_MAX_PROBES, or more blocks than the key buffer and the registers of the sort hold: lists of frequent small hashes,
+// 4 % of the fragments of BASELINE config 3) or the counts do not add up.  The verdict is uniform over the workgroup.
+
 // inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16 lanes, then the row totals
 // broadcast into the rows behind them): six vector instructions, no LDS crossbar -- `__shfl_up` is a ds_bpermute each
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
