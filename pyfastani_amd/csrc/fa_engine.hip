@@ -374,7 +374,7 @@ struct PassStatus {
   uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
-  unsigned long long dbg[12];       // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the sampled workgroups (thread 0's view); [8..10] why block sorts gave up
+  unsigned long long dbg[16];       // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the sampled workgroups (thread 0's view); [8..10] why block sorts gave up
   unsigned long long stamp[6];      // stage_stamp: pass start, lookup, L2, CGI, end (100 MHz ticks); not cleared with the rest
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
 };
@@ -745,7 +745,7 @@ static void ensure_luts(fa_mapper &m, int smax) {
 static uint32_t lds_seed_cap_max(int smax) {
   // (the dynamic request of k_l1 -- l1_lds_bytes: seeds, list offsets and sources, six staged locus arrays -- plus its static
   // LDS, a few hundred bytes, must stay within the 160 KB of a CU)
-  const int64_t room = 160 * 1024 - 1024 - (int64_t)L1_STAGE * 6 * 4 - std::max<int64_t>(((int64_t)smax + 2) * 8, 1024 * 8) - 64;
+  const int64_t room = 160 * 1024 - 2048 - (int64_t)L1_STAGE * 6 * 4 - std::max<int64_t>(((int64_t)smax + 2) * 8, 1024 * 10) - 64;
   return (uint32_t)std::max<int64_t>(256, room / 4 / 256 * 256);
 }
 
@@ -1072,7 +1072,10 @@ struct QueryPass {
     p.seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * p.l1_nt));
     // (a 512-thread workgroup is eight waves: four of them fill a CU whatever their LDS up to 39 KB, so the block table of
     // l1_block_sort -- a third as many entries as seed slots -- gets all the slots the 16-per-thread form can address)
-    if (p.l1_nt == 512 && p.seed_slots <= 16u * 512u) p.seed_slots = std::min<uint32_t>(16u * 512u, lds_seed_cap_max(smax));
+    // (7 936, not 8 192: the kilobyte goes to the key buffer behind the slots, which then holds the (key, place) pairs of 1 024
+    // blocks -- the 4 x 10^8-record index of config 3 adds ~500 chance hits, each a block of its own, to the ~250 blocks of a
+    // fragment's relatives -- and four workgroups still fill a CU)
+    if (p.l1_nt == 512 && p.seed_slots <= 16u * 512u) p.seed_slots = std::min<uint32_t>(16u * 512u - 256u, lds_seed_cap_max(smax));
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
     ln.l_rfirst.ensure((size_t)l_cap); ln.l_rlast.ensure((size_t)l_cap + 4); ln.l_rpart.ensure((size_t)l_cap);
     ln.l_group.ensure((size_t)l_cap); ln.l_shared.ensure((size_t)l_cap); ln.l_pos.ensure((size_t)l_cap);
@@ -1523,8 +1526,9 @@ struct QueryPass {
       const double nf = (double)(h_counters[5] + h_counters[6]);
       fprintf(stderr, "[fa] k_l1 phases, shader-clock ticks per fragment (thread 0):");
       for (int i = 0; i < 8; i++) fprintf(stderr, " %.0f", (double)ln.h_status->dbg[i] / nf);
-      fprintf(stderr, "  (%u block-sorted, %u merged; one workgroup in 64 sampled; gave up on probes / blocks / counts: %llu %llu %llu)\n", h_counters[5], h_counters[6],
-              ln.h_status->dbg[8], ln.h_status->dbg[9], ln.h_status->dbg[10]);
+      fprintf(stderr, "  (%u block-sorted, %u merged; one workgroup in 64 sampled; gave up on probes / blocks / counts: %llu %llu %llu; expansion: bitmaps+places %.0f, pairs+bitmaps %.0f, bits %.0f)\n",
+              h_counters[5], h_counters[6], ln.h_status->dbg[8], ln.h_status->dbg[9], ln.h_status->dbg[10], (double)ln.h_status->dbg[11] / nf, (double)ln.h_status->dbg[12] / nf,
+              (double)ln.h_status->dbg[13] / nf);
     }
     return true;
   }

@@ -639,7 +639,10 @@ constexpr int L1_INPLACE_MAX = 32;  // most seeds per thread the in-place merge 
 __host__ __device__ inline size_t l1_off_offset(uint32_t seed_cap) { return ((size_t)seed_cap * 4 + 15) / 16 * 16; }
 // (nt = threads of the workgroup: once the lists are merged the same bytes hold (contig, window) of a trip's seeds by thread)
 __host__ __device__ inline size_t l1_stage_offset(uint32_t seed_cap, int lut_smax, int nt) {
-  const size_t lists = ((size_t)lut_smax + 2) * 8, trip = (size_t)nt * 8;            // list offsets + list sources
+  // list offsets + list sources; later the saved ballots of the candidate scan (16 bytes per 64-candidate step) and -- ten bytes
+  // per thread, so that with the locus stage behind it the region holds a (key, place) pair for 1 024 blocks at 512 threads --
+  // the key buffer of l1_block_sort
+  const size_t lists = ((size_t)lut_smax + 2) * 8, trip = (size_t)nt * 10;
   return (l1_off_offset(seed_cap) + (lists > trip ? lists : trip) + 15) / 16 * 16;
 }
 __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, int nt) {
@@ -873,11 +876,12 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)(wincl - wt), wv);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 63);
   if (total != n) { if (dbg) atomicAdd(&a.dbg[10], 1ULL); return false; }   // (cannot happen: a record sits in one list only)
+  phase(11);
   // (an entry is expanded as two 32-bit halves: a 64-bit lowest-set-bit loop costs twice the instructions per hit)
   auto expand = [&](uint32_t half, uint32_t first, uint32_t o) __attribute__((always_inline)) {
     while (half) { A[o++] = first | (uint32_t)(__ffs((int)half) - 1); half &= half - 1u; }
   };
-  constexpr int HPT = NT >= 512 ? 2 : 4;                                 // halves per thread at most (registers)
+  constexpr int HPT = 4;                                                 // halves per thread at most (registers)
   const bool spread = 2u * nb32 <= kl && 2u * nb32 <= (uint32_t)(HPT * NT);  // room for the pairs, and at most HPT halves per thread
   if (spread) {
     uint2 *KP = (uint2 *)Kk;
@@ -898,6 +902,7 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
       at[j] = kp.y + ((e & 1u) ? (uint32_t)__popc(lo) : 0u);
     }
     __syncthreads();                                                     // (every probe of the table is done)
+    phase(12);
 #pragma unroll
     for (int j = 0; j < HPT; j++) expand(half[j], first[j], at[j]);
   } else {
@@ -913,6 +918,7 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
     }
   }
   __syncthreads();
+  phase(13);
   return true;
 }
 
