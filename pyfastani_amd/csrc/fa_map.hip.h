@@ -665,8 +665,8 @@ __host__ __device__ inline size_t l1_lds_bytes(uint32_t seed_cap, int lut_smax, 
 // number -- slots are picked by multiply-high, not by a mask); the keys pass through the bytes behind them (list offsets +
 // locus stage).
 // Returns false -- the caller then gathers and merges as before -- when the hits are too scattered (a probe sequence longer
-// than BS_MAX_PROBES, or more blocks than the key buffer and the registers of the sort hold: lists of frequent small hashes,
-// 4 % of the fragments of BASELINE config 3) or the counts do not add up.  The verdict is uniform over the workgroup.
+// than BS_MAX_PROBES, or more blocks than the key buffer and the registers of the sort hold: 1 024 at 256 threads, 2 048 at
+// 512) or the counts do not add up.  The verdict is uniform over the workgroup.
 
 // inclusive prefix sum over the 64 lanes of a wave by DPP (row shifts inside the rows of 16 lanes, then the row totals
 // broadcast into the rows behind them): six vector instructions, no LDS crossbar -- `__shfl_up` is a ds_bpermute each
