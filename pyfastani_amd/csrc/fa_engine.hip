@@ -371,7 +371,7 @@ struct PassStatus {
   int32_t stats[4];                 // [0] largest query sketch
   int32_t total_rows, pad0[3];
   uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
-  uint32_t counters[8];             // loci, groups, loci overflow, wide-state loci, finished row workgroups
+  uint32_t counters[8];             // loci, (unused), loci overflow, wide-state loci, finished row workgroups, k_l1 roads (2)
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
   unsigned long long dbg[16];       // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the sampled workgroups (thread 0's view); [8..10] why block sorts gave up

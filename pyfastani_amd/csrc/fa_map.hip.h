@@ -619,7 +619,7 @@ struct L1Args {
   int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
   int32_t *l_rfirst, *l_rlast;   // record index of the first / last seed of the locus
   int32_t *l_rpart;              // record index of the seed that fixed the locus start (the partner of its first seed); -1 = unknown
-  uint32_t *counters;            // [0] loci, [1] groups, [2] loci overflow flag
+  uint32_t *counters;            // [0] loci (a group is numbered by its first locus), [2] loci overflow flag
   uint32_t *f_loci_lo, *f_loci_n; // [F] loci of each fragment (contiguous)
   unsigned long long *pinfo;     // [1] speculation flags
   int32_t lut_smax;              // sketch sizes the LUTs cover
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   __shared__ uint32_t sh_heads[2];
   __shared__ int sh_has_prev[2];
   __shared__ uint64_t sh_prev_g[2];
-  __shared__ uint32_t sh_base, sh_gbase, sh_grp;
+  __shared__ uint32_t sh_base, sh_gbase;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
   const uint32_t n = a.n_seeds[f];
@@ -1124,10 +1124,11 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   // the loci of a fragment that fit the LDS stage (the common case): (contig, start, end) from their three records, groups,
   // ONE reservation, out.  Ends the workgroup's work.
   auto staged_epilogue = [&](const uint32_t cnt0) __attribute__((always_inline)) {
-    // The common case: the loci are in LDS.  Their groups (consecutive loci on the same reference genome) are
-    // counted from the staged copy first, so that loci and groups are reserved with ONE returning atomic on the
-    // adjacent counters -- thousands of workgroups queue up on that address for ~12 ns each, and two reservations
-    // per workgroup cost k_l1 11 of its 96 us.
+    // The common case: the loci are in LDS.  A group (consecutive loci on the same reference genome) is numbered by the
+    // first locus it holds, so loci and groups need ONE reservation -- thousands of workgroups queue up on that address for
+    // ~12 ns each (on a single query all 1 666 arrive within one resident round: 20 us of queue.  Issuing the atomic as soon
+    // as the candidate scan knows the count does not overlap that queue with the rest of the work: the compiler's atomic
+    // optimizer waits for the answer on the spot).
     uint32_t *st_grp = (uint32_t *)(lds + l1_off_offset(a.lds_seed_cap));   // (the list offsets are no longer needed)
     // (contig, start, end) of every locus from its three records
     for (uint32_t q = tid; q < cnt0; q += NT) {
@@ -1137,22 +1138,21 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     }
     __syncthreads();
     if (wv == 0) {
-      uint32_t run = 0;
+      uint32_t last_head = 0;
       for (uint32_t i0 = 0; i0 < cnt0; i0 += 64) {
         const uint32_t i = i0 + lane;
         bool gh = false;
         if (i < cnt0) gh = (i == 0) || a.ix.contig_genome[st_seq[i]] != a.ix.contig_genome[st_seq[i - 1]];
         const uint64_t gb = __ballot(gh);
-        if (i < cnt0) st_grp[i] = run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1;
-        run += __popcll(gb);
+        const uint64_t upto = gb & ((2ULL << lane) - 1ULL);
+        if (i < cnt0) st_grp[i] = upto ? i0 + (uint32_t)(63 - __clzll(upto)) : last_head;   // first locus of the group of locus i
+        if (gb) last_head = i0 + (uint32_t)(63 - __clzll(gb));
       }
       if (lane == 0) {
-        const unsigned long long old = atomicAdd((unsigned long long *)&a.counters[0], (unsigned long long)cnt0 | ((unsigned long long)run << 32));
-        uint32_t base = (uint32_t)old, cnt = cnt0;
+        uint32_t base = atomicAdd(&a.counters[0], cnt0), cnt = cnt0;
         if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
         sh_gbase = cnt;
-        sh_grp = (uint32_t)(old >> 32);
         a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
       }
     }
@@ -1162,7 +1162,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       const uint32_t li = sh_base + q;
       a.l_frag[li] = f; a.l_seq[li] = st_seq[q]; a.l_start[li] = st_start[q]; a.l_rfirst[li] = st_rfirst[q];
       a.l_end[li] = st_end[q]; a.l_rlast[li] = st_rlast[q]; a.l_rpart[li] = st_rpart[q];
-      a.l_group[li] = (int32_t)(sh_grp + st_grp[q]);
+      a.l_group[li] = (int32_t)(sh_base + st_grp[q]);
     }
     phase(4);
   };
@@ -1421,8 +1421,8 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   __threadfence_block();
   __syncthreads();
   if (wv == 0) {
-    uint32_t run = 0, gbase = 0;
-    // count groups first
+    // a group is numbered by the first locus it holds (see staged_epilogue): no counter of its own
+    uint32_t last_head = 0;
     for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
       uint32_t i = i0 + lane;
       bool gh = false;
@@ -1430,21 +1430,10 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         int g = a.ix.contig_genome[a.l_seq[base + i]];
         gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
       }
-      run += __popcll(__ballot(gh));
-    }
-    if (lane == 0) gbase = atomicAdd(&a.counters[1], run);
-    gbase = __shfl(gbase, 0);
-    run = 0;
-    for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
-      uint32_t i = i0 + lane;
-      bool gh = false;
-      if (i < nl) {
-        int g = a.ix.contig_genome[a.l_seq[base + i]];
-        gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
-      }
-      uint64_t gb = __ballot(gh);
-      if (i < nl) a.l_group[base + i] = (int32_t)(gbase + run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1);
-      run += __popcll(gb);
+      const uint64_t gb = __ballot(gh);
+      const uint64_t upto = gb & ((2ULL << lane) - 1ULL);
+      if (i < nl) a.l_group[base + i] = (int32_t)(base + (upto ? i0 + (uint32_t)(63 - __clzll(upto)) : last_head));
+      if (gb) last_head = i0 + (uint32_t)(63 - __clzll(gb));
     }
   }
 }
@@ -1693,7 +1682,8 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   __threadfence_block();
   __syncthreads();
   if (wv == 0) {
-    uint32_t run = 0, gbase = 0;
+    // a group is numbered by the first locus it holds (see staged_epilogue): no counter of its own
+    uint32_t last_head = 0;
     for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
       uint32_t i = i0 + lane;
       bool gh = false;
@@ -1701,21 +1691,10 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
         int g = a.ix.contig_genome[a.l_seq[base + i]];
         gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
       }
-      run += __popcll(__ballot(gh));
-    }
-    if (lane == 0) gbase = atomicAdd(&a.counters[1], run);
-    gbase = __shfl(gbase, 0);
-    run = 0;
-    for (uint32_t i0 = 0; i0 < nl; i0 += 64) {
-      uint32_t i = i0 + lane;
-      bool gh = false;
-      if (i < nl) {
-        int g = a.ix.contig_genome[a.l_seq[base + i]];
-        gh = (i == 0) || g != a.ix.contig_genome[a.l_seq[base + i - 1]];
-      }
-      uint64_t gb = __ballot(gh);
-      if (i < nl) a.l_group[base + i] = (int32_t)(gbase + run + __popcll(gb & ((2ULL << lane) - 1ULL)) - 1);
-      run += __popcll(gb);
+      const uint64_t gb = __ballot(gh);
+      const uint64_t upto = gb & ((2ULL << lane) - 1ULL);
+      if (i < nl) a.l_group[base + i] = (int32_t)(base + (upto ? i0 + (uint32_t)(63 - __clzll(upto)) : last_head));
+      if (gb) last_head = i0 + (uint32_t)(63 - __clzll(gb));
     }
   }
 }
@@ -2306,7 +2285,7 @@ namespace fa {
 struct CgiArgs {
   IndexView ix;
   const unsigned long long *group_best;
-  const uint32_t *counters;     // [1] number of groups
+  const uint32_t *counters;     // [0] number of loci (= bound of the group numbers)
   const int32_t *l_frag, *l_seq, *l_pos;
   const int32_t *q_size;
   const float *ident_lut;       // triangular
@@ -2322,7 +2301,7 @@ struct CgiArgs {
 __global__ void k_cgi_bins(CgiArgs a) {
   stage_stamp(a.stamp);
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a.counters[2] || g >= a.counters[1]) return;
+  if (a.counters[2] || g >= a.counters[0]) return;                  // (a group carries the number of its first locus)
   // A void part must leave no trace in the bin table, which later parts and the repeat of this one accumulate into: when a
   // locus overflowed the one-byte slide state and the wide pass was not launched, the group maxima lack that locus, and a
   // lesser locus of its group could land in a bin the true best never touches (the host repeats the part, fa_engine.hip)
