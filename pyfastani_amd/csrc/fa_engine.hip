@@ -374,6 +374,7 @@ struct PassStatus {
   uint32_t counters[8];             // loci, (unused), loci overflow, wide-state loci, finished row workgroups, k_l1 roads (2)
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
+  uint32_t loci_region[LOCI_REGIONS];                                  // k_l1: loci reserved per region (LociRegions)
   unsigned long long dbg[16];       // FA_L1_STATS=1: shader-clock ticks of k_l1's phases, summed over the sampled workgroups (thread 0's view); [8..10] why block sorts gave up
   unsigned long long stamp[6];      // stage_stamp: pass start, lookup, L2, CGI, end (100 MHz ticks); not cleared with the rest
   uint32_t seq, pad1;               // host copy only: number of the pass whose status this is (k_publish_status)
@@ -435,7 +436,9 @@ struct Workspace {
   const float *lut_ident = nullptr;
   // last-pass bookkeeping for the debug getters
   int64_t last_F = 0, last_f0 = 0;
-  uint32_t last_loci = 0;
+  uint32_t last_loci = 0;             // loci of the last accepted part (all regions)
+  uint32_t loci_n = 1, loci_shift = 0;                    // regions of the locus numbering of the part in flight / last accepted
+  uint32_t last_region_count[LOCI_REGIONS] = {0};         // live loci per region of the last accepted part
   uint64_t last_items = 0;
   const fa_genomes *last_genomes = nullptr;
   float last_ms[24] = {0};
@@ -1030,6 +1033,7 @@ struct QueryPass {
     int l1_threads = 256, l1_nt = 256;
     uint32_t seed_slots = 0;
     bool wide = false;
+    LociRegions loci{nullptr, 1, 0};          // regions of the locus numbering of this part
     const int32_t *frag_order = nullptr;      // workgroup order of the part (prepare_order), null = identity
     uint32_t order_len = 0;
     Part(QueryPass &q, Run &r)
@@ -1083,6 +1087,11 @@ struct QueryPass {
     ln.l_beg.ensure((size_t)l_cap); ln.l_end0.ensure((size_t)l_cap); ln.l_last.ensure((size_t)l_cap); ln.l_ndrop.ensure((size_t)l_cap);
     ln.l_nev.ensure((size_t)l_cap); ln.l_ioff.ensure((size_t)l_cap); ln.l_redo.ensure((size_t)l_cap + 4);
     ln.ovf_buf.ensure((size_t)sp.scratch_words + 4);
+    // the locus numbering: one region per sixteen fragments (64 at most), each the largest power of two that fits its share
+    p.loci.count = ln.status.p->loci_region;
+    p.loci.n = std::min<uint32_t>(LOCI_REGIONS, ev_regions_for(F));
+    p.loci.shift = (uint32_t)floor_log2((int)std::max<int64_t>(1, l_cap / p.loci.n));
+    ln.loci_n = p.loci.n; ln.loci_shift = p.loci.shift;
     p.wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
     ln.items.ensure(((size_t)sp.items_cap + 8) * (p.wide ? 4 : 2));
 
@@ -1188,7 +1197,7 @@ struct QueryPass {
       a.ovf_off = ln.ovf_off.p; a.ovf_buf = ln.ovf_buf.p; a.min_hits_lut = w.lut_min_hits;
       a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
       a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.l_rpart = ln.l_rpart.p;
-      a.counters = d_counters; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
+      a.counters = d_counters; a.loci = p.loci; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
       a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       static const bool l1_block_sort_on = !(getenv("FA_L1_BLOCK_SORT") && atoi(getenv("FA_L1_BLOCK_SORT")) == 0);
@@ -1258,7 +1267,7 @@ struct QueryPass {
       a.l_beg = ln.l_beg.p; a.l_end0 = ln.l_end0.p; a.l_last = ln.l_last.p; a.l_nev = ln.l_nev.p; a.l_ioff = ln.l_ioff.p; a.l_ndrop = ln.l_ndrop.p;
       a.items = ln.items.p; a.items_cap = sp.items_cap; a.pinfo = d_pinfo; a.l_cap = (int32_t)l_cap;
       a.l_shared = ln.l_shared.p; a.l_pos = ln.l_pos.p; a.pass_lut = w.lut_pass; a.group_best = ln.group_best.p;
-      a.counters = d_counters; a.qcap = qcap; a.cmw = m.cmw;
+      a.counters = d_counters; a.loci = p.loci; a.qcap = qcap; a.cmw = m.cmw;
       a.cnt_slots = smax + 1;
       a.rec_total = (unsigned long long *)(d_totals + 3);
       a.ev_region = ln.status.p->ev_region; a.rec_region = ln.status.p->rec_region;
@@ -1294,6 +1303,8 @@ struct QueryPass {
       const int lanes8 = pick_lanes(1), lanes16 = pick_lanes(2);
       static const size_t scan_pad = (size_t)exp_u64("FA_SCAN_LDS_PAD", 0);   // experiment: fewer scan workgroups per CU
       const size_t lds8 = scan_lds(lanes8, 1) + scan_pad, lds16 = scan_lds(lanes16, 2);
+      // (workgroup b of a scan takes chunk b / n of region b mod n: every region needs its chunks, however few loci it can hold)
+      auto scan_grid = [&](int lanes) { return (unsigned)(p.loci.n * (uint32_t)ceil_div((int64_t)1 << p.loci.shift, lanes)); };
       auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
         if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
         hipLaunchKernelGGL(ev_kernel, dim3(ev_grid), dim3(EV_THREADS), ev_lds, st, a);
@@ -1302,20 +1313,20 @@ struct QueryPass {
         a.lanes = lanes8;
         if (lanes8 == L2_THREADS) {
           if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-          hipLaunchKernelGGL(scan8, dim3(ceil_div(l_cap, lanes8)), dim3(L2_THREADS), lds8, st, a);
+          hipLaunchKernelGGL(scan8, dim3(scan_grid(lanes8)), dim3(L2_THREADS), lds8, st, a);
         } else {
           if (lds8 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan8_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8));
-          hipLaunchKernelGGL(scan8_rt, dim3(ceil_div(l_cap, lanes8)), dim3(L2_THREADS), lds8, st, a);
+          hipLaunchKernelGGL(scan8_rt, dim3(scan_grid(lanes8)), dim3(L2_THREADS), lds8, st, a);
         }
         // the wide-state pass is only launched once some locus has needed it (a part that finds out too late is repeated)
         if (!sp.redo) return;
         a.lanes = lanes16;
         if (lanes16 == L2_THREADS) {
           if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-          hipLaunchKernelGGL(scan16, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
+          hipLaunchKernelGGL(scan16, dim3(scan_grid(lanes16)), dim3(L2_THREADS), lds16, st, a);
         } else {
           if (lds16 > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)scan16_rt, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
-          hipLaunchKernelGGL(scan16_rt, dim3(ceil_div(l_cap, lanes16)), dim3(L2_THREADS), lds16, st, a);
+          hipLaunchKernelGGL(scan16_rt, dim3(scan_grid(lanes16)), dim3(L2_THREADS), lds16, st, a);
         }
       };
 #ifdef FA_EXPERIMENTS
@@ -1410,6 +1421,7 @@ struct QueryPass {
       a.bin_len = m.P.fragment_length - 20;
       a.query_base = g0;                             // frag_query holds batch-wide genome numbers
       a.wide_launched = sp.redo ? 1 : 0;
+      a.group_bound = p.loci.n << p.loci.shift;
       hipLaunchKernelGGL(k_cgi_bins, dim3(ceil_div(l_cap, 256)), dim3(256), 0, st, a);
     }
     // ---- the one hand-over of the part: results, statistics and the speculation verdict (publish_pass) ----
@@ -1443,6 +1455,13 @@ struct QueryPass {
       ev_region_max = std::max<uint64_t>(ev_region_max, ln.h_status->ev_region[i]);
     }
     const unsigned long long flags = h_pinfo[1];
+    // loci: reserved per region (LociRegions); a region asked for more than it holds = SPEC_LOCI
+    uint64_t loci_total = 0, loci_region_max = 0;
+    for (uint32_t i = 0; i < ln.loci_n; i++) {
+      const uint64_t c = ln.h_status->loci_region[i];
+      loci_region_max = std::max(loci_region_max, c);
+      loci_total += std::min<uint64_t>(c, 1ULL << ln.loci_shift);
+    }
     // a part whose seeds / loci / slide events cannot be addressed with 32-bit offsets is cut down and run again
     if (flags || (h_counters[3] > 0 && !sp.redo)) w.last_ms[9] += 1.0f;   // repeated attempts of this call (speculation misses)
     auto shrink_part = [&](double have, double limit, const char *what) {
@@ -1473,9 +1492,11 @@ struct QueryPass {
     const bool slots_changed = want_slots != sp.seed_slots;
     if (flags & SPEC_SCRATCH) sp.scratch_words = std::max<uint64_t>(sp.scratch_words, h_totals[2] + h_totals[2] / 4);
     if (flags & SPEC_LOCI) {
-      const int64_t want = std::max<int64_t>(sp.l_cap * 2, (int64_t)h_counters[0] + h_counters[0] / 4);
+      // every region has to hold its share: size the arrays for the fullest one
+      const int64_t need = (int64_t)(loci_region_max * ln.loci_n);
+      const int64_t want = std::max<int64_t>(sp.l_cap * 2, need + need / 4);
       const int64_t l_max = (1LL << 31) - 64;
-      if ((int64_t)h_counters[0] > l_max) { shrink_part((double)h_counters[0], (double)l_max, "candidate loci"); publish_spec(sp); return false; }
+      if (need > l_max) { shrink_part((double)need, (double)l_max, "candidate loci"); publish_spec(sp); return false; }
       sp.l_cap = std::min(want, l_max);
     }
     if (flags & SPEC_QFUSE) {
@@ -1515,10 +1536,12 @@ struct QueryPass {
     for (int i = 0; i < 4; i++) w.last_ms[i] += (float)((double)(stamp[i + 1] - stamp[i]) * 1e-5);
     t_begin = std::min(t_begin, stamp[0]); t_end = std::max(t_end, stamp[4]);
     ln.last_F = F;
-    ln.last_loci = h_counters[0];
+    ln.last_loci = (uint32_t)loci_total;
+    for (uint32_t i = 0; i < LOCI_REGIONS; i++)
+      ln.last_region_count[i] = i < ln.loci_n ? (uint32_t)std::min<uint64_t>(ln.h_status->loci_region[i], 1ULL << ln.loci_shift) : 0u;
     ln.last_items = events_total;
     w.last_ms[5] += (float)records_total;   // reference records inside the locus ranges of this call (roofline line)
-    w.last_ms[6] += (float)h_counters[0];
+    w.last_ms[6] += (float)loci_total;
     w.last_ms[7] += (float)events_total;  // slide events
     w.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
     w.last_ms[20] += (float)h_counters[5]; w.last_ms[21] += (float)h_counters[6];   // FA_L1_STATS=1: fragments block-sorted / merged by k_l1
@@ -1776,6 +1799,13 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
+// the live loci of a part, region by region (LociRegions): fn(first locus number, count)
+template <class Fn>
+static void for_each_locus_slice(const Workspace &x, Fn fn) {
+  for (uint32_t r = 0; r < x.loci_n && r < (uint32_t)LOCI_REGIONS; r++)
+    if (x.last_region_count[r]) fn((size_t)r << x.loci_shift, (size_t)x.last_region_count[r]);
+}
+
 extern "C" {
 
 const char *fa_last_error(void) { return g_last_error.c_str(); }
@@ -2241,10 +2271,14 @@ int fa_mapper_debug_mappings(fa_mapper *m, fa_mapping *out, int64_t cap, int64_t
     for (Workspace *x : lanes_of_last_pass(w)) {
       const uint32_t L = x->last_loci;
       std::vector<int32_t> lf(L), ls(L), lp(L), lsh(L), qs((size_t)x->last_F);
-      if (L) {
-        x->l_frag.download(lf.data(), L, x->stream); x->l_seq.download(ls.data(), L, x->stream);
-        x->l_pos.download(lp.data(), L, x->stream); x->l_shared.download(lsh.data(), L, x->stream);
-      }
+      size_t at = 0;
+      for_each_locus_slice(*x, [&](size_t first, size_t count) {
+        FA_HIP(hipMemcpyAsync(lf.data() + at, x->l_frag.p + first, count * 4, hipMemcpyDeviceToHost, x->stream));
+        FA_HIP(hipMemcpyAsync(ls.data() + at, x->l_seq.p + first, count * 4, hipMemcpyDeviceToHost, x->stream));
+        FA_HIP(hipMemcpyAsync(lp.data() + at, x->l_pos.p + first, count * 4, hipMemcpyDeviceToHost, x->stream));
+        FA_HIP(hipMemcpyAsync(lsh.data() + at, x->l_shared.p + first, count * 4, hipMemcpyDeviceToHost, x->stream));
+        at += count;
+      });
       x->q_size.download(qs.data(), (size_t)x->last_F, x->stream);
       FA_HIP(hipStreamSynchronize(x->stream));
       for (uint32_t i = 0; i < L; i++) {
@@ -2269,14 +2303,20 @@ int fa_mapper_debug_l1(fa_mapper *m, int32_t *frag, int32_t *seq_id, int32_t *rs
     Workspace &w = m->ws[m->last_ws];
     int64_t k = 0;
     for (Workspace *x : lanes_of_last_pass(w)) {
-      const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>(x->last_loci, cap - k));
-      if (c) {
-        x->l_frag.download(frag + k, c, x->stream); x->l_seq.download(seq_id + k, c, x->stream);
-        x->l_start.download(rs + k, c, x->stream); x->l_end.download(re + k, c, x->stream);
-        FA_HIP(hipStreamSynchronize(x->stream));
-        for (size_t i = 0; i < c; i++) frag[k + i] += (int32_t)(x->last_f0 - w.pass_f0);
-      }
-      k += x->last_loci;
+      int64_t kk = k;
+      for_each_locus_slice(*x, [&](size_t first, size_t count) {
+        const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>((int64_t)count, cap - kk));
+        if (c) {
+          FA_HIP(hipMemcpyAsync(frag + kk, x->l_frag.p + first, c * 4, hipMemcpyDeviceToHost, x->stream));
+          FA_HIP(hipMemcpyAsync(seq_id + kk, x->l_seq.p + first, c * 4, hipMemcpyDeviceToHost, x->stream));
+          FA_HIP(hipMemcpyAsync(rs + kk, x->l_start.p + first, c * 4, hipMemcpyDeviceToHost, x->stream));
+          FA_HIP(hipMemcpyAsync(re + kk, x->l_end.p + first, c * 4, hipMemcpyDeviceToHost, x->stream));
+        }
+        kk += (int64_t)count;
+      });
+      FA_HIP(hipStreamSynchronize(x->stream));
+      for (int64_t i = k; i < std::min<int64_t>(kk, cap); i++) frag[i] += (int32_t)(x->last_f0 - w.pass_f0);
+      k = kk;
     }
     *n = k;
   });
@@ -2363,9 +2403,12 @@ int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, in
     Workspace &w = m->ws[m->last_ws];
     int64_t k = 0;
     for (Workspace *x : lanes_of_last_pass(w)) {
-      const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>(x->last_loci, cap - k));
-      if (c) { x->l_nev.download(events + k, c, x->stream); FA_HIP(hipStreamSynchronize(x->stream)); }
-      k += x->last_loci;
+      for_each_locus_slice(*x, [&](size_t first, size_t count) {
+        const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>((int64_t)count, cap - k));
+        if (c) FA_HIP(hipMemcpyAsync(events + k, x->l_nev.p + first, c * 4, hipMemcpyDeviceToHost, x->stream));
+        k += (int64_t)count;
+      });
+      FA_HIP(hipStreamSynchronize(x->stream));
     }
     *n = k;
   });

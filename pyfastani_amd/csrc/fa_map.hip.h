@@ -599,6 +599,27 @@ __global__ __launch_bounds__(1024) void k_seed_totals(const uint32_t *n_seeds, i
 // overlapping candidates (computeL1CandidateRegions).  One workgroup per fragment; loci are appended to global
 // arrays in (fragment-local) order, and consecutive loci on the same reference genome share a `group`.
 // ----------------------------------------------------------------------------------------------------------
+// Loci are numbered per REGION: fragment f reserves in region f mod n (n a power of two, one region per sixteen fragments, 64
+// at most), region r holds the loci [r << shift, (r << shift) + count[r]).  One counter for everything made thousands of
+// workgroups queue on one address for ~12 ns each -- 20 us at the end of k_l1 on a single query, whose 1 666 workgroups all
+// arrive there within one resident round.  A locus number is live iff it lies inside the filled part of its region.
+constexpr int LOCI_REGIONS = 64;
+struct LociRegions {
+  uint32_t *count;              // [n] loci reserved per region (may exceed the capacity: the pass is void then, counters[2])
+  uint32_t n, shift;
+};
+__device__ __forceinline__ bool locus_live(const LociRegions &g, uint32_t l) {
+  const uint32_t r = l >> g.shift;
+  return r < g.n && (l & ((1u << g.shift) - 1u)) < g.count[r];
+}
+// `cnt` loci for fragment f: the number of the first one; `ok` = they fit the region
+__device__ __forceinline__ uint32_t reserve_loci(const LociRegions &g, int f, uint32_t cnt, bool &ok) {
+  const uint32_t r = (uint32_t)f & (g.n - 1u);
+  const uint32_t off = atomicAdd(&g.count[r], cnt);
+  ok = off + cnt <= (1u << g.shift);
+  return (r << g.shift) + off;
+}
+
 struct L1Args {
   // the seed totals of the pass (seed_totals) as workgroup number F of this launch, when nothing in the pass needs the
   // scratch offsets they produce (no fragment has outgrown the LDS seed slots on this mapper yet)
@@ -619,7 +640,8 @@ struct L1Args {
   int32_t *l_frag, *l_seq, *l_start, *l_end, *l_group;   // loci, capacity l_cap
   int32_t *l_rfirst, *l_rlast;   // record index of the first / last seed of the locus
   int32_t *l_rpart;              // record index of the seed that fixed the locus start (the partner of its first seed); -1 = unknown
-  uint32_t *counters;            // [0] loci (a group is numbered by its first locus), [2] loci overflow flag
+  uint32_t *counters;            // [2] loci overflow flag
+  LociRegions loci;              // where the loci of a fragment are reserved (a group is numbered by its first locus)
   uint32_t *f_loci_lo, *f_loci_n; // [F] loci of each fragment (contiguous)
   unsigned long long *pinfo;     // [1] speculation flags
   int32_t lut_smax;              // sketch sizes the LUTs cover
@@ -1149,8 +1171,9 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
         if (gb) last_head = i0 + (uint32_t)(63 - __clzll(gb));
       }
       if (lane == 0) {
-        uint32_t base = atomicAdd(&a.counters[0], cnt0), cnt = cnt0;
-        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+        bool fits;
+        uint32_t base = reserve_loci(a.loci, f, cnt0, fits), cnt = cnt0;
+        if (!fits) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
         sh_gbase = cnt;
         a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
@@ -1190,7 +1213,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     auto scan_run = [&](auto tag) __attribute__((always_inline)) {
       using G = decltype(tag);
       constexpr bool NARROW = sizeof(G) == 4;
-      constexpr int CB = NARROW ? 9 : 7;                                     // steps per batch (registers: one or two per step)
+      constexpr int CB = NARROW ? 9 : 6;                                     // steps per batch (registers: one or two per step)
       auto coord = [&](uint32_t step) __attribute__((always_inline)) -> G {
         const uint32_t idx = step * 64u + (uint32_t)lane;
         if (!(step <= s1 && idx < n)) return (G)0;
@@ -1269,8 +1292,9 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       // more loci than the stage holds: reserve, and write them straight to HBM
       if (tid == 0) {
         uint32_t cnt = total;
-        uint32_t base = atomicAdd(&a.counters[0], cnt);
-        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+        bool fits;
+        uint32_t base = reserve_loci(a.loci, f, cnt, fits);
+        if (!fits) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
         sh_gbase = cnt;
         a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
@@ -1396,8 +1420,9 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       // more loci than the stage holds (or none): reserve, then a second pass writes them straight to HBM
       if (tid == 0) {
         uint32_t cnt = cnt0;
-        uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
-        if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+        bool fits = true;
+        uint32_t base = cnt ? reserve_loci(a.loci, f, cnt, fits) : 0;
+        if (!fits) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
         sh_base = base;
         sh_gbase = cnt;   // reuse: number of loci (0 => skip)
         a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
@@ -1664,8 +1689,9 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
   // ---- the loci to their final place, then the groups (as in k_l1) ----
   if (tid == 0) {
     uint32_t cnt = sh_loci;
-    uint32_t base = cnt ? atomicAdd(&a.counters[0], cnt) : 0;
-    if (base + cnt > (uint32_t)a.l_cap) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
+    bool fits = true;
+    uint32_t base = cnt ? reserve_loci(a.loci, f, cnt, fits) : 0;
+    if (!fits) { atomicExch(&a.counters[2], 1u); atomicOr(&a.pinfo[1], (unsigned long long)SPEC_LOCI); cnt = 0; }
     sh_base = base; sh_cnt = cnt;
     a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
     a.big_state[f] = 1;
@@ -1738,7 +1764,8 @@ struct L2Args {
   int32_t *l_shared, *l_pos;
   const int32_t *pass_lut;           // [smax+1]
   unsigned long long *group_best;    // [groups] (shared<<32 | ~locus)
-  const uint32_t *counters;          // [0] number of loci
+  const uint32_t *counters;          // [2] loci overflow flag, [3] wide-state loci
+  LociRegions loci;                  // which locus numbers are live (k_l2_scan)
   int32_t qcap, cmw;
   int32_t cnt_slots;                 // smax + 1
   int32_t lanes;                     // loci per workgroup of k_l2_scan (power of two <= 64)
@@ -2216,8 +2243,10 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   ST *st = (ST *)lds;                                              // [cnt_slots + 1][LN], lane-interleaved
   const int lane = threadIdx.x;
   if (lane >= LN) return;
-  const uint32_t l = blockIdx.x * LN + lane;
-  if (a.counters[2] || l >= a.counters[0]) return;
+  // workgroup b takes chunk b / n of region b mod n (regions are filled from their start: the workgroups that have loci come
+  // first in dispatch order, as they did with one dense numbering, and the empty ones behind them exit at once)
+  const uint32_t l = ((blockIdx.x & (a.loci.n - 1u)) << a.loci.shift) + (blockIdx.x / a.loci.n) * (uint32_t)LN + (uint32_t)lane;
+  if (a.counters[2] || (blockIdx.x / a.loci.n) * (uint32_t)LN + (uint32_t)lane >= (1u << a.loci.shift) || !locus_live(a.loci, l)) return;
   if (REDO) { if (!a.l_redo[l]) return; }
   else a.l_redo[l] = 0;
   const int s = a.q_size[a.l_frag[l]];
@@ -2285,7 +2314,7 @@ namespace fa {
 struct CgiArgs {
   IndexView ix;
   const unsigned long long *group_best;
-  const uint32_t *counters;     // [0] number of loci (= bound of the group numbers)
+  const uint32_t *counters;     // [2] loci overflow flag, [3] wide-state loci
   const int32_t *l_frag, *l_seq, *l_pos;
   const int32_t *q_size;
   const float *ident_lut;       // triangular
@@ -2294,6 +2323,7 @@ struct CgiArgs {
   unsigned long long *bins;     // [NQ * total_bins]
   int32_t bin_len;              // fragment_length - 20
   int32_t query_base;           // first query genome of this pass (frag_query is batch-wide)
+  uint32_t group_bound;         // locus numbers (= group numbers) lie below this: regions x their capacity
   int32_t wide_launched;        // the wide-state scan ran in this part (k_l2_scan<., uint16_t>): loci that left the byte state are settled
   unsigned long long *stamp;    // stage_stamp: start of the CGI stage
 };
@@ -2301,7 +2331,8 @@ struct CgiArgs {
 __global__ void k_cgi_bins(CgiArgs a) {
   stage_stamp(a.stamp);
   uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a.counters[2] || g >= a.counters[0]) return;                  // (a group carries the number of its first locus)
+  if (a.counters[2] || g >= a.group_bound) return;                    // (a group carries the number of its first locus; the table of
+                                                                      //  group maxima is cleared per pass: no maximum, no group)
   // A void part must leave no trace in the bin table, which later parts and the repeat of this one accumulate into: when a
   // locus overflowed the one-byte slide state and the wide pass was not launched, the group maxima lack that locus, and a
   // lesser locus of its group could land in a bin the true best never touches (the host repeats the part, fa_engine.hip)
