@@ -1047,7 +1047,7 @@ struct QueryPass {
     Workspace &ln = p.ln;
     hipStream_t st = p.st;
     const fa_mapper::Spec &sp = p.sp;
-    const int64_t f0 = p.f0, f1 = p.f1, F = p.F;
+    const int64_t f0 = p.f0, F = p.F;
     ln.serial = w.serial;
     if (&ln != &w) FA_HIP(hipStreamWaitEvent(st, w.ev_bins, 0));     // (the bin table is cleared on the first lane's stream)
     ln.last_F = 0; ln.last_f0 = f0; ln.last_loci = 0;                 // (filled in when the part is accepted)
@@ -1129,13 +1129,7 @@ struct QueryPass {
     hipStream_t st = p.st;
     const fa_mapper::Spec &sp = p.sp;
     const int64_t f0 = p.f0, F = p.F;
-    const int smax = p.smax;
     const int64_t l_cap = p.l_cap;
-    int32_t *const d_stats = ln.status.p->stats;
-    uint64_t *const d_totals = ln.status.p->totals;
-    uint32_t *const d_counters = ln.status.p->counters;
-    unsigned long long *const d_pinfo = ln.status.p->pinfo;
-    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
     const int t0 = p.t0, ntiles = p.ntiles;
     {
       ClearList cl;
@@ -1171,14 +1165,13 @@ struct QueryPass {
     Workspace &ln = p.ln;
     hipStream_t st = p.st;
     const fa_mapper::Spec &sp = p.sp;
-    const int64_t f0 = p.f0, F = p.F;
+    const int64_t F = p.F;
     const int smax = p.smax;
     const int64_t l_cap = p.l_cap;
     int32_t *const d_stats = ln.status.p->stats;
     uint64_t *const d_totals = ln.status.p->totals;
     uint32_t *const d_counters = ln.status.p->counters;
     unsigned long long *const d_pinfo = ln.status.p->pinfo;
-    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
     const uint32_t seed_slots = p.seed_slots;
     const int l1_threads = p.l1_threads, l1_nt = p.l1_nt;
     // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch).  A kernel of its own
@@ -1246,15 +1239,12 @@ struct QueryPass {
     Workspace &ln = p.ln;
     hipStream_t st = p.st;
     const fa_mapper::Spec &sp = p.sp;
-    const int64_t f0 = p.f0, F = p.F;
+    const int64_t F = p.F;
     const int smax = p.smax;
     const int64_t l_cap = p.l_cap;
-    int32_t *const d_stats = ln.status.p->stats;
     uint64_t *const d_totals = ln.status.p->totals;
     uint32_t *const d_counters = ln.status.p->counters;
     unsigned long long *const d_pinfo = ln.status.p->pinfo;
-    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
-    const int64_t f1 = p.f1;
     const bool wide = p.wide;
     // ---- L2: event streams, then the sequential slide (uint8 state, uint16 redo) ----
     {
@@ -1403,14 +1393,9 @@ struct QueryPass {
     Workspace &ln = p.ln;
     hipStream_t st = p.st;
     const fa_mapper::Spec &sp = p.sp;
-    const int64_t f0 = p.f0, F = p.F;
-    const int smax = p.smax;
+    const int64_t f0 = p.f0;
     const int64_t l_cap = p.l_cap;
-    int32_t *const d_stats = ln.status.p->stats;
-    uint64_t *const d_totals = ln.status.p->totals;
     uint32_t *const d_counters = ln.status.p->counters;
-    unsigned long long *const d_pinfo = ln.status.p->pinfo;
-    (void)f0; (void)F; (void)smax; (void)l_cap; (void)d_stats; (void)d_totals; (void)d_counters; (void)d_pinfo; (void)sp;
     // ---- core-genome identity ----
     if (npairs > 0) {
       CgiArgs a;
@@ -1492,9 +1477,10 @@ struct QueryPass {
     const bool slots_changed = want_slots != sp.seed_slots;
     if (flags & SPEC_SCRATCH) sp.scratch_words = std::max<uint64_t>(sp.scratch_words, h_totals[2] + h_totals[2] / 4);
     if (flags & SPEC_LOCI) {
-      // every region has to hold its share: size the arrays for the fullest one
+      // every region has to hold its share: size the arrays for the fullest one.  A region holds the largest power of two
+      // below its share of l_cap, i.e. more than half of it: twice the need is what makes the repeat fit for certain
       const int64_t need = (int64_t)(loci_region_max * ln.loci_n);
-      const int64_t want = std::max<int64_t>(sp.l_cap * 2, need + need / 4);
+      const int64_t want = std::max<int64_t>(sp.l_cap * 2, need * 2);
       const int64_t l_max = (1LL << 31) - 64;
       if (need > l_max) { shrink_part((double)need, (double)l_max, "candidate loci"); publish_spec(sp); return false; }
       sp.l_cap = std::min(want, l_max);
