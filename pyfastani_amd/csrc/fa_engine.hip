@@ -371,7 +371,7 @@ struct PassStatus {
   int32_t stats[4];                 // [0] largest query sketch
   int32_t total_rows, pad0[3];
   uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
-  uint32_t counters[8];             // loci, (unused), loci overflow, wide-state loci, finished row workgroups, k_l1 roads (2)
+  uint32_t counters[8];             // [0], [1] unused (the loci are counted per region, loci_region); [2] loci overflow, wide-state loci, finished row workgroups, k_l1 roads (2)
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
   uint32_t loci_region[LOCI_REGIONS];                                  // k_l1: loci reserved per region (LociRegions)
