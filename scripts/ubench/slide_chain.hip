@@ -85,6 +85,8 @@ int main(int argc, char **argv) {
   a.pass_lut = dev_i32(h_pass);
   int32_t qs = S; int32_t *d_qs; CHECK(hipMalloc(&d_qs, 4)); CHECK(hipMemcpy(d_qs, &qs, 4, hipMemcpyHostToDevice)); a.q_size = d_qs;
   uint32_t *d_counters; CHECK(hipMalloc(&d_counters, 32)); a.counters = d_counters; a.redo_count = d_counters + 3;
+  // one region that holds every locus of a launch (LociRegions: workgroup b takes loci [64 b, 64 b + 64))
+  uint32_t *d_live; CHECK(hipMalloc(&d_live, 4)); a.loci.count = d_live; a.loci.n = 1; a.loci.shift = 24;
   uint8_t *d_redo; CHECK(hipMalloc(&d_redo, max_loci)); a.l_redo = d_redo;
   unsigned long long *d_gb; CHECK(hipMalloc(&d_gb, 64)); CHECK(hipMemset(d_gb, 0, 64)); a.group_best = d_gb;
   a.items = d_items; a.cnt_slots = 257; a.lanes = 64; a.qcap = 0; a.cmw = 0;
@@ -100,8 +102,9 @@ int main(int argc, char **argv) {
   for (const Cfg &c : cfgs) {
     const size_t lds = std::max(state, (size_t)(c.per_cu == 4 ? 36 * 1024 : 19 * 1024));
     const uint32_t loci = (uint32_t)c.waves * 64;
-    uint32_t cnt[8] = {loci, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     CHECK(hipMemcpy(d_counters, cnt, 32, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(d_live, &loci, 4, hipMemcpyHostToDevice));
     // clock under a comparable load
     hipLaunchKernelGGL(k_clock, dim3(cus), dim3(256), 0, 0, d_clk, 20000);
     std::vector<unsigned long long> hc((size_t)cus * 2);
