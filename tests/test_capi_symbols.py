@@ -102,3 +102,19 @@ def test_no_kernel_of_the_library_needs_scratch_memory():
     assert not spilled, spilled
     hot = [v for k, v in ours.items() if "k_l1ILi" in k and "ELi16E" in k]
     assert hot and all(v["occupancy_waves_per_simd"] == 8 for v in hot), hot
+
+
+def test_the_slide_microbenchmark_still_compiles_against_the_kernels():
+    """`scripts/ubench/slide_chain.hip` launches the PRODUCT `k_l2_scan` on synthetic event streams (the numbers of
+    profiles/r03_valu_rates.txt and of every slide experiment come from it): it fills `L2Args` by hand, so a change of the
+    kernel's arguments must reach it (syntax check only: seconds, no GPU)."""
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "scripts", "ubench", "slide_chain.hip")
+    proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-std=c++17", "-fsyntax-only", "-w", src],
+                          cwd=os.path.dirname(src), stderr=subprocess.PIPE, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    text = open(src).read()
+    assert "a.loci.count" in text and "a.loci.n" in text and "a.loci.shift" in text    # (the arguments k_l2_scan finds its loci by)
