@@ -84,12 +84,10 @@ def launch_ranks(n):
     process per GPU, rendezvous on 127.0.0.1) with this command line, relay its output -- the one JSON line of rank 0 --
     and return its status.  Decided before `import torch` or any HIP call: this process never touches the GPU, and
     nothing is exec'ed over a process that has."""
-    import socket
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the launcher's own c10d rendezvous on 127.0.0.1:0 -- torchrun binds a free port itself and keeps it (a port probed here and
+    # released before the child binds it could be taken in between); --local-addr: the container's host name may not resolve
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr=127.0.0.1", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "1")
     return subprocess.call(cmd, env=env, cwd=ROOT)

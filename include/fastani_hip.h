@@ -178,8 +178,19 @@ void fa_fasta_close(fa_fasta *f);
 /* Parser + Sketch._add_draft (_fastani.pyx:610-690) in one native call: every record of the file is a contig of ONE
  * reference genome; records are split and upper-cased by host threads and packed without passing through Python. */
 int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int64_t *n_short);
-/* One query genome per FASTA file, packed and uploaded as a resident batch (fa_genomes_upload semantics). */
+/* The same for n_paths reference genomes, one per file, in the order given: the files are read and 2-bit packed
+ * concurrently (one host task per file, straight from the file's bytes to packed words), then added as n_paths
+ * consecutive fa_sketch_add_fasta calls would have added them.  n_records / n_short: [n_paths] or NULL.  The host side
+ * of the reference's benchmark loop `for path: sketch.add_draft(name, [r.seq for r in Parser(path)])`
+ * (benches/mapping/bench.py:41-47). */
+int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_paths, int64_t *n_records, int64_t *n_short);
+/* One query genome per FASTA file, packed and uploaded as a resident batch (fa_genomes_upload semantics); the files
+ * are read concurrently, and the upload runs on a stream of the batch's own. */
 int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_paths, fa_genomes **out);
+/* Refills a batch from other files, recycling its device buffers, its pinned staging image and its stream: the
+ * double-buffered form for a stream of query chunks (while one batch is mapped by fa_mapper_query_genomes on one host
+ * thread, another thread refills the other batch).  A failed refill leaves an empty batch. */
+int fa_genomes_reload_fasta(fa_mapper *m, fa_genomes *g, const char *const *paths, int32_t n_paths);
 
 /* ---- resident batches (many-to-many; inputs stay in HBM) -------------- */
 /* Pack + upload a batch of query genomes.  contig_genome[i] is the genome (0..n_genomes-1, non-decreasing)

@@ -703,6 +703,35 @@ cdef class Sketch(_Parameterized):
             warnings.warn("Sketch received a short contig relative to parameters, minimizers will not be added.", UserWarning)
         return self
 
+    def add_fasta_many(self, names, paths):
+        """`add_fasta` for many reference genomes at once (one per file, in order): the files are read and packed
+        concurrently by the library's host threads -- the native form of the reference benchmark's loading loop
+        (``benches/mapping/bench.py:41-47``)."""
+        cdef vector[const char*] arr
+        cdef vector[int64_t] n_rec, n_short
+        cdef int code
+        cdef int32_t n
+        names = list(names)
+        encoded = [os.fsencode(p) for p in paths]
+        if len(names) != len(encoded):
+            raise ValueError("names and paths differ in length")
+        for p in encoded:
+            arr.push_back(<const char*> p)
+        n = <int32_t> len(encoded)
+        n_rec.resize(max(n, 1)); n_short.resize(max(n, 1))
+        if arr.empty():
+            arr.push_back(NULL)
+        with self._lock:
+            with nogil:
+                code = hip.fa_sketch_add_fasta_many(self._hs, arr.data(), n, n_rec.data(), n_short.data())
+            _check(code)
+            self._names.extend(names)
+            self._version += 1
+        for i in range(n):
+            for _ in range(n_short[i]):
+                warnings.warn("Sketch received a short contig relative to parameters, minimizers will not be added.", UserWarning)
+        return self
+
     cpdef Sketch clear(self):
         """Reset the `Sketch`, removing any reference genome it may contain (_fastani.pyx:746-767)."""
         with self._lock:                       # (add_draft / add_genome / add_fasta hold it while they append contigs)
@@ -976,6 +1005,49 @@ cdef class Mapper(_Parameterized):
         """`query_draft` for a genome stored as a FASTA file (its records are the contigs)."""
         return self.upload_fasta([path]).query()[0]
 
+    def query_fasta_stream(self, paths, int chunk=24, rows=False):
+        """Map the genomes stored in `paths` (one FASTA file each) in chunks of `chunk` files, yielding ``(first, result)``
+        per chunk -- ``result`` is one hit list per genome, or the raw row array with ``rows=True`` (``query_id`` counts
+        from 0 inside the chunk).  While chunk c is mapped on the device, a second host thread reads, packs and uploads chunk
+        c + 1 into the other of two recycled batches (``fa_genomes_reload_fasta``: its own stream, a pinned staging image),
+        so the file-to-hits path is bound by the slower of the two sides, not by their sum."""
+        import queue
+        import threading
+        paths = list(paths)
+        chunks = [paths[i:i + chunk] for i in range(0, len(paths), max(1, chunk))]
+        if not chunks:
+            return
+        free = queue.Queue()
+        ready = queue.Queue(maxsize=2)
+        cdef GenomeBatch b
+        for _ in range(2):
+            free.put(None)
+
+        def loader():
+            try:
+                for i, c in enumerate(chunks):
+                    slot = free.get()
+                    if slot is None:
+                        slot = GenomeBatch.from_fasta(self, c, True)
+                    else:
+                        slot.reload_fasta(c)
+                    ready.put((i, slot))
+            except BaseException as exc:  # handed to the consumer
+                ready.put((-1, exc))
+
+        t = threading.Thread(target=loader, name="pyfastani-amd-ingest", daemon=True)
+        t.start()
+        try:
+            for _ in range(len(chunks)):
+                i, slot = ready.get()
+                if i < 0:
+                    raise slot
+                b = slot
+                yield i * chunk, (b.query_rows(0, b.n_genomes) if rows else b.query(0, b.n_genomes))
+                free.put(slot)
+        finally:
+            t.join(timeout=60)
+
     def query_batch(self, batch, first=0, count=None):
         """Map genomes ``[first, first+count)`` of a resident batch; returns one hit list per genome."""
         return batch.query(first, count)
@@ -1056,12 +1128,21 @@ cdef class GenomeBatch:
         self._finish()
 
     @classmethod
-    def from_fasta(cls, Mapper mapper, paths):
-        """One genome per FASTA file, parsed and packed by the library (``fa_genomes_upload_fasta``)."""
+    def from_fasta(cls, Mapper mapper, paths, recyclable=False):
+        """One genome per FASTA file, parsed and packed by the library (``fa_genomes_upload_fasta``).  ``recyclable``: the
+        batch is created empty and filled through `reload_fasta`, i.e. with a pinned staging image that later refills reuse."""
         cdef GenomeBatch self = GenomeBatch.__new__(GenomeBatch)
         cdef vector[const char*] arr
         cdef int code
         self._mapper = mapper
+        if recyclable:
+            arr.push_back(NULL)
+            self.n_genomes = 0
+            with nogil:
+                code = hip.fa_genomes_upload_fasta(mapper._hm, arr.data(), 0, &self._hg)
+            _check(code)
+            self.reload_fasta(paths)
+            return self
         encoded = [os.fsencode(p) for p in paths]
         for p in encoded:
             arr.push_back(<const char*> p)
@@ -1071,6 +1152,27 @@ cdef class GenomeBatch:
         with nogil:
             code = hip.fa_genomes_upload_fasta(mapper._hm, arr.data(), self.n_genomes, &self._hg)
         _check(code)
+        self._finish()
+        return self
+
+    def reload_fasta(self, paths):
+        """Replace the contents of the batch by the genomes of other FASTA files (one per file), recycling its device
+        buffers, pinned staging image and upload stream (``fa_genomes_reload_fasta``)."""
+        cdef vector[const char*] arr
+        cdef int code
+        cdef int32_t n
+        encoded = [os.fsencode(p) for p in paths]
+        for p in encoded:
+            arr.push_back(<const char*> p)
+        n = <int32_t> len(encoded)
+        if arr.empty():
+            arr.push_back(NULL)
+        with nogil:
+            code = hip.fa_genomes_reload_fasta(self._mapper._hm, self._hg, arr.data(), n)
+        if code != 0:
+            self.n_genomes = 0
+        _check(code)
+        self.n_genomes = n
         self._finish()
         return self
 

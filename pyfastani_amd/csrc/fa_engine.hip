@@ -356,6 +356,10 @@ struct fa_genomes {
   int64_t F = 0, ntiles = 0;
   uint64_t total_bases = 0;                 // bases inside fragments
   std::vector<unsigned char> host_image;    // staging image when no pinned buffer is supplied
+  PinnedBuf pin_image;                      // staging image of a batch that is refilled (fa_genomes_reload_fasta)
+  hipStream_t up_stream = nullptr;          // FASTA uploads run on the batch's own stream
+  ~fa_genomes() { if (up_stream) (void)hipStreamDestroy(up_stream); }
+  fa_genomes() = default;
   uint64_t serial = 0;                      // a new number for every upload (caches keyed on a batch compare this, not its address)
 };
 static std::atomic<uint64_t> g_batch_serial{0};
@@ -1038,7 +1042,10 @@ struct QueryPass {
     uint32_t order_len = 0;
     Part(QueryPass &q, Run &r)
         : ln(*q.lanes[r.lane]), st(ln.stream), sp(r.sp), f0(r.f0), f1(r.f1), F(r.f1 - r.f0), t0(q.g.frag_tile_lo[r.f0]),
-          ntiles(q.g.frag_tile_lo[r.f1] - q.g.frag_tile_lo[r.f0]), smax(r.sp.smax), l_cap(r.sp.l_cap) {}
+          ntiles(q.g.frag_tile_lo[r.f1] - q.g.frag_tile_lo[r.f0]), smax(r.sp.smax),
+          // (every region of the locus numbering holds at least one locus: a capacity below the number of regions -- only the
+          //  FA_LOCI_CAP_MIN hook of the tests gets there -- would number loci beyond the arrays sized and cleared for l_cap)
+          l_cap(std::max<int64_t>(r.sp.l_cap, (int64_t)std::min<uint32_t>(LOCI_REGIONS, ev_regions_for(r.f1 - r.f0)))) {}
   };
 
   // one part: its buffers, then the stages in order, then the hand-over -- all asynchronous on the lane's stream
@@ -1482,7 +1489,12 @@ struct QueryPass {
       const int64_t need = (int64_t)(loci_region_max * ln.loci_n);
       const int64_t want = std::max<int64_t>(sp.l_cap * 2, need * 2);
       const int64_t l_max = (1LL << 31) - 64;
-      if (need > l_max) { shrink_part((double)need, (double)l_max, "candidate loci"); publish_spec(sp); return false; }
+      // a region holds the largest power of two below its share: at the cap that is 2^floor_log2(l_max / n), which the fullest
+      // region must fit -- otherwise the repeat would overflow again at the same capacity, for ever
+      const int64_t region_at_cap = (int64_t)1 << floor_log2((int)std::max<int64_t>(1, l_max / (int64_t)ln.loci_n));
+      if (need > l_max || (want >= l_max && (int64_t)loci_region_max > region_at_cap)) {
+        shrink_part((double)loci_region_max, (double)region_at_cap, "candidate loci"); publish_spec(sp); return false;
+      }
       sp.l_cap = std::min(want, l_max);
     }
     if (flags & SPEC_QFUSE) {
@@ -1658,9 +1670,13 @@ struct WorkspaceLease : Lease<fa_mapper, Workspace> {
 // pack + cut into fragments + tiles + upload.  `reuse` (a batch object whose device buffers are recycled, contents
 // replaced) and `pin` (pinned staging memory the image is built in, so that the one upload is a plain DMA) serve the
 // one-query-at-a-time call; without them the image is built in pageable memory.
-static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
-                                                  const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width,
-                                                  float *host_ms = nullptr, std::unique_ptr<fa_genomes> reuse = nullptr, PinnedBuf *pin = nullptr) {
+// `packed` (fa_genomes_upload_fasta): contig c is record packed[c] of a file that read_fasta_packed has packed already -- its
+// words are copied where `contigs` would be packed; `contigs` is not read then.
+// fill_genomes works in place (fa_genomes_reload_fasta: a batch object whose device buffers, pinned image and upload stream are
+// recycled from chunk to chunk); `sync_pinned`: wait for the upload although the image is pinned (the image is reused next).
+static void fill_genomes(fa_genomes *g, const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
+                         const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width,
+                         float *host_ms, PinnedBuf *pin, const PackedRef *packed, bool sync_pinned) {
   require_device();
   const auto t_begin = std::chrono::steady_clock::now();
   auto lap = [&, last = t_begin](int slot) mutable {
@@ -1669,7 +1685,6 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
     last = now;
   };
   FA_REQUIRE(width == 1 || width == 2 || width == 4, FA_ERR_INVALID, "char_width must be 1, 2 or 4");
-  std::unique_ptr<fa_genomes> g = reuse ? std::move(reuse) : std::unique_ptr<fa_genomes>(new fa_genomes());
   g->P = P;
   g->serial = ++g_batch_serial;
   g->n_genomes = n_genomes;
@@ -1683,13 +1698,17 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   const int64_t min_len = std::min<int64_t>(std::min(P.window_size, P.kmer_size), frag);
   // pass 1: which contigs are mapped, and how many whole fragments each holds -- this fixes every size of the image
   std::vector<const void *> use_ptr;
+  std::vector<PackedRef> use_ref;
   std::vector<int64_t> use_len;
   int64_t F = 0;
   for (int64_t c = 0; c < n_contigs; c++) {
     const int64_t len = lengths[c];
     if (len < min_len) continue;
     const int64_t nfrag = len / frag;
-    if (nfrag > 0) { use_ptr.push_back(contigs[c]); use_len.push_back(nfrag * frag); F += nfrag; }   // the tail past the last whole fragment is never read
+    if (nfrag > 0) {                                                  // the tail past the last whole fragment is never read
+      if (packed) use_ref.push_back(PackedRef{packed[c].file, packed[c].rec, nfrag * frag}); else use_ptr.push_back(contigs[c]);
+      use_len.push_back(nfrag * frag); F += nfrag;
+    }
   }
   const int64_t npos_frag = (int64_t)frag - P.kmer_size + 1;
   const int64_t tiles_per_frag = npos_frag > 0 ? (npos_frag + TILE - 1) / TILE : 0;
@@ -1711,7 +1730,8 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   StageTrace tr("upload_genomes");
   // the slack behind the packed words / bytes (the sketch kernel's funnel shift reads one word past the end)
   if (!hs.protein) memset(img + o_packed + bases / 4, 0, n_packed - bases / 4); else memset(img + o_bytes + bases, 0, n_bytes - bases);
-  hs.pack_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width, (uint32_t *)(img + o_packed), img + o_bytes);
+  if (packed) place_packed(hs, use_ref.data(), (int64_t)use_ref.size(), (uint32_t *)(img + o_packed), img + o_bytes);
+  else hs.pack_many(use_ptr.data(), use_len.data(), (int64_t)use_ptr.size(), width, (uint32_t *)(img + o_packed), img + o_bytes);
   tr.mark("pack", st);
   lap(0);
   // pass 2: fragments, tiles and per-genome bookkeeping, in contig order, written straight into the image
@@ -1773,13 +1793,38 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
   // are asynchronous).  An image in the caller's pinned block (the one-query call: the block belongs to the workspace and
   // is not touched again before the call returns, and the pass runs on this same stream, behind the copy) needs no
   // synchronisation; otherwise one per upload
-  if (!pin) {
+  if (!pin || sync_pinned) {
     FA_HIP(hipStreamSynchronize(st));
     std::vector<unsigned char>().swap(g->host_image);
   }
   tr.mark("uploads", st);
   lap(2);
+}
+
+static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_t st, const void *const *contigs, const int64_t *lengths,
+                                                  const int32_t *contig_genome, int64_t n_contigs, int32_t n_genomes, int width,
+                                                  float *host_ms = nullptr, std::unique_ptr<fa_genomes> reuse = nullptr, PinnedBuf *pin = nullptr,
+                                                  const PackedRef *packed = nullptr) {
+  std::unique_ptr<fa_genomes> g = reuse ? std::move(reuse) : std::unique_ptr<fa_genomes>(new fa_genomes());
+  fill_genomes(g.get(), P, st, contigs, lengths, contig_genome, n_contigs, n_genomes, width, host_ms, pin, packed, false);
   return g;
+}
+
+// one genome per FASTA file, every file read + packed by its own task of the host pool (read_fasta_packed_many), then the
+// batch image assembled from the packed records and uploaded on the batch's own stream
+static void fill_genomes_from_fasta(fa_mapper *m, fa_genomes *g, const char *const *paths, int32_t n_paths, bool pinned) {
+  std::vector<PackedFasta> files;
+  read_fasta_packed_many(paths, (size_t)n_paths, m->P.alphabet_size != 4, files);
+  std::vector<PackedRef> refs;
+  std::vector<int64_t> lens;
+  std::vector<int32_t> genome;
+  for (int32_t i = 0; i < n_paths; i++)
+    for (size_t r = 0; r < files[i].rec_len.size(); r++) { refs.push_back(PackedRef{&files[i], (int64_t)r, files[i].rec_len[r]}); lens.push_back(files[i].rec_len[r]); genome.push_back(i); }
+  bind_device(m->device);
+  // (its own stream: a batch may be uploaded while another thread maps the previous one, Mapper.query_fasta_stream)
+  if (!g->up_stream) FA_HIP(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
+  fill_genomes(g, m->P, g->up_stream, nullptr, lens.data(), genome.data(), (int64_t)refs.size(), n_paths, 1, nullptr,
+               pinned ? &g->pin_image : nullptr, refs.data(), true);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1933,6 +1978,54 @@ int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int6
     s->seqs_by_file.push_back((int32_t)s->counter);      // :690
     if (n_records) *n_records = (int64_t)seqs.size();
     if (n_short) *n_short = shorts;
+  });
+}
+// Many reference genomes at once, one per FASTA file, in the order given: the files are read and packed concurrently (one
+// task per file), then appended to the pending store exactly as fa_sketch_add_fasta would have added them one by one.
+int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_paths, int64_t *n_records, int64_t *n_short) {
+  return guarded([&] {
+    FA_REQUIRE(paths && n_paths >= 0, FA_ERR_INVALID, "null paths or negative count");
+    std::vector<PackedFasta> files;
+    read_fasta_packed_many(paths, (size_t)n_paths, s->P.alphabet_size != 4, files);
+    std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
+    // staged in locals, committed after the store has taken the records (as fa_sketch_add_fasta)
+    std::vector<PackedRef> refs;
+    std::vector<int32_t> contig_ids;
+    std::vector<uint64_t> lengths;
+    std::vector<int32_t> by_file;
+    std::vector<int64_t> shorts((size_t)n_paths, 0);
+    int64_t counter = s->counter;
+    FA_REQUIRE(s->cur_total == 0 || n_paths == 0, FA_ERR_INVALID, "a genome is still open (add_contig without end_genome)");
+    for (int32_t i = 0; i < n_paths; i++) {
+      uint64_t total = 0;
+      for (size_t r = 0; r < files[i].rec_len.size(); r++) {
+        const int64_t length = files[i].rec_len[r];
+        FA_REQUIRE(length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
+        if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
+          refs.push_back(PackedRef{&files[i], (int64_t)r, length});
+          contig_ids.push_back((int32_t)counter);
+        } else {
+          shorts[i]++;
+        }
+        total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
+        counter += 1;                                                                // :683
+      }
+      lengths.push_back(total);                            // :687
+      by_file.push_back((int32_t)counter);                 // :690
+    }
+    s->pending_contig.reserve(s->pending_contig.size() + contig_ids.size());
+    s->lengths.reserve(s->lengths.size() + lengths.size());
+    s->seqs_by_file.reserve(s->seqs_by_file.size() + by_file.size());
+    if (!refs.empty()) append_packed(s->pending, refs.data(), (int64_t)refs.size());
+    s->pending_contig.insert(s->pending_contig.end(), contig_ids.begin(), contig_ids.end());
+    s->counter = counter;
+    s->lengths.insert(s->lengths.end(), lengths.begin(), lengths.end());
+    s->seqs_by_file.insert(s->seqs_by_file.end(), by_file.begin(), by_file.end());
+    for (int32_t i = 0; i < n_paths; i++) {
+      if (n_records) n_records[i] = (int64_t)files[i].rec_len.size();
+      if (n_short) n_short[i] = shorts[i];
+    }
   });
 }
 int fa_sketch_end_genome(fa_sketch *s) {
@@ -2181,17 +2274,21 @@ int fa_genomes_upload(fa_mapper *m, const void *const *contigs, const int64_t *l
 int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_paths, fa_genomes **out) {
   return guarded([&] {
     FA_REQUIRE(n_paths >= 0, FA_ERR_INVALID, "negative count");
-    std::vector<std::vector<FastaSeq>> files((size_t)n_paths);
-    std::vector<const void *> ptrs;
-    std::vector<int64_t> lens;
-    std::vector<int32_t> genome;
-    for (int32_t i = 0; i < n_paths; i++) {
-      read_fasta_records(paths[i], files[i]);
-      for (auto &q : files[i]) { ptrs.push_back(q.data.get()); lens.push_back((int64_t)q.size); genome.push_back(i); }
+    std::unique_ptr<fa_genomes> g(new fa_genomes());
+    fill_genomes_from_fasta(m, g.get(), paths, n_paths, false);
+    *out = g.release();
+  });
+}
+int fa_genomes_reload_fasta(fa_mapper *m, fa_genomes *g, const char *const *paths, int32_t n_paths) {
+  return guarded([&] {
+    FA_REQUIRE(g && n_paths >= 0, FA_ERR_INVALID, "null batch or negative count");
+    try {
+      fill_genomes_from_fasta(m, g, paths, n_paths, true);
+    } catch (...) {
+      g->n_genomes = 0; g->F = 0; g->ntiles = 0;                      // a failed refill leaves an empty (but valid) batch
+      g->genome_frag_lo.assign(1, 0); g->total_fragments.clear(); g->total_length.clear(); g->n_short.clear();
+      throw;
     }
-    std::lock_guard<std::mutex> lock(m->mtx);
-    bind_device(m->device);
-    *out = upload_genomes(m->P, m->stream, ptrs.data(), lens.data(), genome.data(), (int64_t)ptrs.size(), n_paths, 1).release();
   });
 }
 void fa_genomes_free(fa_genomes *g) { delete g; }

@@ -16,6 +16,8 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <utility>
+#include <vector>
 
 #include "fa_error.h"
 
@@ -48,12 +50,18 @@ static const uint8_t kCodeOf[256] = {
 #undef X4
 };
 
-// host threads used for packing (FA_HOST_THREADS overrides; default = hardware concurrency, at most 128)
+// host threads used for packing (FA_HOST_THREADS overrides; default = hardware concurrency, at most 128, divided by the ranks
+// of this node when the process is one of several -- LOCAL_WORLD_SIZE, set by torch.distributed.run: eight ranks of a node
+// with 256 hardware threads start 32 packer threads each, not 8 x 128)
 inline int host_threads() {
   static const int v = [] {
     const char *e = getenv("FA_HOST_THREADS");
     int x = e ? atoi(e) : 0;
-    if (x <= 0) x = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 128u);
+    if (x <= 0) {
+      const char *lw = getenv("LOCAL_WORLD_SIZE");
+      const unsigned ranks = (unsigned)std::max(1, lw ? atoi(lw) : 1);
+      x = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency() / ranks), 128u);
+    }
     return x;
   }();
   return v;
@@ -159,11 +167,23 @@ inline bool host_has_avx2() {
   return v;
 }
 
+// std::vector whose resize(n) leaves new elements uninitialised: the packers write every word of what they append, and the
+// zero fill of a 250 MB store by ONE thread (plus its page faults) took longer than reading and packing 200 genomes on all of
+// them (scripts/ubench/ingest_host.cpp: 40 of 57 ms); the pages are now first touched by the pool's threads
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U> &) {}
+  template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+  template <class U, class... A> void construct(U *p, A &&...a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+
 // Host image of a sequence store, appended to contig by contig and uploaded in one go.
 struct HostStore {
   bool protein = false;
-  std::vector<uint32_t> packed;   // nucleotide
-  std::vector<uint8_t> bytes;     // protein
+  std::vector<uint32_t, NoInitAlloc<uint32_t>> packed;   // nucleotide
+  std::vector<uint8_t, NoInitAlloc<uint8_t>> bytes;      // protein
   std::vector<int64_t> exc_pos;
   std::vector<uint8_t> exc_val;
   std::vector<int64_t> seq_off;   // store offset of each sequence
@@ -204,11 +224,11 @@ struct HostStore {
     try {
       if (protein) {
         grow(bytes, o_bytes + add);
-        bytes.resize(o_bytes + add, 0);
+        bytes.resize(o_bytes + add);                                  // (uninitialised: pack_many writes every byte / word)
         pack_many(datas, lens, n, width, nullptr, bytes.data() + o_bytes);
       } else {
         grow(packed, o_packed + add / 16);
-        packed.resize(o_packed + add / 16, 0u);
+        packed.resize(o_packed + add / 16);
         pack_many(datas, lens, n, width, packed.data() + o_packed, nullptr);
       }
     } catch (...) {

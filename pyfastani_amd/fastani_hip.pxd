@@ -67,6 +67,7 @@ cdef extern from "fastani_hip.h" nogil:
                                    int64_t counter, int64_t n_minimizers, const uint32_t* d_hash, const int32_t* d_seq_id,
                                    const int32_t* d_wpos)
     int fa_sketch_add_fasta(fa_sketch* s, const char* path, int64_t* n_records, int64_t* n_short)   # _fasta.pyx:41-103 + :610-690
+    int fa_sketch_add_fasta_many(fa_sketch* s, const char* const* paths, int32_t n_paths, int64_t* n_records, int64_t* n_short)
     int fa_sketch_index(fa_sketch* s, fa_mapper** out)                                        # :790-791 (+ ownership move :793-806)
 
     # Sketch_t after index() + skch::Map
@@ -91,6 +92,7 @@ cdef extern from "fastani_hip.h" nogil:
     int fa_genomes_upload(fa_mapper* m, const void* const* contigs, const int64_t* lengths, const int32_t* contig_genome,
                           int64_t n_contigs, int32_t n_genomes, int char_width, fa_genomes** out)
     int fa_genomes_upload_fasta(fa_mapper* m, const char* const* paths, int32_t n_paths, fa_genomes** out)
+    int fa_genomes_reload_fasta(fa_mapper* m, fa_genomes* g, const char* const* paths, int32_t n_paths)
     void fa_genomes_free(fa_genomes* g)
     int fa_genomes_info(fa_genomes* g, int32_t* n_genomes, uint64_t* total_fragments, uint64_t* total_length, int32_t* n_short)
     int fa_mapper_query_genomes(fa_mapper* m, fa_genomes* g, int32_t first, int32_t count, fa_cgi_row* rows, int64_t cap,

@@ -11,6 +11,7 @@ runtime in a process that uses both: import torch BEFORE the first pyfastani_amd
 tests do) -- torch's bundled runtime is then the one ``libfastani_hip.so`` binds to, and torch does not have to register
 its kernels with a runtime that is already live (which works but takes 10 s to minutes).
 """
+import collections
 import numpy as np
 
 from ._batch import ROW_DTYPE
@@ -123,7 +124,9 @@ class ResidentHitTable:
         self.owned = torch.as_tensor(np.asarray(owned, dtype=np.int64), device=self.table_device)
         self.out = (torch.empty((self.world * (self.max_rows + 1), 5), dtype=torch.int32, device=self.comm_device)
                     if self.world > 1 else None)
-        self.exchange_marks = []                  # per step: a pair of CUDA events (device collective) or seconds (host collective)
+        # per step: a pair of CUDA events (device collective) or seconds (host collective); bounded -- a service loop that steps
+        # for ever keeps the marks of its latest 256 steps, not one pair of event objects per step
+        self.exchange_marks = collections.deque(maxlen=256)
         self._sync()
 
     def _sync(self):
@@ -163,9 +166,11 @@ class ResidentHitTable:
         return self.out.view(self.world, self.max_rows + 1, 5)
 
     def exchange_ms(self, last=None):
-        """Mean duration of the all-gather over the last ``last`` steps (all, if None), in ms; 0.0 at world size 1.
-        Call it after the steps are done: it synchronises."""
-        marks = self.exchange_marks[-last:] if last else self.exchange_marks
+        """Mean duration of the all-gather over the last ``last`` steps (all that are kept -- 256 at most -- if None), in
+        ms; 0.0 at world size 1.  Call it after the steps are done: it synchronises.  The first mark of a step is recorded
+        behind the id translation and in front of the collective, so the figure INCLUDES the wait for the slowest rank to
+        arrive at the collective (rank skew), not only the transfer."""
+        marks = list(self.exchange_marks)[-last:] if last else list(self.exchange_marks)
         if not marks:
             return 0.0
         self._sync()

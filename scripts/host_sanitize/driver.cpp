@@ -44,6 +44,7 @@ static void plain_append(Plain &p, bool protein, const std::vector<uint32_t> &se
   p.total += padded;
 }
 
+template <class A, class B> static bool same_vec(const A &a, const B &b) { return a.size() == b.size() && std::equal(a.begin(), a.end(), b.begin()); }
 template <class T> static std::vector<T> widen(const std::vector<uint32_t> &s) { return std::vector<T>(s.begin(), s.end()); }
 
 static std::vector<std::vector<uint32_t>> edge_sequences(std::mt19937_64 &rng) {
@@ -88,9 +89,9 @@ static void test_packer(bool protein, int width, int clients) {
     for (size_t i = seqs.size() / 2; i < seqs.size(); i++) plain_append(want, protein, seqs[i]);
     CHECK(hs.total == want.total, "client %d: store length %lld vs %lld", id, (long long)hs.total, (long long)want.total);
     CHECK(hs.seq_off == want.off, "client %d: sequence offsets differ", id);
-    if (protein) CHECK(hs.bytes == want.bytes, "client %d: protein bytes differ", id);
+    if (protein) CHECK(same_vec(hs.bytes, want.bytes), "client %d: protein bytes differ", id);
     else {
-      CHECK(hs.packed == want.packed, "client %d: packed words differ (width %d)", id, width);
+      CHECK(same_vec(hs.packed, want.packed), "client %d: packed words differ (width %d)", id, width);
       CHECK(hs.exc_pos == want.epos && hs.exc_val == want.eval, "client %d: exception lists differ (%zu vs %zu)", id, hs.exc_pos.size(), want.epos.size());
     }
     // pack_many into caller memory that is exactly as large as promised (ASan guards its ends)
@@ -166,6 +167,82 @@ static void test_fasta(int clients) {
   for (auto &t : th) t.join();
 }
 
+// read_fasta_packed (one sweep from file bytes to 2-bit words) and place_packed against the definition: the records of
+// FastaFile, packed byte by byte; whole records and prefixes (a query batch holds whole fragments only); many files at once
+static void test_fasta_packed(bool protein) {
+  std::mt19937_64 rng(protein ? 77 : 78);
+  std::vector<std::string> texts = {
+    "", "ACGT\n>x\nAC\n", ">id one\nACgt\nNNac\n", ">a\nAC\n>b\nGT", ">a\n>b\n\nAC\n\n>c\n", ">a\nAC>GT\nTT\n", ">crlf\r\nACGT\r\nAC\r\n",
+    ">x\n" + std::string(31, 'A') + "\n" + std::string(32, 'C') + "\n" + std::string(33, 'G') + "\n" + std::string(64, 'T') + "\n" + std::string(65, 'a') + "\nN",
+  };
+  const char alpha[] = "ACGTACGTACGTACGTacgtNnRYKM*";
+  for (int t = 0; t < 40; t++) {                                   // random files: 1-6 records, line widths 1-100, rare exceptions
+    std::string text;
+    const int nrec = 1 + (int)(rng() % 6);
+    for (int r = 0; r < nrec; r++) {
+      text += ">rec" + std::to_string(r) + " some description\n";
+      const size_t len = (rng() % 5 == 0) ? rng() % 70 : rng() % 20000;
+      const size_t width = 1 + rng() % 100;
+      const bool dirty = rng() % 3 == 0;
+      for (size_t i = 0; i < len; i++) {
+        text += dirty && rng() % 50 == 0 ? alpha[rng() % (sizeof(alpha) - 1)] : "ACGT"[rng() % 4];
+        if ((i + 1) % width == 0) text += '\n';
+      }
+      if (rng() % 4) text += '\n';
+      if (rng() % 8 == 0) text += "\n\n";
+    }
+    texts.push_back(text);
+  }
+  std::vector<std::string> paths;
+  for (size_t i = 0; i < texts.size(); i++) paths.push_back(write_tmp("packed_" + std::to_string(i) + ".fa", texts[i]));
+  std::vector<const char *> cpaths;
+  for (auto &p : paths) cpaths.push_back(p.c_str());
+  std::vector<PackedFasta> files;
+  read_fasta_packed_many(cpaths.data(), cpaths.size(), protein, files);
+  HostStore whole, part;
+  whole.protein = part.protein = protein;
+  Plain want_whole, want_part;
+  std::vector<PackedRef> refs_whole, refs_part;
+  for (size_t i = 0; i < texts.size(); i++) {
+    FastaFile f; f.open(paths[i].c_str());
+    size_t r = 0;
+    while (f.next()) {
+      CHECK(r < files[i].rec_len.size() && files[i].rec_len[r] == (int64_t)f.seq.size(), "file %zu record %zu: %lld bases vs %zu", i, r,
+            r < files[i].rec_len.size() ? (long long)files[i].rec_len[r] : -1LL, f.seq.size());
+      if (r >= files[i].rec_len.size()) break;
+      std::vector<uint32_t> seq(f.seq.begin(), f.seq.end());
+      plain_append(want_whole, protein, seq);
+      refs_whole.push_back(PackedRef{&files[i], (int64_t)r, (int64_t)seq.size()});
+      const int64_t cut = seq.empty() ? 0 : (int64_t)(rng() % (seq.size() + 1));
+      seq.resize((size_t)cut);
+      plain_append(want_part, protein, seq);
+      refs_part.push_back(PackedRef{&files[i], (int64_t)r, cut});
+      r++;
+    }
+    CHECK(r == files[i].rec_len.size(), "file %zu: %zu records vs %zu", i, files[i].rec_len.size(), r);
+  }
+  append_packed(whole, refs_whole.data(), (int64_t)refs_whole.size());
+  append_packed(part, refs_part.data(), (int64_t)refs_part.size());
+  auto same = [&](const HostStore &hs, const Plain &w, const char *what) {
+    CHECK(hs.total == w.total, "%s: total %lld vs %lld", what, (long long)hs.total, (long long)w.total);
+    CHECK(hs.seq_off == w.off, "%s: sequence offsets differ", what);
+    if (protein) CHECK(same_vec(hs.bytes, w.bytes), "%s: bytes differ", what); else CHECK(same_vec(hs.packed, w.packed), "%s: packed words differ", what);
+    CHECK(hs.exc_pos == w.epos && hs.exc_val == w.eval, "%s: exceptions differ (%zu vs %zu)", what, hs.exc_pos.size(), w.epos.size());
+  };
+  same(whole, want_whole, protein ? "packed fasta, protein, whole records" : "packed fasta, whole records");
+  same(part, want_part, protein ? "packed fasta, protein, prefixes" : "packed fasta, prefixes");
+  bool threw = false;
+  const std::string longid = write_tmp("packed_longid.fa", ">" + std::string(3000, 'x') + "\nAC\n");
+  try { PackedFasta pf; read_fasta_packed(longid.c_str(), protein, pf); } catch (const Error &e) { threw = e.code == FA_ERR_BUFFER; }
+  CHECK(threw, "over-long identifier should fail with FA_ERR_BUFFER in the packed reader");
+  threw = false;
+  const char *missing[2] = {paths[2].c_str(), "/nonexistent/fa.fa"};
+  try { std::vector<PackedFasta> v; read_fasta_packed_many(missing, 2, protein, v); } catch (const Error &e) { threw = e.code == FA_ERR_IO; }
+  CHECK(threw, "a missing file among many should fail with FA_ERR_IO");
+  unlink(longid.c_str());
+  for (auto &p : paths) unlink(p.c_str());
+}
+
 static void test_stats() {
   CHECK(stat_recommended_window(1e-3, 16, 4, 80.0f, 3000, 5000000ULL) == 24, "default window is 24 (test_ani.py:60)");
   StatTables t; t.k = 16; t.pid = 80.0f; t.smax = -1;
@@ -224,6 +301,8 @@ int main() {
   test_packer(true, 4, 4);
   test_fasta(1);
   test_fasta(4);
+  test_fasta_packed(false);
+  test_fasta_packed(true);
   test_stats();
   test_lease(8);
   test_spin();

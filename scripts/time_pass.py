@@ -17,11 +17,13 @@ mapper = sk.index()
 batch = mapper.upload_genomes(workloads.config2_query(anc, 0, 1) if nq == 1 else [workloads.config2_query(anc, 100 + i, 1)[0] for i in range(nq)])
 for _ in range(3):
     rows = batch.query_rows(0, nq)
-ph = np.zeros(16)
+ph = np.zeros(24)
 for _ in range(steps):
     rows = batch.query_rows(0, nq)
-    ms = (C.c_float * 16)(); lib.fa_mapper_last_timings(mapper._h, ms, 16)
-    ph += np.array(list(ms)[:16])
+    ms = (C.c_float * 24)(); lib.fa_mapper_last_timings(mapper._h, ms, 24)
+    ph += np.array(list(ms)[:24])
 ph /= steps
+import hashlib
+digest = hashlib.sha256(np.ascontiguousarray(rows).tobytes()).hexdigest()[:16]
 print(json.dumps({"queries": nq, "env": {k: v for k, v in os.environ.items() if k.startswith("FA_")}, "rows": int(len(rows)),
-                  "sketch_ms": ph[0], "lookup_l1_ms": ph[1], "l2_ms": ph[2], "cgi_ms": ph[3], "total_ms": ph[4], "events": ph[7], "smax": ph[14], "fu_c": ph[15]}))
+                  "sketch_ms": ph[0], "lookup_l1_ms": ph[1], "l2_ms": ph[2], "cgi_ms": ph[3], "total_ms": ph[4], "events": ph[7], "smax": ph[14], "loci": ph[6], "rows_sha": digest}))

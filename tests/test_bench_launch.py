@@ -33,7 +33,9 @@ def test_gpus_n_without_world_size_spawns_a_child_launcher(monkeypatch):
         raise AssertionError("main() went on after launching the ranks")
     cmd = seen["cmd"]
     assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
-    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    # the launcher rendezvouses on 127.0.0.1 and lets torchrun bind (and hold) a free port itself
+    assert "--rdzv-backend=c10d" in cmd and "--rdzv-endpoint=127.0.0.1:0" in cmd and "--local-addr=127.0.0.1" in cmd
     assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["cwd"] == ROOT
     assert seen["torch_loaded"] == torch_was_loaded  # the launcher itself imports no torch

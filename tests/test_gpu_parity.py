@@ -1081,6 +1081,38 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         pf.Sketch().add_fasta("x", files[0])                 # the 6-base contig is reported like add_draft does
     with pytest.raises(OSError):
         pf.Sketch().add_fasta("x", str(tmp_path / "missing.fna"))
+    # round 5: every file read + packed by its own host task in ONE sweep (fa_sketch_add_fasta_many), and the streamed form of
+    # the query side (chunks of files into two recycled batches while the previous chunk maps) -- the same records, sketch and hits
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        many = pf.Sketch().add_fasta_many(range(len(files)), files)
+        assert all(np.array_equal(x, y) for x, y in zip(many._read_minimizers(), a))
+        assert many.names == [0, 1, 2]
+        m3 = many.index()
+        for chunk in (1, 2, 5):
+            streamed = {}
+            for first, hits in m3.query_fasta_stream(files * 2, chunk=chunk):
+                for i, h in enumerate(hits):
+                    streamed[first + i] = hit_tuples(h)
+            assert [streamed[i] for i in range(2 * len(files))] == want * 2
+        rows = [r for _, r in m3.query_fasta_stream(files, chunk=2, rows=True)]
+        assert sum(len(r) for r in rows) == 9
+    with pytest.warns(UserWarning):
+        pf.Sketch().add_fasta_many(["x"], files[:1])
+    with pytest.raises(OSError):
+        pf.Sketch().add_fasta_many(["x", "y"], [files[0], str(tmp_path / "missing.fna")])
+    with pytest.raises(OSError):
+        list(m3.query_fasta_stream([files[0], str(tmp_path / "missing.fna")], chunk=1))
+    # a protein file through the packed reader (bytes kept, upper-cased)
+    prot = str(tmp_path / "p.faa")
+    with open(prot, "wb") as f:
+        f.write(b">p1\nMKVlaa\nGG\n>p2\n" + b"ACDEFGHIKLMNPQRSTVWY" * 40 + b"\n")
+    ps, pp = pf.Sketch(protein=True, fragment_length=100), pf.Sketch(protein=True, fragment_length=100)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ps.add_fasta_many(["p"], [prot])
+        pp.add_draft("p", [r.seq for r in Parser(prot)])
+    assert all(np.array_equal(x, y) for x, y in zip(ps._read_minimizers(), pp._read_minimizers()))
 
 
 def test_fastani_style_outputs_from_device_rows(tmp_path):
