@@ -67,6 +67,7 @@ def parse_args():
     ap.add_argument("--no-saturated", action="store_true", help="N=1: skip the `saturated` legs (16 queries per launch; config 3 at N=1)")
     ap.add_argument("--saturated-steps", type=int, default=3, help="steps of the config-3 leg of `saturated` (its batch-16 leg runs 10)")
     ap.add_argument("--no-config45", action="store_true", help="N=1: skip BASELINE configs 4 (500 drafts all-vs-all) and 5 (nine (k, fragment_length) cells)")
+    ap.add_argument("--no-fasta-leg", action="store_true", help="N=1: skip the files-to-table leg of config 3 (`saturated.config3.fasta_to_table`)")
     ap.add_argument("--config4", type=str, default="10x50", help="families x members of the config-4 leg (tests shrink it)")
     ap.add_argument("--config5", type=str, default="10x20", help="families x members of the config-5 leg (tests shrink it)")
     return ap.parse_args()
@@ -113,7 +114,13 @@ def main():
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FA_BENCH_FORCE_DIST=1 (started under torch.distributed.run --nproc-per-node=1): the process group is initialised at world
+    # size 1 and every exchange below runs -- through RCCL, on one GPU -- instead of being skipped (tests/test_gpu_rccl.py)
+    force_dist = os.environ.get("FA_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    dist_on = world > 1 or force_dist
+    if force_dist:
+        os.environ["FA_FORCE_DIST"] = "1"                 # (pyfastani_amd.sharding: collectives_on)
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share_gpu:
             dist.init_process_group("gloo")
@@ -125,9 +132,9 @@ def main():
     from pyfastani_amd._lib import lib, check
 
     check(lib.fa_set_device(local_rank))
-    ctx = dict(args=args, rank=rank, world=world, share_gpu=share_gpu, torch=torch, dist=dist)
+    ctx = dict(args=args, rank=rank, world=world, share_gpu=share_gpu, torch=torch, dist=dist, dist_on=dist_on)
     result = strong_scaling(ctx) if args.strong else weak_scaling(ctx)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -135,13 +142,13 @@ def main():
 
 
 def fence(ctx):
-    if ctx["world"] > 1:
+    if ctx["dist_on"]:
         ctx["dist"].barrier()
     ctx["torch"].cuda.synchronize()
 
 
 def max_over_ranks(ctx, seconds):
-    if ctx["world"] == 1:
+    if not ctx["dist_on"]:
         return seconds
     torch, dist = ctx["torch"], ctx["dist"]
     t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if ctx["share_gpu"] else "cuda")
@@ -155,7 +162,7 @@ def build_mapper(ctx, names, refs):
     from pyfastani_amd import sharding
     args, rank, world, share_gpu, torch, dist = (ctx[k] for k in ("args", "rank", "world", "share_gpu", "torch", "dist"))
     mapper, index_mode, t_pack, t_index = None, "single sketch", 0.0, 0.0
-    if world > 1 and not args.replicated_index:
+    if ctx["dist_on"] and not args.replicated_index:
         # every rank packs and sketches references rank, rank+world, ...; the minimizer shards are all-gathered (RCCL) and
         # every rank indexes the merged records -- the same index a single Sketch builds (build_index_sharded votes before
         # its first collective, so a rank-local failure raises on every rank; whatever happens after the exchange, every
@@ -223,7 +230,7 @@ def weak_scaling(ctx):
         return counts[i]
 
     def exchange(k):
-        if world == 1:
+        if not ctx["dist_on"]:
             return table[:k]
         table[:k, 0, 0] = torch.from_numpy(counts[:k]).to(table.device)   # the row counts travel with the rows
         local = table[:k].contiguous()
@@ -251,13 +258,13 @@ def weak_scaling(ctx):
     fence(ctx)
     elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
     # hits of one step over all ranks (every rank holds the whole table now)
-    n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if world > 1 else int(n_last)
+    n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if ctx["dist_on"] else int(n_last)
     phase_ms = stage_log[: args.steps, :5].astype(np.float64).sum(axis=0) / max(args.steps, 1)
     # N > 1: the STRONG leg rides in the same line -- BASELINE config 3 dealt over the N ranks by fragment count, one all-gather of
     # the device-resident hit table per step, digest compared with the table rank 0 computes alone (never `value`: the N = 1
     # point of `value` must be the BENCH line).  Every rank takes part.
     strong = None
-    if world > 1 and not args.no_saturated and args.saturated_steps > 0:
+    if ctx["dist_on"] and not args.no_saturated and args.saturated_steps > 0:
         strong = strong_core(ctx, args.saturated_steps, 1)
     if rank != 0:
         return None
@@ -328,8 +335,8 @@ def weak_scaling(ctx):
                             "note": "the sketch kernel alone over the query's tiles (50 launches, fa_bench_sketch_kernel); in the timed step the same tile body runs inside k_query_fused, in one launch with the per-fragment sort and index lookup",
                             **sketch_extra},
         "phases_ms": phase,
-        "rccl_ranks": dist.get_world_size() if world > 1 else 1,
-        "backend": (dist.get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if share_gpu else " (RCCL over xGMI)")) if world > 1 else "none (one rank)",
+        "rccl_ranks": dist.get_world_size() if ctx["dist_on"] else 1,
+        "backend": (dist.get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if share_gpu else " (RCCL over xGMI)")) if ctx["dist_on"] else "none (one rank)",
     }
     if strong is not None:
         if strong["digest_matches_n1"] is False:
@@ -342,7 +349,7 @@ def weak_scaling(ctx):
             result["boundary_call"] = boundary_call(args, mapper, queries[0], timed_rows[::ROTATE])
         if args.clients > 1:
             result["concurrent_clients"] = concurrent_clients(args, batch, cap_rows, n_pairs_step)
-        if not args.no_saturated and args.batch == 1:
+        if not args.no_saturated and args.batch == 1 and not ctx["dist_on"]:   # (FA_BENCH_FORCE_DIST: config 3 ran as the strong leg)
             result["saturated"] = saturated_legs(ctx, mapper, anc)
             if not args.no_config45:
                 result["saturated"]["config4"] = config4_leg(ctx)
@@ -750,15 +757,22 @@ def strong_core(ctx, steps, warmup):
     # ---- N > 1: the table every rank holds now must be the table ONE rank computes.  Rank 0 maps all genomes against its
     #      replica (outside the timed region, no collective) and the digests are compared; the other ranks wait at the fence. ----
     n1_digest = None
-    if world > 1 and rank == 0:
+    if ctx["dist_on"] and rank == 0:
         everything = mapper.upload_genomes(genomes)
-        alone = sharding.ResidentHitTable(list(range(n)), n * n, 1)
+        alone = sharding.ResidentHitTable(list(range(n)), n * n, 1, collective=False)
         n1_digest = _sha256_rows(sharding.ResidentHitTable.rows_of(alone.step(everything)))
         del everything, alone
     fence(ctx)
     if rank != 0:
         return None
     rows = sharding.ResidentHitTable.rows_of(tables)          # (outside the timed region: the table stays in HBM inside it)
+    from_files = None
+    if world == 1 and not ctx["dist_on"] and not args.no_fasta_leg:
+        del batch, exchange, tables
+        from_files = fasta_to_table_leg(ctx, genomes)
+        if from_files["table_sha256"] != _sha256_rows(rows):
+            raise SystemExit(f"FASTA-TO-TABLE FAILURE: the table built from files ({from_files['table_sha256']}) differs from the table of the "
+                             f"resident genomes ({_sha256_rows(rows)})")
     phase /= max(steps, 1)
     self_rows = rows[rows["query_id"] == rows["ref_genome_id"]]
     full = args.families == 20 and args.members == 50 and args.length == 5_000_000 and world == 1
@@ -768,7 +782,7 @@ def strong_core(ctx, steps, warmup):
         "value": n * n * steps / elapsed, "unit": "pairs/s", "steps": steps, "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3,
         "us_per_pair": elapsed / steps / (n * n) * 1e6,
         "pairs_per_step": n * n, "rows_per_step": int(len(rows)), "parallelism": f"queries sharded by fragment count x{world}, index replicated",
-        "exchange": "rows written into a preallocated HBM table by the pass kernels, query ids remapped on the device, one all_gather_into_tensor per step" if world > 1
+        "exchange": "rows written into a preallocated HBM table by the pass kernels, query ids remapped on the device, one all_gather_into_tensor per step" if ctx["dist_on"]
                     else "rows written into a preallocated HBM table by the pass kernels (N = 1: no collective)",
         "fragments_per_rank": [int(sum(weights[i] for i in o)) for o in deal],
         "phases_ms_rank0": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase])),
@@ -782,7 +796,71 @@ def strong_core(ctx, steps, warmup):
         "exchange_ms": exchange_ms, "exchange_bytes_per_rank": int((max_rows + 1) * 20),
         "table_sha256_n1": n1_digest, "digest_matches_n1": (None if n1_digest is None else bool(n1_digest == _sha256_rows(rows))),
         "table_sha256_committed_n1": COMMITTED_CONFIG3_DIGEST if (args.families, args.members, args.length) == (20, 50, 5_000_000) else None,
+        **({"fasta_to_table": from_files} if from_files is not None else {}),
     }
+
+
+def fasta_to_table_leg(ctx, genomes, chunk=24):
+    """From FASTA FILES to the hit table in HBM: what a user of the reference's benchmark loop starts from
+    (benches/mapping/bench.py:41-53 reads its genomes with the FASTA parser before it maps).  The genomes of the workload are
+    written to /dev/shm as 60-column FASTA (untimed); timed: `Sketch.add_fasta_many` (every file read + 2-bit packed by its
+    own host task, one sweep) -> `index()` -> `Mapper.query_fasta_stream` (chunks of files read, packed and uploaded into two
+    recycled batches by a second host thread WHILE the previous chunk maps; rows land in a preallocated HBM table).
+    host_s = the ingest work (references + query chunks), device_s = index build + the passes' device time;
+    `overlap` = wall / max(host_s, device_s): 1.0 would be a perfect overlap of the two sides."""
+    import shutil
+    import tempfile
+    import warnings
+    import pyfastani_amd as pf
+    from pyfastani_amd import workloads
+    from pyfastani_amd._batch import ROW_DTYPE
+    from pyfastani_amd._lib import lib
+    torch = ctx["torch"]
+    n = len(genomes)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    tmp = tempfile.mkdtemp(prefix="fa_bench_fasta_", dir=base)
+    try:
+        t0 = time.time()
+        paths, nbytes = workloads.write_fasta_set(tmp, genomes)
+        t_write = time.time() - t0
+        table = torch.zeros((n * n + 1, 5), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        ms = (C.c_float * 16)()
+        stats, spans, dev_ms = {}, [], 0.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            sk = pf.Sketch()
+            sk.add_fasta_many(list(range(n)), paths)
+            t_refs = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            mapper = sk.index()
+            t_index = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            for first, (off, cnt) in mapper.query_fasta_stream(paths, chunk=chunk, device_ptr=table.data_ptr(), device_cap=n * n, stats=stats):
+                if cnt:
+                    table[off: off + cnt, 0] += first              # chunk-local -> global query ids, on the device
+                lib.fa_mapper_last_timings(mapper._h, ms, 16)
+                dev_ms += float(ms[4])
+                spans.append((off, cnt))
+            torch.cuda.synchronize()
+            t_stream = time.perf_counter() - t1
+            wall = time.perf_counter() - t0
+        n_rows = sum(c for _, c in spans)
+        rows = table[:n_rows].cpu().numpy().reshape(-1).view(ROW_DTYPE)
+        host_s = t_refs + stats["ingest_s"]
+        device_s = t_index + dev_ms * 1e-3
+        return {
+            "workload": f"{n} FASTA files ({nbytes / 1e9:.2f} GB, 60-column lines) in {tmp.rsplit('/', 1)[0]}: references AND queries are read from the files",
+            "wall_s": wall, "pairs_per_s": n * n / wall, "rows": int(n_rows), "table_sha256": _sha256_rows(rows),
+            "ingest_refs_s": t_refs, "ingest_refs_GBps": nbytes / t_refs / 1e9, "index_s": t_index, "stream_s": t_stream,
+            "stream_ingest_s": stats["ingest_s"], "stream_ingest_GBps": nbytes / max(stats["ingest_s"], 1e-9) / 1e9,
+            "stream_map_s": stats["map_s"], "stream_wait_s": stats["wait_s"], "chunks": stats["chunks"], "chunk_files": chunk,
+            "device_pass_s": dev_ms * 1e-3, "host_s": host_s, "device_s": device_s, "overlap": wall / max(host_s, device_s),
+            "ingest_GBps": 2 * nbytes / host_s / 1e9, "write_files_s": t_write, "host_threads": os.cpu_count(),
+        }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _sha256_rows(rows):
@@ -810,8 +888,9 @@ def strong_scaling(ctx):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": config, "roofline": r["roofline"], "phases_ms": r["phases_ms_rank0"],
         "repeated_attempts_per_step": r["repeated_attempts_per_step"],
-        "rccl_ranks": ctx["dist"].get_world_size() if world > 1 else 1,
-        "backend": (ctx["dist"].get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if ctx["share_gpu"] else " (RCCL over xGMI)")) if world > 1 else "none (one rank)",
+        **({"fasta_to_table": r["fasta_to_table"]} if "fasta_to_table" in r else {}),
+        "rccl_ranks": ctx["dist"].get_world_size() if ctx["dist_on"] else 1,
+        "backend": (ctx["dist"].get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if ctx["share_gpu"] else " (RCCL over xGMI)")) if ctx["dist_on"] else "none (one rank)",
     }
 
 

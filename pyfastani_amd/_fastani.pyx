@@ -1005,21 +1005,33 @@ cdef class Mapper(_Parameterized):
         """`query_draft` for a genome stored as a FASTA file (its records are the contigs)."""
         return self.upload_fasta([path]).query()[0]
 
-    def query_fasta_stream(self, paths, int chunk=24, rows=False):
+    def query_fasta_stream(self, paths, int chunk=24, rows=False, uintptr_t device_ptr=0, int64_t device_cap=0, stats=None):
         """Map the genomes stored in `paths` (one FASTA file each) in chunks of `chunk` files, yielding ``(first, result)``
         per chunk -- ``result`` is one hit list per genome, or the raw row array with ``rows=True`` (``query_id`` counts
-        from 0 inside the chunk).  While chunk c is mapped on the device, a second host thread reads, packs and uploads chunk
-        c + 1 into the other of two recycled batches (``fa_genomes_reload_fasta``: its own stream, a pinned staging image),
-        so the file-to-hits path is bound by the slower of the two sides, not by their sum."""
+        from 0 inside the chunk).  With ``device_ptr`` / ``device_cap`` (a caller-owned HBM table of 20-byte rows, e.g. a
+        torch tensor) the rows never leave the device: chunk after chunk is written behind the rows of the chunks before it
+        and ``result`` is ``(row offset, row count)``.
+
+        While chunk c is mapped on the device, a second host thread reads, packs and uploads chunk c + 1 into the other of
+        two recycled batches (``fa_genomes_reload_fasta``: its own stream, a pinned staging image), so the file-to-hits path
+        is bound by the slower of the two sides, not by their sum.  ``stats`` (a dict) receives ``ingest_s`` (read + pack +
+        upload, summed over the chunks, on the loader thread), ``map_s`` (the mapping calls) and ``wait_s`` (the consumer
+        waiting for a chunk): the overlap is what ``ingest_s + map_s`` exceeds the wall clock by."""
         import queue
         import threading
+        import time
         paths = list(paths)
-        chunks = [paths[i:i + chunk] for i in range(0, len(paths), max(1, chunk))]
+        chunk = max(1, chunk)
+        chunks = [paths[i:i + chunk] for i in range(0, len(paths), chunk)]
+        if stats is None:
+            stats = {}
+        stats.update(ingest_s=0.0, map_s=0.0, wait_s=0.0, chunks=len(chunks))
         if not chunks:
             return
         free = queue.Queue()
-        ready = queue.Queue(maxsize=2)
+        ready = queue.Queue()
         cdef GenomeBatch b
+        cdef int64_t written = 0, n_rows
         for _ in range(2):
             free.put(None)
 
@@ -1027,10 +1039,14 @@ cdef class Mapper(_Parameterized):
             try:
                 for i, c in enumerate(chunks):
                     slot = free.get()
+                    if slot is False:                     # the consumer gave up
+                        return
+                    t0 = time.perf_counter()
                     if slot is None:
                         slot = GenomeBatch.from_fasta(self, c, True)
                     else:
                         slot.reload_fasta(c)
+                    stats["ingest_s"] += time.perf_counter() - t0
                     ready.put((i, slot))
             except BaseException as exc:  # handed to the consumer
                 ready.put((-1, exc))
@@ -1039,13 +1055,24 @@ cdef class Mapper(_Parameterized):
         t.start()
         try:
             for _ in range(len(chunks)):
+                t0 = time.perf_counter()
                 i, slot = ready.get()
+                stats["wait_s"] += time.perf_counter() - t0
                 if i < 0:
                     raise slot
                 b = slot
-                yield i * chunk, (b.query_rows(0, b.n_genomes) if rows else b.query(0, b.n_genomes))
+                t0 = time.perf_counter()
+                if device_ptr:
+                    n_rows = b.query_rows_device(0, b.n_genomes, device_ptr + 20 * written, device_cap - written)
+                    result = (written, n_rows)
+                    written += n_rows
+                else:
+                    result = b.query_rows(0, b.n_genomes) if rows else b.query(0, b.n_genomes)
+                stats["map_s"] += time.perf_counter() - t0
                 free.put(slot)
+                yield i * chunk, result
         finally:
+            free.put(False); free.put(False)
             t.join(timeout=60)
 
     def query_batch(self, batch, first=0, count=None):

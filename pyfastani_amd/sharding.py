@@ -12,9 +12,24 @@ tests do) -- torch's bundled runtime is then the one ``libfastani_hip.so`` binds
 its kernels with a runtime that is already live (which works but takes 10 s to minutes).
 """
 import collections
+import os
+
 import numpy as np
 
 from ._batch import ROW_DTYPE
+
+
+def collectives_on(world_size):
+    """Whether the exchanges run.  Always for more than one rank; at world size 1 only with ``FA_FORCE_DIST=1`` and an
+    initialised process group -- a one-rank all-gather is a copy, but it is RCCL (backend ``nccl``) that makes it, so a
+    1-GPU box can push every collective of this module through the library the 8-GPU run will use
+    (tests/test_gpu_rccl.py::test_every_collective_through_rccl_at_world_size_one)."""
+    if world_size > 1:
+        return True
+    if os.environ.get("FA_FORCE_DIST") != "1":
+        return False
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_indices(n_items, rank, world_size):
@@ -114,7 +129,7 @@ class ResidentHitTable:
     GPU between the ranks) the local table is copied to the host for the collective and nothing else changes.
     """
 
-    def __init__(self, owned, max_rows, world_size, comm_device="cuda", group=None, table_device="cuda"):
+    def __init__(self, owned, max_rows, world_size, comm_device="cuda", group=None, table_device="cuda", collective=None):
         import torch
         self.torch, self.world, self.group, self.max_rows = torch, int(world_size), group, int(max_rows)
         self.n_owned = len(owned)
@@ -123,7 +138,7 @@ class ResidentHitTable:
         self.local = torch.zeros((self.max_rows + 1, 5), dtype=torch.int32, device=self.table_device)
         self.owned = torch.as_tensor(np.asarray(owned, dtype=np.int64), device=self.table_device)
         self.out = (torch.empty((self.world * (self.max_rows + 1), 5), dtype=torch.int32, device=self.comm_device)
-                    if self.world > 1 else None)
+                    if (collectives_on(self.world) if collective is None else collective) else None)
         # per step: a pair of CUDA events (device collective) or seconds (host collective); bounded -- a service loop that steps
         # for ever keeps the marks of its latest 256 steps, not one pair of event objects per step
         self.exchange_marks = collections.deque(maxlen=256)
@@ -143,7 +158,7 @@ class ResidentHitTable:
         if n:
             rows = self.local[1: n + 1]
             rows[:, 0] = self.owned[rows[:, 0].long()].to(torch.int32)      # batch-local -> global query ids
-        if self.world == 1:
+        if self.out is None:
             return self.local.view(1, self.max_rows + 1, 5)
         import torch.distributed as dist
         # the collective is bracketed by two events on torch's stream (a blocking collective makes that stream wait for it);
@@ -208,7 +223,7 @@ def all_vs_all(mapper, genomes, rank, world_size, device=None, group=None, chunk
         parts.append(batch.query_rows(first, min(chunk, len(owned) - first)))
     rows = np.concatenate(parts) if parts else np.zeros(0, ROW_DTYPE)
     rows = remap_query_ids(rows, owned)
-    if world_size == 1:
+    if not collectives_on(world_size):
         return rows
     dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
     gathered = all_gather_rows(rows_to_tensor(rows, dev), group=group)
@@ -327,7 +342,8 @@ def build_index_sharded(genomes, names=None, rank=0, world_size=1, group=None, d
         rec, (lengths, sbf, counter) = local._export_records(dev)
     except Exception as e:                       # noqa: BLE001 -- reported to every rank below
         failure = e
-    if world_size > 1:
+    exchange = collectives_on(world_size)
+    if exchange:
         # a rank that failed on its own share must not leave the others waiting in the all-gather: vote first
         import torch.distributed as dist
         ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=dev)
@@ -336,7 +352,7 @@ def build_index_sharded(genomes, names=None, rank=0, world_size=1, group=None, d
             raise RuntimeError(f"sketching the reference shard failed on some rank (this rank: {failure!r})") from failure
     elif failure is not None:
         raise failure
-    if world_size > 1:
+    if exchange:
         gathered, rec_off, ctg, lengths = exchange_record_shards(rec, lengths, sbf, n, rank, world_size, group)
         rec, sbf = merge_record_shards(gathered, rec_off, ctg)
         sbf = sbf.numpy()
@@ -405,7 +421,7 @@ def global_frequency(keys, counts, world_size=1, group=None):
     import torch
     k = keys.to(torch.int64) & 0xFFFFFFFF
     c = counts.to(torch.int64)
-    if world_size > 1:
+    if collectives_on(world_size):
         import torch.distributed as dist
         n = torch.tensor([k.numel()], dtype=torch.int64, device=k.device)
         sizes = torch.zeros(world_size, dtype=torch.int64, device=k.device)
@@ -452,7 +468,7 @@ def query_ref_sharded(mapper, owned, queries, world_size=1, group=None, device=N
     rows = np.concatenate(parts) if parts else np.zeros(0, ROW_DTYPE)
     rows = rows.copy()
     rows["ref_genome_id"] = np.asarray(owned, dtype=np.int64)[rows["ref_genome_id"]] if len(rows) else rows["ref_genome_id"]
-    if world_size > 1:
+    if collectives_on(world_size):
         dev = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
         rows = tensor_to_rows(all_gather_rows(rows_to_tensor(rows, dev), group=group))
     return rows[np.lexsort((rows["ref_genome_id"], rows["query_id"]))]

@@ -65,6 +65,34 @@ def config5(n_families=10, n_members=20, length=5_000_000):
     return families(4000, n_families, n_members, length)
 
 
+def write_fasta(path, contigs, width=60, prefix="contig"):
+    """One genome as a FASTA file: a record per contig, `width`-column lines (numpy: no Python loop over lines)."""
+    with open(path, "wb") as f:
+        for i, c in enumerate(contigs):
+            a = np.frombuffer(bytes(c), np.uint8) if not isinstance(c, np.ndarray) else c.astype(np.uint8, copy=False)
+            f.write(b">%s_%d\n" % (prefix.encode(), i))
+            whole = len(a) // width * width
+            if whole:
+                lines = np.empty((whole // width, width + 1), np.uint8)
+                lines[:, :width] = a[:whole].reshape(-1, width)
+                lines[:, width] = 10
+                f.write(lines.tobytes())
+            if whole < len(a):
+                f.write(a[whole:].tobytes() + b"\n")
+
+
+def write_fasta_set(directory, genomes, width=60):
+    """Every genome of a workload as ``directory/g<i>.fna``; returns (paths, total bytes)."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    paths = []
+    for i, contigs in enumerate(genomes):
+        p = os.path.join(directory, f"g{i:05d}.fna")
+        write_fasta(p, contigs, width, prefix=f"g{i}")
+        paths.append(p)
+    return paths, sum(os.path.getsize(p) for p in paths)
+
+
 def row_properties(rows, batch, mapper, genomes, fam):
     """What must hold for the hit rows of an all-vs-all run without an oracle (see `all_vs_all`): counts and verdicts."""
     n = len(genomes)

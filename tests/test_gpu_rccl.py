@@ -3,7 +3,6 @@ one-GPU boxes; the strong-scaling mode of bench.py is also run on ONE GPU (N = 1
 gloo) so that its code path is exercised by the driver-run suite."""
 import json
 import os
-import socket
 import subprocess
 import sys
 import textwrap
@@ -20,15 +19,9 @@ def _gpus():
     return torch.cuda.device_count()
 
 
-def _free_port():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def _run_ranks(script_or_args, n, env=None, timeout=1200):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port())] + list(script_or_args)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr=127.0.0.1"] + list(script_or_args)
     e = dict(os.environ, OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.update(env or {})
     return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
@@ -58,6 +51,11 @@ def test_bench_strong_one_gpu(strong_n1):
     device-resident (rows written into a preallocated HBM table) and carries its L2 roofline."""
     assert strong_n1["roofline"]["algorithmic_bytes"] > 0 and strong_n1["phases_ms"]["l2_ms"] > 0
     assert "HBM table" in strong_n1["config"]["exchange"]
+    # ... and the same table once more FROM FASTA FILES (references and queries read, packed and uploaded while the previous chunk
+    # maps): same digest, host and device sides reported with their overlap
+    f = strong_n1["fasta_to_table"]
+    assert f["table_sha256"] == strong_n1["config"]["table_sha256"] and f["rows"] == strong_n1["config"]["rows_per_step"]
+    assert f["ingest_GBps"] > 0 and f["overlap"] >= 1.0 - 1e-6 and f["wall_s"] <= f["host_s"] + f["device_s"] + 1.0
 
 
 def test_bench_strong_two_ranks_sharing_one_gpu(strong_n1):
@@ -123,6 +121,75 @@ def test_bench_line_carries_configs_4_and_5():
     assert sum(c["degenerate"] for c in cells) == 1 and all(c["value"] > 0 and "sketch_stage" in c for c in cells)
     default = [c for c in cells if (c["k"], c["fragment_length"]) == (16, 3000)][0]
     assert default["window_size"] == 24 and default["sketch_stage"].startswith("k_query_fused")
+
+
+def test_every_collective_through_rccl_at_world_size_one(tmp_path):
+    """The `nccl` branches on a ONE-GPU box: a single rank started under torch.distributed.run initialises RCCL at world size 1
+    and, with FA_FORCE_DIST=1, runs every exchange of the multi-GPU layer through it instead of skipping it -- the vote and
+    the two all-gathers of the cooperative index build, the all-gather of the device-resident hit table
+    (`ResidentHitTable.step`), the variable-length row gather, and the hash / list-length gather of the reference-sharded index
+    (`global_frequency`).  Results are compared with the plain single-process path.  The first 8-GPU run is then not the first
+    time RCCL sees this code."""
+    code = textwrap.dedent("""
+        import os, sys, warnings
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        assert dist.get_world_size() == 1 and dist.get_backend() == "nccl"
+        import pyfastani_amd as pf
+        from pyfastani_amd import sharding, workloads
+        pf.set_device(0)
+        assert sharding.collectives_on(1)
+        genomes, fam = workloads.families(77, 2, 4, 200_000, contigs=3)
+        n = len(genomes)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            sk = pf.Sketch()
+            for i, c in enumerate(genomes):
+                sk.add_draft(i, c)
+            direct = sk.index()
+            os.environ["FA_FORCE_DIST"] = "0"
+            want = sharding.all_vs_all(direct, genomes, 0, 1)
+            os.environ["FA_FORCE_DIST"] = "1"
+            m = sharding.build_index_sharded(genomes, rank=0, world_size=1, device="cuda")          # vote + two all-gathers
+            assert len(m.minimizers) == len(direct.minimizers) and m.occurences_threshold == direct.occurences_threshold
+            assert len(m.lookup_index) == len(direct.lookup_index)
+            got = sharding.all_vs_all(m, genomes, 0, 1, device="cuda")                             # counts + padded rows
+            assert got.tobytes() == want.tobytes(), (len(got), len(want))
+            table = sharding.ResidentHitTable(list(range(n)), n * n, 1, comm_device="cuda")        # the HBM table
+            assert table.out is not None
+            batch = m.upload_genomes(genomes)
+            rows = sharding.ResidentHitTable.rows_of(table.step(batch))
+            order = np.lexsort((rows["ref_genome_id"], rows["query_id"]))
+            assert rows[order].tobytes() == want.tobytes()
+            assert table.exchange_ms() > 0
+            rm, owned = sharding.build_ref_sharded_mapper(genomes, rank=0, world_size=1, device="cuda")   # global_frequency
+            got2 = sharding.query_ref_sharded(rm, owned, genomes, world_size=1, device="cuda")
+            assert got2.tobytes() == want.tobytes()
+        dist.barrier(); dist.destroy_process_group()
+        open(os.path.join(%r, "ws1.ok"), "w").write("rccl_ranks: 1, backend: nccl, rows: %%d" %% len(got))
+    """ % (ROOT, str(tmp_path)))
+    script = tmp_path / "worker_ws1.py"
+    script.write_text(code)
+    res = _run_ranks([str(script)], 1, env={"FA_FORCE_DIST": "1"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert (tmp_path / "ws1.ok").read_text().startswith("rccl_ranks: 1, backend: nccl")
+
+
+def test_bench_exchanges_through_rccl_at_world_size_one():
+    """bench.py as ONE rank with FA_BENCH_FORCE_DIST=1: the weak-scaled line's `exchange()` and the strong leg's
+    `ResidentHitTable.step` all-gather go through RCCL (backend nccl, one rank), the index is built through the cooperative
+    path, and the strong leg's table has the digest of the table computed without any collective."""
+    args = ["--gpus", "1", "--refs", "6", "--length", "300000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-boundary",
+            "--clients", "0", "--families", "2", "--members", "5", "--saturated-steps", "2"]
+    res = _run_ranks([os.path.join(ROOT, "bench.py")] + args, 1, env={"FA_BENCH_FORCE_DIST": "1"})
+    assert res.returncode == 0, res.stdout + res.stderr
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["backend"].startswith("nccl")
+    assert "sharded sketching x1" in line["config"]["index_build"] and line["value"] > 0
+    s = line["strong"]
+    assert s["digest_matches_n1"] is True and s["exchange_ms"] > 0 and "all_gather_into_tensor" in s["exchange"]
 
 
 def test_bench_refuses_a_world_size_that_is_not_gpus():
