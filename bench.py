@@ -39,9 +39,21 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-TRAFFIC_PROFILE = "r04_traffic.json"                   # the timed step (1 query per launch)
-TRAFFIC_PROFILE_BATCH16 = "r04_batch16_traffic.json"     # `saturated.batch16`: 16 queries per launch
-TRAFFIC_PROFILE_CONFIG3 = "r04_config3_traffic.json"     # `saturated.config3`: 1000 x 1000, two steps profiled
+# committed rocprofv3 summaries (scripts/collect_profiles.sh): the newest round that holds a file wins
+PROFILE_TAGS = ("r05", "r04")
+TRAFFIC_PROFILE = "traffic.json"                         # the timed step (1 query per launch)
+TRAFFIC_PROFILE_BATCH16 = "batch16_traffic.json"         # `saturated.batch16`: 16 queries per launch
+TRAFFIC_PROFILE_CONFIG3 = "config3_traffic.json"         # `saturated.config3`: 1000 x 1000, two steps profiled
+TRAFFIC_PROFILE_CONFIG4 = "config4_traffic.json"         # `saturated.config4`: 500 x 500 draft assemblies
+
+
+def profile_file(suffix):
+    """profiles/<tag>_<suffix> of the newest round that has it (None: no round has)."""
+    for tag in PROFILE_TAGS:
+        path = os.path.join(ROOT, "profiles", f"{tag}_{suffix}")
+        if os.path.exists(path):
+            return path
+    return None
 # digest of the config-3 hit table (20 x 50 x 5 Mb) as the driver-run N = 1 benches of rounds 2 and 3 printed it (BENCH_r03.json,
 # profiles/r03_bench_default.json: `saturated.config3.table_sha256`); an N > 1 run must reproduce it
 COMMITTED_CONFIG3_DIGEST = "f3eea1ae46a1386c"
@@ -67,6 +79,7 @@ def parse_args():
     ap.add_argument("--no-saturated", action="store_true", help="N=1: skip the `saturated` legs (16 queries per launch; config 3 at N=1)")
     ap.add_argument("--saturated-steps", type=int, default=3, help="steps of the config-3 leg of `saturated` (its batch-16 leg runs 10)")
     ap.add_argument("--no-config45", action="store_true", help="N=1: skip BASELINE configs 4 (500 drafts all-vs-all) and 5 (nine (k, fragment_length) cells)")
+    ap.add_argument("--leg", type=str, default=None, help="N=1: run ONE leg and print it (profile collection): config4 | config5:k<k>f<fragment>")
     ap.add_argument("--no-fasta-leg", action="store_true", help="N=1: skip the files-to-table leg of config 3 (`saturated.config3.fasta_to_table`)")
     ap.add_argument("--config4", type=str, default="10x50", help="families x members of the config-4 leg (tests shrink it)")
     ap.add_argument("--config5", type=str, default="10x20", help="families x members of the config-5 leg (tests shrink it)")
@@ -133,6 +146,11 @@ def main():
 
     check(lib.fa_set_device(local_rank))
     ctx = dict(args=args, rank=rank, world=world, share_gpu=share_gpu, torch=torch, dist=dist, dist_on=dist_on)
+    if args.leg:
+        if world != 1 or not (args.leg == "config4" or args.leg.startswith("config5:")):
+            raise SystemExit("--leg takes config4 or config5:k<k>f<fragment>, at N = 1")
+        print(json.dumps(config4_leg(ctx) if args.leg == "config4" else config5_leg(ctx)))
+        return
     result = strong_scaling(ctx) if args.strong else weak_scaling(ctx)
     if dist_on:
         dist.barrier()
@@ -306,7 +324,7 @@ def weak_scaling(ctx):
     k1_model = valu_model().get("k_sketch_fast", {})
     sketch_extra = ({"issue_floor_gbases_per_s": k1_model["issue_floor_gbases_per_s"],
                      "valu_frac": bases.value / (k1_ms.value * 1e-3) / 1e9 / k1_model["issue_floor_gbases_per_s"],
-                     "issue_floor_source": "profiles/r04_valu_model.json"} if k1_model else {})
+                     "issue_floor_source": valu_model().get("_source")} if k1_model else {})
     result = {
         "metric": "genome-pair ANI/sec (5 Mb bacterial, 3 kb frags)",
         "value": value,
@@ -335,6 +353,7 @@ def weak_scaling(ctx):
                             "note": "the sketch kernel alone over the query's tiles (50 launches, fa_bench_sketch_kernel); in the timed step the same tile body runs inside k_query_fused, in one launch with the per-fragment sort and index lookup",
                             **sketch_extra},
         "phases_ms": phase,
+        **({"stage_bounds": stage_bounds("step", phase)} if standard else {}),
         "rccl_ranks": dist.get_world_size() if ctx["dist_on"] else 1,
         "backend": (dist.get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if share_gpu else " (RCCL over xGMI)")) if ctx["dist_on"] else "none (one rank)",
     }
@@ -442,37 +461,59 @@ def profiled_traffic(which, profile=None):
     collected on this exact workload by scripts/collect_profiles.sh): FETCH_SIZE and WRITE_SIZE come from separate
     passes, are in KB, and FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950.  PMC counters cannot be read
     from inside the benchmark, so this is the profiled value, not a live one; (None, None) if the profile is missing."""
-    profile = profile or TRAFFIC_PROFILE
-    path = os.path.join(ROOT, "profiles", profile)
+    path = profile_file(profile or TRAFFIC_PROFILE)
+    prefixes = {"l2": ("k_l2_",), "k1": ("k_sketch_fast<16, 24>",), "l1": ("k_l1<", "k_l1_big"), "sketch": ("k_query_fused", "k_sketch_")}[which]
     try:
         doc = json.load(open(path))
         table = doc["kernels"]
-        pick = [k for k in table if (k.startswith("k_l2_") if which == "l2" else k.startswith("k_sketch_fast<16, 24>"))]
+        pick = [k for k in table if k.startswith(prefixes)]
         if not pick:
             return None, None
         total = sum((2.0 * table[k]["fetch_size_kb"] + table[k]["write_size_kb"]) * 1024.0 * table[k].get("launches_per_step", 1) for k in pick)
-        return total / float(doc.get("steps_summed", 1)), f"profiles/{profile}@{doc.get('head', 'unknown')}"
-    except (OSError, KeyError, ValueError):
+        return total / float(doc.get("steps_summed", 1)), f"profiles/{os.path.basename(path)}@{doc.get('head', 'unknown')}"
+    except (OSError, KeyError, ValueError, TypeError):
         return None, None
 
 
 def valu_model():
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r04_valu_model.json")))
-    except (OSError, ValueError):
+        path = profile_file("valu_model.json")
+        doc = json.load(open(path))
+        doc["_source"] = f"profiles/{os.path.basename(path)} (scripts/valu_model.py)"
+        return doc
+    except (OSError, ValueError, TypeError):
         return {}
 
 
 def issue_floor(regime, l2_ms):
-    """Vector-issue floor of the L2 stage from profiles/r04_valu_model.json (executed VALU wave-instructions of the two
+    """Vector-issue floor of the L2 stage from profiles/<round>_valu_model.json (executed VALU wave-instructions of the two
     kernels x the measured issue-slot cost of their instruction mix / (1024 SIMDs x clock)) and its share of the measured
     stage time: the stage is integer work on the vector pipes, this -- not HBM -- is the roofline it actually sits under."""
-    rows = valu_model().get("regimes", {}).get(regime, {})
+    model = valu_model()
+    rows = model.get("regimes", {}).get(regime, {})
     floors = {k: v["issue_floor_ms"] for k, v in rows.items() if k.startswith("k_l2_")}
     if len(floors) < 2 or l2_ms <= 0:
         return {}
     return {"issue_floor_ms": sum(floors.values()), "valu_frac": sum(floors.values()) / l2_ms,
-            "issue_floor_ms_by_kernel": floors, "issue_floor_source": "profiles/r04_valu_model.json (scripts/valu_model.py)"}
+            "issue_floor_ms_by_kernel": floors, "issue_floor_source": model.get("_source")}
+
+
+def stage_bounds(regime, phase):
+    """Every hot kernel with its bound (round 5): per stage of the pass -- sketch (k_query_fused), lookup + L1 (k_l1), L2
+    (k_l2_events + k_l2_scan) -- the vector-issue floor of its kernels (valu_model, above) next to the measured stage time.
+    `valu_frac` = floor / measured: 1.0 would be a stage that does nothing but issue vector instructions back to back."""
+    model = valu_model()
+    rows = model.get("regimes", {}).get(regime, {})
+    stages = {"sketch": ("sketch_ms", ("k_query_fused",)), "lookup_l1": ("lookup_l1_ms", ("k_l1<",)), "l2": ("l2_ms", ("k_l2_",))}
+    out = {}
+    for name, (key, prefixes) in stages.items():
+        floors = {k: v["issue_floor_ms"] for k, v in rows.items() if k.startswith(prefixes)}
+        ms = float(phase.get(key, 0.0))
+        if floors and ms > 0:
+            out[name] = {"measured_ms": ms, "issue_floor_ms": sum(floors.values()), "valu_frac": sum(floors.values()) / ms, "kernels": floors}
+    if out:
+        out["source"] = model.get("_source")
+    return out
 
 
 def stage_roofline(l2_records, l2_ms, traffic, traffic_source):
@@ -520,13 +561,15 @@ def saturated_legs(ctx, mapper, anc, batch16_steps=10):
     phase /= batch16_steps
     traffic, src = (profiled_traffic("l2", TRAFFIC_PROFILE_BATCH16) if args.refs == 100 and args.length == 5_000_000 else (None, None))
     roof16 = stage_roofline(rec / batch16_steps, float(phase[2]), traffic, src)
+    bounds16 = {}
     if args.refs == 100 and args.length == 5_000_000:
         roof16.update(issue_floor("batch16", float(phase[2])))
+        bounds16 = stage_bounds("batch16", dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms"], [float(x) for x in phase[:3]])))
     out["batch16"] = {"workload": f"{nq} queries x {args.refs} synthetic {args.length / 1e6:g} Mb refs in ONE launch sequence, k=16 frag=3000",
                       "value": nq * args.refs * batch16_steps / dt, "unit": "pairs/s", "steps": batch16_steps, "ms_per_step": dt / batch16_steps * 1e3,
                       "ms_per_query": dt / batch16_steps / nq * 1e3, "rows_per_step": int(n_rows), "l2_loci": int(loci / batch16_steps),
                       "phases_ms": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase])),
-                      "roofline": roof16}
+                      "roofline": roof16, **({"stage_bounds": bounds16} if bounds16 else {})}
     del batch, table
     # ---- config 3 at N = 1 ----
     if args.saturated_steps > 0:
@@ -598,7 +641,8 @@ def config4_leg(ctx):
     n = len(genomes)
     return {"workload": f"{n} x {n} draft assemblies all-vs-all ({f} families x {m}), 50 contigs each, {args.length / 1e6:g} Mb, k=16 frag=3000 w={r['window_size']}",
             "generate_s": t_gen, "contigs": int(sum(len(c) for c in genomes)),
-            "roofline": stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"], None, None), **r}
+            "roofline": stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"],
+                                       *(profiled_traffic("l2", TRAFFIC_PROFILE_CONFIG4) if (f, m, args.length) == (10, 50, 5_000_000) else (None, None))), **r}
 
 
 def config5_leg(ctx):
@@ -612,7 +656,10 @@ def config5_leg(ctx):
     genomes, fam = workloads.config5(f, m, args.length)
     t_gen = time.time() - t0
     cells = []
+    only = getattr(args, "leg", None)
     for k, frag in workloads.CONFIG5_CELLS:
+        if only and only.startswith("config5:") and only != f"config5:k{k}f{frag}":
+            continue
         r, mapper = resident_all_vs_all(ctx, genomes, fam, {"k": k, "fragment_length": frag}, 2)
         degenerate = r["window_size"] >= frag
         # (1 kb fragments carry ~80 minimizers: unrelated genomes pass the 80 % cut-off by chance there -- the oracle shows the
@@ -620,7 +667,12 @@ def config5_leg(ctx):
         ok = (r["rows"] == 0) if degenerate else (r["self_hits_exact"] and (r["hits_within_family"] or not (frag >= 3000 and k <= 16)))
         if not ok:
             raise SystemExit(f"CONFIG 5 FAILURE in cell k={k} fragment_length={frag}: {r}")
-        cells.append({"k": k, "fragment_length": frag, "degenerate": degenerate, **r})
+        # every cell with its roofline: 12 algorithmic bytes per reference record inside a locus range over the L2 stage time, and
+        # the HBM traffic of the cells that have a committed PMC profile (the two slowest: scripts/collect_profiles.sh <tag> config5:...)
+        full = (f, m, args.length) == (10, 20, 5_000_000)
+        roof = (stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"], *(profiled_traffic("l2", f"config5_k{k}_f{frag}_traffic.json") if full else (None, None)))
+                if not degenerate and r["phases_ms"]["l2_ms"] > 0 else None)
+        cells.append({"k": k, "fragment_length": frag, "degenerate": degenerate, "roofline": roof, **r})
         del mapper
     n = len(genomes)
     return {"workload": f"{n} x {n} all-vs-all ({f} families x {m}) of {args.length / 1e6:g} Mb genomes per (k, fragment_length) cell", "generate_s": t_gen,

@@ -232,7 +232,7 @@ int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, in
  * [13] device pass + rows ms; [14], [15] development (fused L2 form); [16] the L2 stage once more, bracketed by HIP
  * events on the library's stream, when fa_mapper_set_stage_events is on (0 otherwise); [17] parts of the call whose sketch
  * stage ran as ONE launch (k_query_fused), [18] parts that ran K1 and the fragment sketch as two kernels, [19] parts whose
- * k_l2_events workgroups ran in the offset-major order.  n <= 24. */
+ * k_l2_events workgroups ran in the offset-major order; [23] positions per tile of the last fa_bench_sketch_kernel.  n <= 24. */
 int fa_mapper_last_timings(fa_mapper *m, float *ms, int n);
 /* on != 0: also bracket the L2 stage of every pass with two HIP events (slot [16] above).  Off by default: an event
  * record costs the stream about as much as a small kernel. */
@@ -240,7 +240,9 @@ int fa_mapper_set_stage_events(fa_mapper *m, int on);
 /* the HIP stream the library launches on (so callers can bracket it with their own events) */
 int fa_mapper_stream(fa_mapper *m, void **stream);
 /* run only the minimizer-extraction kernel (K1) over a resident batch `repeat` times and report the mean
- * kernel time; used by bench.py for the roofline line. */
+ * kernel time; used by bench.py for the roofline line.  The batch is sketched the way REFERENCE genomes are
+ * (_fastani.pyx:651-659: whole contigs, windows across fragment boundaries): its fragments are joined into the contigs
+ * they were cut from and tiled as fa_sketch tiles them. */
 int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_per_launch, uint64_t *bases,
                            uint64_t *minimizers);
 

@@ -262,12 +262,13 @@ struct fa_sketch {
       std::vector<Tile> tiles;
       std::vector<int32_t> seq_tile_lo, seq_ids;
       int64_t s1 = s0, positions = 0;
-      while (s1 < nseq_all && (s1 == s0 || positions + pending.seq_len[s1] <= chunk_positions)) {
+      while (s1 < nseq_all && (s1 == s0 || positions + pending.seq_len[s1] <= chunk_positions)) { positions += pending.seq_len[s1]; s1++; }
+      // (tiles whose positions + halo are whole hashing trips: k1_tile_len)
+      const int tile_len = k1_tile_len(P.window_size);
+      for (int64_t q = s0; q < s1; q++) {
         seq_tile_lo.push_back((int32_t)tiles.size());
-        make_tiles(tiles, pending, pending.seq_off[s1], pending.seq_len[s1], (int)(s1 - s0), P.kmer_size, P.window_size);
-        seq_ids.push_back(pending_contig[s1]);
-        positions += pending.seq_len[s1];
-        s1++;
+        make_tiles(tiles, pending, pending.seq_off[q], pending.seq_len[q], (int)(q - s0), P.kmer_size, P.window_size, tile_len);
+        seq_ids.push_back(pending_contig[q]);
       }
       seq_tile_lo.push_back((int32_t)tiles.size());
       const int nseq = (int)(s1 - s0), ntiles = (int)tiles.size();
@@ -355,7 +356,7 @@ struct fa_genomes {
   std::vector<int32_t> n_short;
   int64_t F = 0, ntiles = 0;
   uint64_t total_bases = 0;                 // bases inside fragments
-  std::vector<unsigned char> host_image;    // staging image when no pinned buffer is supplied
+  std::vector<unsigned char, NoInitAlloc<unsigned char>> host_image;   // staging image when no pinned buffer is supplied (every byte of it is written: no zero fill)
   PinnedBuf pin_image;                      // staging image of a batch that is refilled (fa_genomes_reload_fasta)
   hipStream_t up_stream = nullptr;          // FASTA uploads run on the batch's own stream
   ~fa_genomes() { if (up_stream) (void)hipStreamDestroy(up_stream); }
@@ -1202,7 +1203,9 @@ struct QueryPass {
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       static const bool l1_block_sort_on = !(getenv("FA_L1_BLOCK_SORT") && atoi(getenv("FA_L1_BLOCK_SORT")) == 0);
       static const bool l1_stats = getenv("FA_L1_STATS") && atoi(getenv("FA_L1_STATS")) != 0;
-      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0);
+      // FA_L1_NEAR=0: every hit fetches its padded global coordinate (the round-4 form; A/B of the HBM fetch)
+      static const bool l1_near_on = !(getenv("FA_L1_NEAR") && atoi(getenv("FA_L1_NEAR")) == 0);
+      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
@@ -1795,7 +1798,7 @@ static void fill_genomes(fa_genomes *g, const fa_params &P, hipStream_t st, cons
   // synchronisation; otherwise one per upload
   if (!pin || sync_pinned) {
     FA_HIP(hipStreamSynchronize(st));
-    std::vector<unsigned char>().swap(g->host_image);
+    std::vector<unsigned char, NoInitAlloc<unsigned char>>().swap(g->host_image);
   }
   tr.mark("uploads", st);
   lap(2);
@@ -2513,17 +2516,46 @@ int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_pe
     WorkspaceLease lease(*m);
     Workspace &w = *lease.w;
     require_device();
-    const int ntiles = (int)g->ntiles;
+    int ntiles = (int)g->ntiles;
     FA_REQUIRE(ntiles > 0 && repeat > 0, FA_ERR_INVALID, "nothing to sketch");
+    // the genome as REFERENCE sketching sees it: the fragments of a contig lie back to back in the batch's store, so they are
+    // joined into whole sequences again and cut into the tiles reference sketching uses (k1_tile_len: positions + halo = whole
+    // hashing trips); the batch's own tiles are per query fragment, for k_query_fused.  Batches with exceptions keep their tiles.
+    const Tile *tiles = g->tiles;
+    DevBuf<Tile> retiled;
+    const int tile_len = k1_tile_len(m->P.window_size);
+    if (g->store.n_exc == 0 && m->P.alphabet_size == 4) {
+      std::vector<Tile> host((size_t)ntiles), cut;
+      FA_HIP(hipMemcpy(host.data(), g->tiles, (size_t)ntiles * sizeof(Tile), hipMemcpyDeviceToHost));
+      int64_t run_base = -1, run_len = 0;
+      int32_t run_id = 0, last_seq = -1;
+      auto close = [&] {
+        if (run_base < 0) return;
+        const int64_t npos = run_len - m->P.kmer_size + 1;
+        for (int64_t p0 = 0; p0 < npos; p0 += tile_len)
+          cut.push_back(Tile{run_base, (int32_t)run_len, (int32_t)p0, (int32_t)std::min<int64_t>(tile_len, npos - p0), run_id, 0, 0});
+        run_id++; run_base = -1; run_len = 0;
+      };
+      for (const Tile &t : host) {
+        if (t.seq == last_seq) continue;                               // (the other tiles of a fragment seen already)
+        last_seq = t.seq;
+        if (run_base >= 0 && t.base == run_base + run_len && run_len + t.seq_len < (1LL << 31)) run_len += t.seq_len;
+        else { close(); run_base = t.base; run_len = t.seq_len; }
+      }
+      close();
+      retiled.upload(cut, w.stream);
+      tiles = retiled.p; ntiles = (int)cut.size();
+    }
+    w.last_ms[23] = (float)tile_len;
     w.sk.stage_hash.ensure((size_t)ntiles * TILE);
     w.sk.stage_wpos.ensure((size_t)ntiles * TILE);
     w.sk.tile_count.ensure((size_t)ntiles + 1);
     hipEvent_t e0, e1;
     FA_HIP(hipEventCreate(&e0)); FA_HIP(hipEventCreate(&e1));
-    launch_sketch_tiles(m->P, g->store, g->tiles, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
+    launch_sketch_tiles(m->P, g->store, tiles, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
     FA_HIP(hipEventRecord(e0, w.stream));
     for (int i = 0; i < repeat; i++)
-      launch_sketch_tiles(m->P, g->store, g->tiles, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
+      launch_sketch_tiles(m->P, g->store, tiles, ntiles, w.sk.stage_hash.p, w.sk.stage_wpos.p, w.sk.tile_count.p, w.stream);
     FA_HIP(hipEventRecord(e1, w.stream));
     FA_HIP(hipEventSynchronize(e1));
     float ms = 0;

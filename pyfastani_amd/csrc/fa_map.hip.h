@@ -649,7 +649,8 @@ struct L1Args {
   int32_t qcap, frag_len, l_cap;
   uint32_t lds_seed_cap;
   unsigned long long *dbg;       // [8] FA_L1_STATS=1: ticks of the phases of k_l1
-  int32_t block_sort;            // k_l1: bit 0 = try l1_block_sort before the merge (FA_L1_BLOCK_SORT=0 switches it off), bit 1 = count the roads taken
+  int32_t block_sort;            // k_l1: bit 0 = try l1_block_sort before the merge (FA_L1_BLOCK_SORT=0 switches it off), bit 1 = count the roads taken,
+                                 // bit 2 = skip the coordinate fetch of hits that cannot be an end of a candidate (FA_L1_NEAR=0: off)
   uint8_t *big_state;            // [F] k_l1_big: 1 = this fragment was handled there, 0 = not (k_l1 takes it)
   int32_t big_enabled;           // k_l1_big ran before k_l1 in this pass
   uint32_t big_cap;              // seed hits per chunk of k_l1_big (<= L1_BIG_E x L1_BIG_THREADS)
@@ -1210,14 +1211,52 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     uint32_t heads = 0;
     // (the scan proper, on 32-bit coordinates while the index spans less than 2^32 padded bases -- twice the steps per batch
     // in the same registers, half the lane exchanges -- and on 64-bit ones beyond)
-    auto scan_run = [&](auto tag) __attribute__((always_inline)) {
+    auto scan_run = [&](auto tag, auto near_tag) __attribute__((always_inline)) {
       using G = decltype(tag);
       constexpr bool NARROW = sizeof(G) == 4;
-      constexpr int CB = NARROW ? 9 : 6;                                     // steps per batch (registers: one or two per step)
-      auto coord = [&](uint32_t step) __attribute__((always_inline)) -> G {
+      constexpr bool NEAR = decltype(near_tag)::value;
+      // steps per batch (registers: one or two per step; the partner read of the near test takes one step's worth)
+      constexpr int CB = NEAR ? (NARROW ? 8 : 5) : (NARROW ? 9 : 6);
+      // The coordinate of a hit is only fetched if the hit can be one end of a candidate (round 5).  Records are ordered by
+      // (contig, window) and window positions grow by at least one per record, so the padded global coordinates of two hits
+      // differ by at least their distance in RECORDS: hit i can START a candidate (`fwd`) only if its partner, m - 1 hits ahead,
+      // is less than a fragment length of records away, and its coordinate is needed only then or if the hit m - 1 places
+      // BACK can start one -- a bit of the previous lanes' ballot, of this step or the one before (scalar shifts: no third LDS
+      // read, no further live register in a kernel that has none to spare).  Every other hit reads record 0 (one cached
+      // line): that is what the ~500 chance hits a fragment collects in a 4 x 10^8-record index are, and each had cost a
+      // 64-128 byte line of rec_gpos for 4 bytes nobody used (k_l1's fetch on 500 x 500 genomes: 110 -> 72 GB).  A candidate
+      // is only tested where `fwd` holds; both coordinates are real then.  FA_L1_NEAR=0: every hit counts as a possible start.
+      auto fwd_of = [&](uint32_t idx, uint32_t r) __attribute__((always_inline)) {
+        if constexpr (!NEAR) return true;
+        else return idx + (uint32_t)mp < n && seeds[idx + (uint32_t)mp] - r < (uint32_t)len;
+      };
+      uint64_t prev_fwdb = 0;
+      if (NEAR && s0 > 0 && s0 < s1) {
+        const uint32_t idx = (s0 - 1u) * 64u + (uint32_t)lane;
+        prev_fwdb = __ballot(idx < n && fwd_of(idx, seeds[min(idx, n - 1u)]));
+      }
+      auto coord = [&](uint32_t step, bool &fwd) __attribute__((always_inline)) -> G {
         const uint32_t idx = step * 64u + (uint32_t)lane;
-        if (!(step <= s1 && idx < n)) return (G)0;
-        if constexpr (NARROW) return (G)a.ix.rec_gpos[seeds[idx]]; else return (G)gpos_of(a.ix, seeds[idx]);
+        if constexpr (!NEAR) {                                             // (the round-4 form, for the A/B: every coordinate is fetched)
+          fwd = true;
+          if (!(step <= s1 && idx < n)) return (G)0;
+          if constexpr (NARROW) return (G)a.ix.rec_gpos[seeds[idx]]; else return (G)gpos_of(a.ix, seeds[idx]);
+        }
+        const bool in = step <= s1 && idx < n;
+        const uint32_t r = in ? seeds[idx] : 0u;
+        fwd = in && fwd_of(idx, r);
+        const uint64_t fwdb = __ballot(fwd);
+        bool need;
+        if (mp < 64) {
+          const uint64_t bwdb = mp == 0 ? fwdb : ((fwdb << mp) | (prev_fwdb >> (64 - mp)));
+          need = (((fwdb | bwdb) >> lane) & 1ULL) != 0ULL;
+        } else {                                                           // (huge sketches only)
+          need = fwd || (in && idx >= (uint32_t)mp && fwd_of(idx - (uint32_t)mp, seeds[idx - (uint32_t)mp]));
+        }
+        prev_fwdb = fwdb;
+        if (!in) return (G)0;
+        const uint32_t rr = need ? r : 0u;
+        if constexpr (NARROW) return (G)a.ix.rec_gpos[rr]; else return (G)gpos_of(a.ix, rr);
       };
       auto from_lane = [&](G v, int l) __attribute__((always_inline)) -> G {       // v of lane l (any l)
         if constexpr (NARROW) return (G)__shfl((int)v, l); else return (G)__shfl((long long)v, l);
@@ -1228,12 +1267,14 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       };
       const G lenG = (G)len;
       G carry = 0;
-      G g_next = s0 < s1 ? coord(s0) : (G)0;
+      bool fwd_next = false;
+      G g_next = s0 < s1 ? coord(s0, fwd_next) : (G)0;
       for (uint32_t sb = s0; sb < s1; sb += CB) {
         G g[CB + 1];
+        uint32_t fwd_bits = fwd_next ? 1u : 0u;                            // bit u: the hit of g[u] may start a candidate
         g[0] = g_next;
 #pragma unroll
-        for (int u = 1; u <= CB; u++) g[u] = coord(sb + (uint32_t)u);
+        for (int u = 1; u <= CB; u++) { bool fw; g[u] = coord(sb + (uint32_t)u, fw); if constexpr (NEAR) fwd_bits |= fw ? (1u << u) : 0u; }
 #pragma unroll
         for (int u = 0; u < CB; u++) {
           const uint32_t step = sb + (uint32_t)u;
@@ -1246,9 +1287,9 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
               gb = lane + mp < 64 ? x : y;
             } else {                                                       // (huge sketches only)
               gb = 0;
-              if (i < ncand) { if constexpr (NARROW) gb = (G)a.ix.rec_gpos[seeds[i + mp]]; else gb = (G)gpos_of(a.ix, seeds[i + mp]); }
+              if (i < ncand && (!NEAR || ((fwd_bits >> u) & 1u))) { if constexpr (NARROW) gb = (G)a.ix.rec_gpos[seeds[i + mp]]; else gb = (G)gpos_of(a.ix, seeds[i + mp]); }
             }
-            const bool flag = i < ncand && (G)(gb - ga) < lenG;
+            const bool flag = i < ncand && (!NEAR || ((fwd_bits >> u) & 1u)) && (G)(gb - ga) < lenG;
             const uint64_t bal = __ballot(flag);
             const uint64_t below = bal & ((1ULL << lane) - 1ULL);
             const int src_lane = below ? 63 - __clzll(below) : -1;
@@ -1266,9 +1307,11 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
           }
         }
         g_next = g[CB];
+        fwd_next = (fwd_bits >> CB) & 1u;
       }
     };
-    if (a.ix.n_wraps == 0) scan_run((uint32_t)0); else scan_run((uint64_t)0);
+    if (a.block_sort & 4) { if (a.ix.n_wraps == 0) scan_run((uint32_t)0, std::true_type()); else scan_run((uint64_t)0, std::true_type()); }
+    else { if (a.ix.n_wraps == 0) scan_run((uint32_t)0, std::false_type()); else scan_run((uint64_t)0, std::false_type()); }
     if (lane == 0) { cw_heads[wv] = heads; cw_any[wv] = any ? 1u : 0u; cw_last_g[wv] = carry_g; cw_first_gb[wv] = first_gb; }
     __syncthreads();
     // every wave resolves the chain of summaries for itself: loci before its run, and whether its first flagged candidate

@@ -92,13 +92,15 @@ struct DevStore {
 };
 
 // Appends the tiles of one sequence slice [off, off+len) (a whole contig, or one query fragment).
-inline void make_tiles(std::vector<Tile> &tiles, const HostStore &hs, int64_t off, int64_t len, int seq, int k, int w) {
+// `tile_len` <= TILE k-mer positions per tile (a multiple of 4: a thread owns four consecutive positions): the kernels take any
+// tile up to TILE (k1_tile_len below: the length reference sketching uses).
+inline void make_tiles(std::vector<Tile> &tiles, const HostStore &hs, int64_t off, int64_t len, int seq, int k, int w, int tile_len = TILE) {
   int64_t npos_total = len - k + 1;
   if (npos_total <= 0) return;
-  for (int64_t p0 = 0; p0 < npos_total; p0 += TILE) {
+  for (int64_t p0 = 0; p0 < npos_total; p0 += tile_len) {
     Tile t;
     t.base = off; t.seq_len = (int32_t)len; t.pos0 = (int32_t)p0;
-    t.npos = (int32_t)std::min<int64_t>(TILE, npos_total - p0);
+    t.npos = (int32_t)std::min<int64_t>(tile_len, npos_total - p0);
     t.seq = seq; t.exc_lo = 0; t.exc_n = 0;
     if (!hs.exc_pos.empty()) {
       int64_t hb = std::min<int64_t>(p0, 2 * (int64_t)w - 2);
@@ -110,6 +112,20 @@ inline void make_tiles(std::vector<Tile> &tiles, const HostStore &hs, int64_t of
     }
     tiles.push_back(t);
   }
+}
+
+// Positions per tile of REFERENCE sketching (round 5).  A workgroup hashes its tile's positions PLUS a halo of 2w - 2 in
+// front of it in trips of SK_THREADS: a full tile of 1 024 positions behind a 46-position halo (w = 24) is 1 070 hashes = FIVE
+// trips, the last one 18 % full -- a fifth of the hashing loop (82 % of the kernel's instructions) for 4 % of the positions.
+// TILE - (2w - 2) positions per tile make it four full trips: 4.7 % more tiles, 20 % fewer hashing instructions each.  (Half
+// tiles, asked for to even out the last resident round of a one-genome launch, buy nothing beyond that: rounds x trips is
+// 3 x 4 for 976-position tiles, 4 x 3 for 722, 6 x 2 for 466 -- 12 either way, against 3 x 5 for the full tile.)  Query
+// fragments keep whole tiles: 2 985 positions do not fit three four-trip tiles (2 980), and a fourth tile costs more than the
+// fifth trip.  FA_K1_TILE = 1024 restores the full tile (A/B).
+inline int k1_tile_len(int w) {
+  static const int forced = [] { const char *e = getenv("FA_K1_TILE"); const int x = e ? atoi(e) : 0; return (x >= 256 && x <= TILE && x % 4 == 0) ? x : 0; }();
+  if (forced) return forced;
+  return std::max(256, (TILE - (2 * w - 2)) & ~3);
 }
 
 // ----------------------------------------------------------------------------------------------------------

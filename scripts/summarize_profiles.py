@@ -62,7 +62,7 @@ json.dump({"head": head(),
 sq = last_launch("sq_a")
 for k, v in last_launch("sq_b").items():
     sq.setdefault(k, {}).update(v)
-keep = {k: v for k, v in sq.items() if k.startswith(("k_l2", "k_l1", "k_sketch_tiles", "k_lookup", "k_query_sketch", "k_cgi"))}
+keep = {k: v for k, v in sq.items() if k.startswith(("k_l2", "k_l1", "k_sketch_tiles", "k_lookup", "k_query_sketch", "k_query_fused", "k_sketch_fast", "k_cgi"))}
 for k, v in keep.items():
     if v.get("SQ_LDS_IDX_ACTIVE"):
         v["lds_bank_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"]

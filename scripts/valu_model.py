@@ -26,14 +26,18 @@ def load(name):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"      # whose counters (the instruction mix of the L2 kernels is round 3's: they have not changed since)
-    mix = load("r03_isa_mix.json")
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"      # whose counters
+    mix_name = f"{tag}_isa_mix.json" if load(f"{tag}_isa_mix.json") else "r03_isa_mix.json"   # (the instruction mix of that round's kernels, if it was regenerated)
+    mix = load(mix_name)
     out = {"simds": SIMDS, "clock_mhz": CLOCK_MHZ, "slot_cycles": mix["slot_cycles"],
-           "sources": ["profiles/r03_isa_mix.json", f"profiles/{tag}_map_kernels_pmc.json", f"profiles/{tag}_batch16_map_kernels_pmc.json",
+           "sources": [f"profiles/{mix_name}", f"profiles/{tag}_map_kernels_pmc.json", f"profiles/{tag}_batch16_map_kernels_pmc.json",
                        "profiles/r03_k1_pmc.json", "profiles/r03_valu_rates.txt"], "regimes": {}}
     slot = {k: v["mean_slot_cycles"] for k, v in mix["kernels"].items()}
+    # (k_query_fused and k_l1 are priced with the mix of their hot loops -- the hashing loop, the merge level: their other
+    # phases are lane exchanges, LDS atomics and scans with a similar share of slow opcodes)
     alias = {"k_sketch_fast<16, 24>": "k_sketch_fast<16, 24>", "k_l2_scan<unsigned short, unsigned char, 64>": "k_l2_scan<unsigned short, unsigned char, 64>",
-             "k_l2_events<unsigned short, true>": "k_l2_events<unsigned short, true>", "k_l1<256, 16>": "k_l1<256, 16>"}
+             "k_l2_events<unsigned short, true>": "k_l2_events<unsigned short, true>", "k_l1<256, 16>": "k_l1<256, 16>", "k_l1<512, 16>": "k_l1<256, 16>",
+             "k_query_fused<16, 24>": "k_query_fused<16, 24>"}
     for regime, fname in (("step", f"{tag}_map_kernels_pmc.json"), ("batch16", f"{tag}_batch16_map_kernels_pmc.json")):
         pmc = load(fname)
         if not pmc:
