@@ -75,6 +75,11 @@ typedef struct fa_mapping {
 /* ---- library ---------------------------------------------------------- */
 const char *fa_last_error(void);
 int fa_version(void);
+/* Device memory the library's handles give back is kept in a per-device pool and reused (on this runtime memory that went
+ * through hipFree is scrubbed before it is handed out again, which made the second index build of a process twelve times
+ * slower than the first).  fa_device_trim returns everything the pool holds to the runtime (*held_bytes, if not NULL: what
+ * it held); FA_POOL_MAX_GB (default 96, 0 = no pool) bounds it. */
+int fa_device_trim(uint64_t *held_bytes);
 int fa_device_count(int *count);
 int fa_set_device(int device);            /* one process per GPU: call once per rank */
 

@@ -19,6 +19,7 @@ try:
         Position,
         Sketch,
         device_count,
+        device_trim,
         set_device,
     )
 except ImportError as exc:  # the compiled binding or libfastani_hip.so is missing: there is nothing to fall back to
@@ -30,6 +31,6 @@ except ImportError as exc:  # the compiled binding or libfastani_hip.so is missi
 
 __all__ = [
     "MAX_KMER_SIZE", "Hit", "Mapper", "MinimizerIndex", "MinimizerInfo", "Minimizers", "Position", "Sketch",
-    "GenomeBatch", "device_count", "set_device",
+    "GenomeBatch", "device_count", "device_trim", "set_device",
 ]
 __version__ = "0.2.0"

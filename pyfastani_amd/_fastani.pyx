@@ -61,6 +61,14 @@ def device_count():
     return n
 
 
+def device_trim():
+    """Return the device memory the library keeps for reuse (freed indices, batches, workspaces) to the runtime; returns the
+    number of bytes it held (``fa_device_trim``)."""
+    cdef uint64_t held = 0
+    _check(hip.fa_device_trim(&held))
+    return int(held)
+
+
 def set_device(int device):
     """Select the GPU for sketches and mappers created afterwards (one process per GPU: call once per rank)."""
     _check(hip.fa_set_device(device))
@@ -730,6 +738,58 @@ cdef class Sketch(_Parameterized):
         for i in range(n):
             for _ in range(n_short[i]):
                 warnings.warn("Sketch received a short contig relative to parameters, minimizers will not be added.", UserWarning)
+        return self
+
+    def flush(self):
+        """Sketch the contigs added so far on the device now (it happens by itself when the minimizers are first needed:
+        `index`, `minimizers`, pickling).  Releases the GIL; other threads may go on adding genomes -- their host work (reading,
+        packing) overlaps with the device work here, only the final append waits."""
+        cdef int64_t n = 0
+        cdef int code
+        with nogil:
+            code = hip.fa_sketch_num_minimizers(self._hs, &n)
+        _check(code)
+        return self
+
+    def add_fasta_stream(self, names, paths, int chunk=128, stats=None):
+        """`add_fasta_many` in chunks of `chunk` files with the device working behind the host: while the files of chunk c + 1 are
+        read and packed by the host pool, a second thread has the device sketch chunk c (`flush`).  Same sketch as one
+        `add_fasta_many` call; the reference-side half of a files-to-table run (``bench.py``: ``fasta_to_table``).  ``stats`` (a
+        dict) receives ``add_s`` (the `add_fasta_many` calls: reading, packing and the wait for a sketch in flight before the
+        append) and ``sketch_s`` (the `flush` calls on the second thread)."""
+        import threading
+        import time
+        names, paths = list(names), list(paths)
+        if len(names) != len(paths):
+            raise ValueError("names and paths differ in length")
+        chunk = max(1, chunk)
+        worker, failure = None, []
+        if stats is None:
+            stats = {}
+        stats.update(add_s=0.0, sketch_s=0.0, chunks=(len(paths) + chunk - 1) // chunk)
+
+        def sketch_pending():
+            t0 = time.perf_counter()
+            try:
+                self.flush()
+            except BaseException as exc:      # re-raised on the calling thread
+                failure.append(exc)
+            stats["sketch_s"] += time.perf_counter() - t0
+
+        for i in range(0, len(paths), chunk):
+            t0 = time.perf_counter()
+            self.add_fasta_many(names[i:i + chunk], paths[i:i + chunk])      # (its append waits for a flush in flight)
+            stats["add_s"] += time.perf_counter() - t0
+            if worker is not None:
+                worker.join()
+            if failure:
+                raise failure[0]
+            worker = threading.Thread(target=sketch_pending, name="pyfastani-amd-sketch", daemon=True)
+            worker.start()
+        if worker is not None:
+            worker.join()
+        if failure:
+            raise failure[0]
         return self
 
     cpdef Sketch clear(self):

@@ -56,6 +56,7 @@ _P = C.POINTER
 SIGNATURES = {
     "fa_last_error": (C.c_char_p, []),
     "fa_version": (_i32, []),
+    "fa_device_trim": (_i32, [_P(C.c_uint64)]),
     "fa_device_count": (_i32, [_P(_i32)]),
     "fa_set_device": (_i32, [_i32]),
     "fa_recommended_window_size": (_i32, [_f64, _i32, _i32, _f32, _i32, _u64, _P(_i32)]),

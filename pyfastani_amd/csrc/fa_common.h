@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 #include "fa_error.h"
 
@@ -20,35 +25,104 @@ inline void hip_check(hipError_t e, const char *what, const char *file, int line
 }
 #define FA_HIP(x) ::fa::hip_check((x), #x, __FILE__, __LINE__)
 
+// Device memory that is handed back is kept, not freed (round 5).  A mapper life cycle allocates and frees tens of GB in a few
+// dozen blocks (a 4 x 10^8-record index: 33 GB; its build: 10 GB of temporaries), and on this runtime memory that comes back from
+// hipFree is scrubbed before it is handed out again: the SECOND index build of a process took 0.90 s where the first took 0.07
+// (FA_TRACE=1: alloc 0.3 -> 255 ms, and every kernel that ran next to the scrubbing 5-10 x slower; profiles/r05_trace_index.txt) --
+// that, not the sort, was the 0.58 s `index_build_s` of the config-3 leg.  Blocks are kept per device in size classes (four per
+// octave: at most a quarter of a block is slack) and reused by the next request of their class.  `release` synchronises the
+// device before the block can be handed out again -- what hipFree did implicitly, and what callers of `ensure` / `release`
+// relied on.  The pool holds at most FA_POOL_MAX_GB (default 96) and gives everything back when an allocation fails.
+class DevPool {
+ public:
+  static DevPool &get() { static DevPool *p = new DevPool(); return *p; }
+  static size_t class_of(size_t bytes) {
+    if (bytes <= 4096) return 4096;
+    int lg = 63 - __builtin_clzll((unsigned long long)(bytes - 1));   // 2^lg < bytes <= 2^(lg+1)
+    const size_t q = (size_t)1 << (lg > 2 ? lg - 2 : 0);                 // a quarter of the octave
+    return (bytes + q - 1) / q * q;
+  }
+  void *alloc(size_t bytes, size_t &got) {
+    got = class_of(std::max<size_t>(bytes, 1));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      auto it = free_.find({dev, got});
+      if (it != free_.end() && !it->second.empty()) {
+        void *p = it->second.back();
+        it->second.pop_back();
+        held_ -= got;
+        return p;
+      }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, got);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); trim(); e = hipMalloc(&p, got); }
+    hip_check(e, "hipMalloc", __FILE__, __LINE__);
+    return p;
+  }
+  void free(void *p, size_t got) {
+    if (!p) return;
+    (void)hipDeviceSynchronize();                                     // (hipFree's implicit barrier: nothing in flight reads the block)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (held_ + got <= max_held_) { free_[{dev, got}].push_back(p); held_ += got; return; }
+    }
+    (void)hipFree(p);
+  }
+  // everything the pool holds back to the runtime
+  void trim() {
+    std::map<std::pair<int, size_t>, std::vector<void *>> all;
+    { std::lock_guard<std::mutex> lk(mu_); all.swap(free_); held_ = 0; }
+    for (auto &kv : all) for (void *p : kv.second) (void)hipFree(p);
+  }
+  size_t held() { std::lock_guard<std::mutex> lk(mu_); return held_; }
+
+ private:
+  DevPool() {
+    const char *e = getenv("FA_POOL_MAX_GB");
+    const double gb = e ? atof(e) : 96.0;
+    max_held_ = gb <= 0 ? 0 : (size_t)(gb * 1024.0 * 1024.0 * 1024.0);
+  }
+  std::mutex mu_;
+  std::map<std::pair<int, size_t>, std::vector<void *>> free_;
+  size_t held_ = 0, max_held_ = 0;
+};
+
 // Owning device array with geometric growth; contents are preserved on growth only when asked.
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
+  size_t block = 0;      // bytes of the pool block behind p
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), block(o.block) { o.p = nullptr; o.cap = 0; o.block = 0; }
   DevBuf &operator=(DevBuf &&o) noexcept {
-    if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; }
+    if (this != &o) { release(); p = o.p; cap = o.cap; block = o.block; o.p = nullptr; o.cap = 0; o.block = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr; cap = 0;
+    if (p) DevPool::get().free(p, block);
+    p = nullptr; cap = 0; block = 0;
   }
   void ensure(size_t n, bool keep = false, hipStream_t stream = nullptr, size_t used = 0) {
     if (n <= cap) return;
     size_t ncap = keep ? std::max(n, cap + cap / 2) : n;
-    T *np = nullptr;
-    FA_HIP(hipMalloc((void **)&np, std::max<size_t>(ncap, 1) * sizeof(T)));
+    size_t got = 0;
+    T *np = (T *)DevPool::get().alloc(std::max<size_t>(ncap, 1) * sizeof(T), got);
     if (keep && p && used) {
-      FA_HIP(hipMemcpyAsync(np, p, used * sizeof(T), hipMemcpyDeviceToDevice, stream));
-      FA_HIP(hipStreamSynchronize(stream));
+      hipError_t e = hipMemcpyAsync(np, p, used * sizeof(T), hipMemcpyDeviceToDevice, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) { DevPool::get().free(np, got); hip_check(e, "copy on growth", __FILE__, __LINE__); }
     }
-    if (p) (void)hipFree(p);
-    p = np; cap = ncap;
+    if (p) DevPool::get().free(p, block);
+    p = np; cap = got / sizeof(T); block = got;                    // (the whole block is usable: fewer regrowths)
   }
   void upload(const T *src, size_t n, hipStream_t stream) {
     ensure(n);

@@ -255,7 +255,23 @@ struct fa_sketch {
     store.upload(pending, stream);
     tr.mark("upload", stream);
     const int64_t nseq_all = (int64_t)pending.seq_off.size();
-    const int64_t chunk_positions = 96LL << 20;   // staging is 8 B per k-mer position: <= 768 MiB per chunk
+    // staging is 8 B per k-mer position; a chunk takes an eighth of the free HBM at most (96 M positions = 768 MiB at least):
+    // a thousand genomes are a handful of chunks on a 288 GB device, not fifty with two synchronisations each
+    size_t hbm_free = 0, hbm_total = 0;
+    if (hipMemGetInfo(&hbm_free, &hbm_total) != hipSuccess) { (void)hipGetLastError(); hbm_free = 0; }
+    const int64_t chunk_positions = std::max<int64_t>(96LL << 20, std::min<int64_t>((int64_t)(hbm_free / 8 / 8), 4LL << 30));
+    // the records are appended chunk by chunk: reserve for all of them once (2 / (w + 1) of the positions are minimizers, a
+    // quarter of headroom; `ensure(keep)` below still grows the arrays if a sequence is denser) instead of regrowing -- and
+    // copying -- them a dozen times
+    {
+      int64_t positions_all = 0;
+      for (int64_t q = 0; q < nseq_all; q++) positions_all += pending.seq_len[q];
+      const double per_pos = P.alphabet_size == 4 ? 2.0 / (P.window_size + 1) : 1.0;
+      const size_t expect = (size_t)nrec + (size_t)((double)positions_all * std::min(1.0, per_pos * 1.25)) + 1024;
+      rec_hash.ensure(expect, true, stream, (size_t)nrec);
+      rec_seq.ensure(expect, true, stream, (size_t)nrec);
+      rec_wpos.ensure(expect, true, stream, (size_t)nrec);
+    }
     int64_t s0 = 0;
     DevBuf<int32_t> d_seq_tile_lo, d_drop, d_drop_off, d_seq_ids;
     while (s0 < nseq_all) {
@@ -265,12 +281,23 @@ struct fa_sketch {
       while (s1 < nseq_all && (s1 == s0 || positions + pending.seq_len[s1] <= chunk_positions)) { positions += pending.seq_len[s1]; s1++; }
       // (tiles whose positions + halo are whole hashing trips: k1_tile_len)
       const int tile_len = k1_tile_len(P.window_size);
+      // (five million tiles for a thousand genomes: counted first, then filled by the host pool -- 91 ms of one thread before)
+      int64_t tile_total = 0;
       for (int64_t q = s0; q < s1; q++) {
-        seq_tile_lo.push_back((int32_t)tiles.size());
-        make_tiles(tiles, pending, pending.seq_off[q], pending.seq_len[q], (int)(q - s0), P.kmer_size, P.window_size, tile_len);
+        seq_tile_lo.push_back((int32_t)tile_total);
+        tile_total += tile_count(pending.seq_len[q], P.kmer_size, tile_len);
         seq_ids.push_back(pending_contig[q]);
       }
-      seq_tile_lo.push_back((int32_t)tiles.size());
+      seq_tile_lo.push_back((int32_t)tile_total);
+      FA_REQUIRE(tile_total < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "too many tiles in one sketch chunk");
+      tiles.resize((size_t)tile_total);
+      {
+        const int64_t nq = s1 - s0, per = std::max<int64_t>(1, nq / 512);       // (a few hundred tasks at most)
+        HostPool::get().parallel_for((size_t)((nq + per - 1) / per), [&](size_t t) {
+          for (int64_t q = s0 + (int64_t)t * per; q < std::min(s1, s0 + ((int64_t)t + 1) * per); q++)
+            make_tiles_at(tiles.data() + seq_tile_lo[(size_t)(q - s0)], pending, pending.seq_off[q], pending.seq_len[q], (int)(q - s0), P.kmer_size, P.window_size, tile_len);
+        });
+      }
       const int nseq = (int)(s1 - s0), ntiles = (int)tiles.size();
       tr.mark("host_tiles", stream);
       if (ntiles > 0) {
@@ -1203,8 +1230,13 @@ struct QueryPass {
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       static const bool l1_block_sort_on = !(getenv("FA_L1_BLOCK_SORT") && atoi(getenv("FA_L1_BLOCK_SORT")) == 0);
       static const bool l1_stats = getenv("FA_L1_STATS") && atoi(getenv("FA_L1_STATS")) != 0;
-      // FA_L1_NEAR=0: every hit fetches its padded global coordinate (the round-4 form; A/B of the HBM fetch)
-      static const bool l1_near_on = !(getenv("FA_L1_NEAR") && atoi(getenv("FA_L1_NEAR")) == 0);
+      // Hits that cannot be an end of a candidate skip the fetch of their padded global coordinate (k_l1, scan_run<., NEAR>).  The
+      // hits it saves are the chance hits, whose number grows with the index (~500 per fragment at 4 x 10^8 records, ~50 at
+      // 4 x 10^7), and it costs a second LDS read per hit: lookup + L1 70.8 -> 67.0 ms per step on 1000 x 1000 genomes, 28.6 ->
+      // 28.6 on 500 x 500, 10.1 -> 10.6 on 200 x 200 (profiles/r05_l1_near_time.txt) -- so it is on from 3 x 10^8 records.
+      // FA_L1_NEAR = 0 / 1: never / always (the A/B of the HBM fetch: profiles/r05_l1_near_fetch.txt).
+      static const int l1_near_env = getenv("FA_L1_NEAR") ? atoi(getenv("FA_L1_NEAR")) : -1;
+      const bool l1_near_on = l1_near_env < 0 ? m.N >= 300000000LL : l1_near_env != 0;
       a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
@@ -1740,11 +1772,13 @@ static void fill_genomes(fa_genomes *g, const fa_params &P, hipStream_t st, cons
   // pass 2: fragments, tiles and per-genome bookkeeping, in contig order, written straight into the image
   Tile *tiles = (Tile *)(img + o_tiles);
   int32_t *frag_query = (int32_t *)(img + o_fq), *frag_qseq = (int32_t *)(img + o_fs), *tf = (int32_t *)(img + o_tf);
-  g->frag_tile_lo.reserve((size_t)F + 1);
-  std::vector<Tile> scratch;
+  // (the bookkeeping per contig on this thread, the per-fragment tables and tiles by the host pool: 1.7 M fragments and 5 M
+  // tiles for a thousand genomes were one thread's loop)
+  struct ContigJob { int64_t si, nfrag, nf0, q0; int32_t gi; };
+  std::vector<ContigJob> jobs;
   int32_t cur = 0;
   size_t used = 0;
-  int64_t nf = 0, nt = 0;
+  int64_t nf = 0;
   for (int64_t c = 0; c < n_contigs; c++) {
     int32_t gi = contig_genome ? contig_genome[c] : 0;
     FA_REQUIRE(gi >= cur && gi < n_genomes, FA_ERR_INVALID, "contig_genome must be non-decreasing and < n_genomes");
@@ -1753,25 +1787,29 @@ static void fill_genomes(fa_genomes *g, const fa_params &P, hipStream_t st, cons
     if (len < min_len) { g->n_short[gi]++; continue; }               // _fastani.pyx:1061-1070
     const int64_t nfrag = len / frag;                                 // :1097
     if (nfrag > 0) {
-      const int64_t si = (int64_t)used++;
-      for (int64_t i = 0; i < nfrag; i++) {
-        g->frag_tile_lo.push_back((int32_t)nt);
-        scratch.clear();
-        make_tiles(scratch, hs, hs.seq_off[si] + i * frag, frag, (int)nf, P.kmer_size, P.window_size);
-        for (const Tile &t : scratch) tiles[nt++] = t;
-        frag_qseq[nf] = (int32_t)(g->total_fragments[gi] + i);        // :985
-        frag_query[nf] = gi;
-        nf++;
-      }
+      jobs.push_back(ContigJob{(int64_t)used++, nfrag, nf, (int64_t)g->total_fragments[gi], gi});   // querySeqId = fragments before + i, :985
+      nf += nfrag;
     }
     g->total_fragments[gi] += (uint64_t)nfrag;                        // :1104
     g->total_length[gi] += (uint64_t)len;                             // :1105
     g->total_bases += (uint64_t)(nfrag * frag);
   }
+  g->frag_tile_lo.assign((size_t)F + 1, 0);
+  HostPool::get().parallel_for(jobs.size(), [&](size_t j) {
+    const ContigJob &cj = jobs[j];
+    for (int64_t i = 0; i < cj.nfrag; i++) {
+      const int64_t f = cj.nf0 + i;
+      g->frag_tile_lo[(size_t)f] = (int32_t)(f * tiles_per_frag);
+      make_tiles_at(tiles + f * tiles_per_frag, hs, hs.seq_off[cj.si] + i * frag, frag, (int)f, P.kmer_size, P.window_size);
+      frag_qseq[f] = (int32_t)(cj.q0 + i);
+      frag_query[f] = cj.gi;
+    }
+  });
+  const int64_t nt = nf * tiles_per_frag;
   while (cur < n_genomes) { cur++; g->genome_frag_lo[cur] = nf; }
   FA_REQUIRE(nf == F && nt == ntiles, FA_ERR_INTERNAL, "fragment / tile count mismatch while building the batch image");
   g->F = F;
-  g->frag_tile_lo.push_back((int32_t)nt);
+  g->frag_tile_lo[(size_t)F] = (int32_t)nt;
   g->ntiles = ntiles;
   memcpy(img + o_ftl, g->frag_tile_lo.data(), ((size_t)F + 1) * 4);
   for (int i = 0; i < n_genomes; i++) tf[i] = (int32_t)g->total_fragments[i];
@@ -1844,6 +1882,12 @@ extern "C" {
 
 const char *fa_last_error(void) { return g_last_error.c_str(); }
 int fa_version(void) { return 100; }
+int fa_device_trim(uint64_t *held_bytes) {
+  return guarded([&] {
+    if (held_bytes) *held_bytes = (uint64_t)DevPool::get().held();
+    DevPool::get().trim();
+  });
+}
 
 int fa_device_count(int *count) {
   int n = 0;
@@ -1988,8 +2032,10 @@ int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int6
 int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_paths, int64_t *n_records, int64_t *n_short) {
   return guarded([&] {
     FA_REQUIRE(paths && n_paths >= 0, FA_ERR_INVALID, "null paths or negative count");
+    StageTrace tr("add_fasta_many");
     std::vector<PackedFasta> files;
     read_fasta_packed_many(paths, (size_t)n_paths, s->P.alphabet_size != 4, files);
+    tr.mark("read_pack", nullptr);
     std::lock_guard<std::mutex> lock(s->mtx);
     bind_device(s->device);
     // staged in locals, committed after the store has taken the records (as fa_sketch_add_fasta)
@@ -2020,7 +2066,9 @@ int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_p
     s->pending_contig.reserve(s->pending_contig.size() + contig_ids.size());
     s->lengths.reserve(s->lengths.size() + lengths.size());
     s->seqs_by_file.reserve(s->seqs_by_file.size() + by_file.size());
+    tr.mark("bookkeeping", nullptr);
     if (!refs.empty()) append_packed(s->pending, refs.data(), (int64_t)refs.size());
+    tr.mark("place", nullptr);
     s->pending_contig.insert(s->pending_contig.end(), contig_ids.begin(), contig_ids.end());
     s->counter = counter;
     s->lengths.insert(s->lengths.end(), lengths.begin(), lengths.end());

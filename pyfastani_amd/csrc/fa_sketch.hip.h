@@ -116,16 +116,41 @@ inline void make_tiles(std::vector<Tile> &tiles, const HostStore &hs, int64_t of
 
 // Positions per tile of REFERENCE sketching (round 5).  A workgroup hashes its tile's positions PLUS a halo of 2w - 2 in
 // front of it in trips of SK_THREADS: a full tile of 1 024 positions behind a 46-position halo (w = 24) is 1 070 hashes = FIVE
-// trips, the last one 18 % full -- a fifth of the hashing loop (82 % of the kernel's instructions) for 4 % of the positions.
-// TILE - (2w - 2) positions per tile make it four full trips: 4.7 % more tiles, 20 % fewer hashing instructions each.  (Half
-// tiles, asked for to even out the last resident round of a one-genome launch, buy nothing beyond that: rounds x trips is
-// 3 x 4 for 976-position tiles, 4 x 3 for 722, 6 x 2 for 466 -- 12 either way, against 3 x 5 for the full tile.)  Query
-// fragments keep whole tiles: 2 985 positions do not fit three four-trip tiles (2 980), and a fourth tile costs more than the
-// fifth trip.  FA_K1_TILE = 1024 restores the full tile (A/B).
+// trips, the last one a single wave's worth.  TILE - (2w - 2) positions per tile make it four full trips at 4.7 % more tiles.
+// Measured (profiles/r05_k1_tiles.txt): 142.4 -> 144.9 G bases/s on one 5 Mb genome, 179.1 -> 180.4 on forty -- the fifth trip
+// only ever ran on one of the four waves, so this is a per cent, not the fifth of the hashing loop its trip count suggests.
+// (Half tiles, asked for to even out the last resident round of a one-genome launch, buy nothing on top: rounds x trips is
+// 3 x 4 for 976-position tiles, 4 x 3 for 722, 6 x 2 for 466.)  Query fragments keep whole tiles: 2 985 positions do not fit
+// three four-trip tiles (2 980), and a fourth tile costs more than the fifth trip.  FA_K1_TILE = 1024 restores the full tile (A/B).
 inline int k1_tile_len(int w) {
   static const int forced = [] { const char *e = getenv("FA_K1_TILE"); const int x = e ? atoi(e) : 0; return (x >= 256 && x <= TILE && x % 4 == 0) ? x : 0; }();
   if (forced) return forced;
   return std::max(256, (TILE - (2 * w - 2)) & ~3);
+}
+
+// the same into place: `dst` holds tile_count(len, k, tile_len) tiles (the tile lists of many sequences are filled concurrently)
+inline int64_t tile_count(int64_t len, int k, int tile_len = TILE) {
+  const int64_t npos_total = len - k + 1;
+  return npos_total <= 0 ? 0 : (npos_total + tile_len - 1) / tile_len;
+}
+inline void make_tiles_at(Tile *dst, const HostStore &hs, int64_t off, int64_t len, int seq, int k, int w, int tile_len = TILE) {
+  const int64_t npos_total = len - k + 1;
+  if (npos_total <= 0) return;
+  for (int64_t p0 = 0; p0 < npos_total; p0 += tile_len) {
+    Tile t;
+    t.base = off; t.seq_len = (int32_t)len; t.pos0 = (int32_t)p0;
+    t.npos = (int32_t)std::min<int64_t>(tile_len, npos_total - p0);
+    t.seq = seq; t.exc_lo = 0; t.exc_n = 0;
+    if (!hs.exc_pos.empty()) {
+      int64_t hb = std::min<int64_t>(p0, 2 * (int64_t)w - 2);
+      int64_t lo = off + p0 - hb, hi = off + p0 + t.npos + k - 1;
+      auto a = std::lower_bound(hs.exc_pos.begin(), hs.exc_pos.end(), lo);
+      auto b = std::lower_bound(a, hs.exc_pos.end(), hi);
+      t.exc_lo = (int32_t)(a - hs.exc_pos.begin());
+      t.exc_n = (int32_t)(b - a);
+    }
+    *dst++ = t;
+  }
 }
 
 // ----------------------------------------------------------------------------------------------------------

@@ -39,6 +39,7 @@ cdef extern from "fastani_hip.h" nogil:
 
     const char* fa_last_error()
     int fa_version()
+    int fa_device_trim(uint64_t* held_bytes)
     int fa_device_count(int* count)
     int fa_set_device(int device)
 

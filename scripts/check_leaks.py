@@ -8,6 +8,7 @@ from pyfastani_amd import synthetic as syn
 
 def used():
     torch.cuda.synchronize()
+    pf.device_trim()                      # (freed blocks are kept for reuse: what the pool holds is not a leak)
     free, total = torch.cuda.mem_get_info()
     return (total - free) / 2**20
 

@@ -39,6 +39,45 @@ def test_add_fasta_counts_records_and_short_contigs(tmp_path):
     assert sk.names == ["genome"] and len(w) == 1 and "short" in str(w[0].message)
 
 
+def test_add_fasta_many_counts_like_add_fasta(tmp_path):
+    # fa_sketch_add_fasta_many: every file read + packed by its own host task, one genome per file in the order given; names,
+    # short-contig warnings and errors as n calls of add_fasta (host side only: no device needed until the sketch is flushed)
+    import warnings
+    import pyfastani_amd as pf
+    body = (b"ACGTTGCA" * 10 + b"\n") * 400
+    paths = [write(tmp_path, f"g{i}.fna", b">c1\n" + body + (b">c2 short\nACGT\n" if i % 2 else b"") + b">c3\n" + body) for i in range(5)]
+    sk = pf.Sketch()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert sk.add_fasta_many([f"n{i}" for i in range(5)], paths) is sk
+    assert sk.names == [f"n{i}" for i in range(5)] and len(w) == 2 and all("short" in str(x.message) for x in w)
+    with pytest.raises(ValueError):
+        sk.add_fasta_many(["a"], paths[:2])
+    with pytest.raises(OSError):
+        sk.add_fasta_many(["a", "b"], [paths[0], str(tmp_path / "missing.fna")])
+    assert sk.names == [f"n{i}" for i in range(5)]                      # a failed call adds nothing
+    assert sk.add_fasta_many([], []).names == sk.names
+
+
+def test_host_pieces_against_their_definition():
+    """The host-only pieces of the library -- the 2-bit packer, the FASTA readers (the one-sweep reader of round 5 against
+    the byte-by-byte definition of the store on 40 random files, prefixes of records, protein), the statistics tables, the
+    workspace lease -- built from the same headers with AddressSanitizer + UBSan and run (scripts/host_sanitize/driver.cpp)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    from conftest import ROOT
+    out = os.path.join(ROOT, "build", "host_sanitize")
+    os.makedirs(out, exist_ok=True)
+    exe = os.path.join(out, "driver_pytest")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-pthread",
+                    os.path.join(ROOT, "scripts", "host_sanitize", "driver.cpp"), "-o", exe], check=True, capture_output=True, text=True)
+    for env in ({"FA_HOST_THREADS": "8"}, {"FA_HOST_THREADS": "3", "FA_NO_AVX2": "1"}):
+        res = subprocess.run([exe], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0 and "all checks passed" in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
+
+
 def test_crlf_is_kept_like_the_reference(tmp_path):
     # only the '\n' is stripped (_fasta.pyx:95-96): a carriage return stays in the id and in the sequence
     recs = list(Parser(write(tmp_path, "crlf.fa", b">id\r\nAC\r\nGT\r\n")))

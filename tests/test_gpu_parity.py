@@ -1088,6 +1088,9 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         many = pf.Sketch().add_fasta_many(range(len(files)), files)
         assert all(np.array_equal(x, y) for x, y in zip(many._read_minimizers(), a))
         assert many.names == [0, 1, 2]
+        stats = {}
+        streamed_refs = pf.Sketch().add_fasta_stream(range(len(files)), files, chunk=1, stats=stats)   # the device sketches chunk c while c + 1 is read
+        assert all(np.array_equal(x, y) for x, y in zip(streamed_refs._read_minimizers(), a)) and stats["chunks"] == 3 and stats["sketch_s"] > 0
         m3 = many.index()
         for chunk in (1, 2, 5):
             streamed = {}

@@ -334,3 +334,42 @@ def test_strong_scaling_step_world2(tmp_path):
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout + res.stderr
     assert (tmp_path / "rank0.ok").read_text() == "18" and (tmp_path / "rank1.ok").read_text() == "18"
+
+
+def test_forced_collectives_at_world_size_one(tmp_path):
+    """FA_FORCE_DIST=1 with an initialised process group makes a single rank take every exchange instead of skipping it (the
+    switch the 1-GPU RCCL tests use, tests/test_gpu_rccl.py): here over gloo, on fabricated rows -- the strong-scaling step's
+    table and the frequency exchange give what the collective-free paths give, and without the switch (or without a process
+    group) nothing is exchanged."""
+    import ctypes
+    import torch
+    import torch.distributed as dist
+    assert not sharding.collectives_on(1) and sharding.collectives_on(2)
+    os.environ["FA_FORCE_DIST"] = "1"
+    try:
+        assert not sharding.collectives_on(1)                          # no process group yet
+        dist.init_process_group("gloo", init_method=f"file://{tmp_path}/rdzv", rank=0, world_size=1)
+        assert sharding.collectives_on(1)
+        rows = np.array([(0, 1, 5, 10, 91.5), (1, 0, 7, 10, 88.25)], dtype=ROW_DTYPE)
+
+        class Batch:
+            def query_rows_device(self, first, count, ptr, cap):
+                ctypes.memmove(ptr, rows.ctypes.data, rows.nbytes)
+                return len(rows)
+        forced = sharding.ResidentHitTable([3, 8], 4, 1, comm_device="cpu", table_device="cpu")
+        plain = sharding.ResidentHitTable([3, 8], 4, 1, comm_device="cpu", table_device="cpu", collective=False)
+        assert forced.out is not None and plain.out is None
+        a, b = sharding.ResidentHitTable.rows_of(forced.step(Batch())), sharding.ResidentHitTable.rows_of(plain.step(Batch()))
+        assert a.tobytes() == b.tobytes() and a["query_id"].tolist() == [3, 8] and len(forced.exchange_marks) == 1
+        keys = torch.tensor([5, -3, 77, 5000], dtype=torch.int32)
+        counts = torch.tensor([4, 1, 9, 2], dtype=torch.int64)
+        thr_f, drop_f = sharding.global_frequency(keys, counts, 1)
+        os.environ["FA_FORCE_DIST"] = "0"
+        thr_p, drop_p = sharding.global_frequency(keys, counts, 1)
+        assert thr_f == thr_p and torch.equal(drop_f, drop_p)
+        g = sharding.tensor_to_rows(sharding.all_gather_rows(sharding.rows_to_tensor(rows)))
+        assert g.tobytes() == rows.tobytes()
+    finally:
+        os.environ.pop("FA_FORCE_DIST", None)
+        if dist.is_initialized():
+            dist.destroy_process_group()
