@@ -2036,6 +2036,11 @@ int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_p
     std::vector<PackedFasta> files;
     read_fasta_packed_many(paths, (size_t)n_paths, s->P.alphabet_size != 4, files);
     tr.mark("read_pack", nullptr);
+    if (tr.on) {
+      FastaTaskClock &c = fasta_task_clock();
+      fprintf(stderr, "[fa trace] fasta tasks so far: %llu files, per-task sums: read %.1f ms, record search %.1f ms, pack %.1f ms\n", (unsigned long long)c.files.load(),
+              c.read_ns.load() * 1e-6, c.scan_ns.load() * 1e-6, c.pack_ns.load() * 1e-6);
+    }
     std::lock_guard<std::mutex> lock(s->mtx);
     bind_device(s->device);
     // staged in locals, committed after the store has taken the records (as fa_sketch_add_fasta)

@@ -12,7 +12,9 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -195,10 +197,42 @@ inline void read_fasta_records(const char *path, std::vector<FastaSeq> &seqs) {
 // file-relative base offsets.  Record semantics as FastaFile (src/pyfastani/_fasta.pyx:41-103).  Protein files keep their
 // upper-cased bytes.
 // ----------------------------------------------------------------------------------------------------------
+// One anonymous mapping handed out in slices: the packed words of MANY files.  A fresh 1.3 MB block per file had made the first
+// call of a process three to four times slower than its steady state (1 000 mmaps + 3 x 10^5 page faults of 4 KB under 25
+// threads, every one a visit to the address space's lock: per-task sums of 3.8 ms read + 2.0 ms pack per 5 MB file against 2 ms
+// all in all once the allocator was warm); the arena is one mapping, 2 MB aligned so that transparent huge pages serve it.
+struct HostArena {
+  char *raw = nullptr, *base = nullptr;
+  size_t raw_bytes = 0, bytes = 0;
+  std::atomic<size_t> used{0};
+  explicit HostArena(size_t n) {
+    const size_t huge = (size_t)2 << 20;
+    bytes = (n + huge - 1) / huge * huge;
+    raw_bytes = bytes + huge;
+    void *p = mmap(nullptr, raw_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (p == MAP_FAILED) throw Error(FA_ERR_NOMEM, "mmap of the packing arena failed");
+    raw = (char *)p;
+    base = (char *)(((uintptr_t)raw + huge - 1) / huge * huge);
+    (void)madvise(base, bytes, MADV_HUGEPAGE);
+  }
+  HostArena(const HostArena &) = delete;
+  HostArena &operator=(const HostArena &) = delete;
+  ~HostArena() { if (raw) munmap(raw, raw_bytes); }
+  // n bytes on a 64-byte boundary, or nullptr when the arena is used up (the caller allocates for itself then)
+  void *take(size_t n) {
+    n = (n + 63) / 64 * 64;
+    const size_t at = used.fetch_add(n);
+    return at + n <= bytes ? base + at : nullptr;
+  }
+};
+
 struct PackedFasta {
   bool protein = false;
-  std::unique_ptr<uint32_t[]> words;   // nucleotide: 16 bases per word (A=0 C=1 G=2 T=3; anything else 0 + an exception)
-  std::unique_ptr<uint8_t[]> bytes;    // protein: upper-cased residues
+  uint32_t *words = nullptr;           // nucleotide: 16 bases per word (A=0 C=1 G=2 T=3; anything else 0 + an exception)
+  uint8_t *bytes = nullptr;            // protein: upper-cased residues
+  std::unique_ptr<uint32_t[]> own_words;   // (the arrays above live here, or in a slice of `arena`)
+  std::unique_ptr<uint8_t[]> own_bytes;
+  std::shared_ptr<HostArena> arena;
   std::vector<int64_t> rec_off;        // first base of every record in the arrays above (a multiple of 64)
   std::vector<int64_t> rec_len;        // bases of every record
   std::vector<int64_t> exc_pos;        // ascending, relative to the file's arrays
@@ -323,16 +357,65 @@ inline int64_t pack_body_scalar(const uint8_t *data, size_t b0, size_t b1, uint3
 
 }  // namespace fasta_detail
 
-inline void read_fasta_packed(const char *path, bool protein, PackedFasta &out) {
+// (FA_TRACE: where a file's task spends its time, summed over the tasks -- nanoseconds of reading, record search, packing)
+struct FastaTaskClock { std::atomic<uint64_t> read_ns{0}, scan_ns{0}, pack_ns{0}, files{0}; };
+inline FastaTaskClock &fasta_task_clock() { static FastaTaskClock c; return c; }
+
+// The bytes of a file for the one-sweep reader, with 64 readable zero bytes behind them: read() into the thread's buffer, or --
+// FA_FASTA_IO=mmap -- the file mapped over the front of an anonymous reservation one page longer than the file (the page
+// behind the last file page is the reservation's own zero page, so the 32-byte loads of the packer may run past the end).
+struct FileBytes {
+  const char *data = nullptr;
+  size_t size = 0;
+  void *map = nullptr;
+  size_t map_len = 0;
+  FileBytes() = default;
+  FileBytes(const FileBytes &) = delete;
+  FileBytes &operator=(const FileBytes &) = delete;
+  ~FileBytes() { if (map) munmap(map, map_len); }
+  void open(const char *path) {
+    static const bool use_mmap = [] { const char *e = getenv("FA_FASTA_IO"); return e && std::string(e) == "mmap"; }();
+    if (!use_mmap) {
+      std::vector<char> &buf = fasta_detail::io_buffer();
+      size = fasta_detail::slurp(path, buf);
+      data = buf.data();
+      return;
+    }
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) throw Error(FA_ERR_IO, std::string(path) + ": " + strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0) { const int e = errno; ::close(fd); throw Error(FA_ERR_IO, std::string(path) + ": " + strerror(e)); }
+    if (S_ISDIR(st.st_mode)) { ::close(fd); throw Error(FA_ERR_IO, std::string(path) + ": is a directory"); }
+    size = (size_t)st.st_size;
+    const size_t page = 4096;
+    map_len = (size + page - 1) / page * page + page;
+    void *r = mmap(nullptr, map_len, PROT_READ, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (r == MAP_FAILED) { ::close(fd); throw Error(FA_ERR_NOMEM, std::string(path) + ": mmap (reservation) failed"); }
+    map = r;
+    if (size > 0) {
+      void *p = mmap(r, size, PROT_READ, MAP_PRIVATE | MAP_FIXED | MAP_POPULATE, fd, 0);
+      if (p == MAP_FAILED) { const int e = errno; ::close(fd); throw Error(FA_ERR_IO, std::string(path) + ": mmap: " + strerror(e)); }
+    }
+    ::close(fd);
+    data = (const char *)r;
+  }
+};
+
+inline void read_fasta_packed(const char *path, bool protein, PackedFasta &out, const std::shared_ptr<HostArena> &arena = nullptr) {
   using namespace fasta_detail;
-  std::vector<char> &buf = io_buffer();
-  const size_t size = slurp(path, buf);
+  static const bool timed = getenv("FA_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  FileBytes fb;
+  fb.open(path);
+  const size_t size = fb.size;
+  const auto t1 = std::chrono::steady_clock::now();
   FastaFile f;
-  f.attach(buf.data(), size);
+  f.attach(fb.data, size);
   std::vector<FastaFile::Span> spans;
   FastaFile::Span sp;
   size_t body_bytes = 0;
   while (f.next_span(sp)) { spans.push_back(sp); body_bytes += sp.body_end - sp.body; }
+  const auto t2 = std::chrono::steady_clock::now();
   out = PackedFasta();
   out.protein = protein;
   out.file_bytes = size;
@@ -340,12 +423,13 @@ inline void read_fasta_packed(const char *path, bool protein, PackedFasta &out) 
   // (an upper bound that needs no counting sweep: a body holds at most as many bases as bytes, and every record is padded
   //  to 64 bases)
   const size_t cap_bases = body_bytes + 64 * spans.size() + 64;
-  const uint8_t *data = (const uint8_t *)buf.data();
+  const uint8_t *data = (const uint8_t *)fb.data;
   int64_t at = 0;
   if (protein) {
-    out.bytes.reset(new uint8_t[cap_bases]);
+    out.bytes = arena ? (uint8_t *)arena->take(cap_bases) : nullptr;
+    if (out.bytes) out.arena = arena; else { out.own_bytes.reset(new uint8_t[cap_bases]); out.bytes = out.own_bytes.get(); }
     for (const auto &s : spans) {
-      uint8_t *dst = out.bytes.get() + at;
+      uint8_t *dst = out.bytes + at;
       int64_t n = 0;
       size_t p = s.body;
       while (p < s.body_end) {
@@ -360,10 +444,11 @@ inline void read_fasta_packed(const char *path, bool protein, PackedFasta &out) 
       at += padded;
     }
   } else {
-    out.words.reset(new uint32_t[cap_bases / 16 + 4]);
+    out.words = arena ? (uint32_t *)arena->take((cap_bases / 16 + 4) * 4) : nullptr;
+    if (out.words) out.arena = arena; else { out.own_words.reset(new uint32_t[cap_bases / 16 + 4]); out.words = out.own_words.get(); }
     const bool avx2 = host_has_avx2();
     for (const auto &s : spans) {
-      uint32_t *dst = out.words.get() + at / 16;
+      uint32_t *dst = out.words + at / 16;
       const int64_t n = avx2 ? pack_body_avx2(data, s.body, s.body_end, dst, at, out.exc_pos, out.exc_val)
                              : pack_body_scalar(data, s.body, s.body_end, dst, at, out.exc_pos, out.exc_val);
       out.rec_off.push_back(at); out.rec_len.push_back(n);
@@ -372,13 +457,35 @@ inline void read_fasta_packed(const char *path, bool protein, PackedFasta &out) 
   }
   out.total = at;
   f.close();
+  if (timed) {
+    const auto t3 = std::chrono::steady_clock::now();
+    auto ns = [](auto a, auto b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+    FastaTaskClock &c = fasta_task_clock();
+    c.read_ns += ns(t0, t1); c.scan_ns += ns(t1, t2); c.pack_ns += ns(t2, t3); c.files++;
+  }
 }
+
+// (FA_FASTA_THREADS=all: every pool worker takes files; default: the pool's usual two dozen -- on tmpfs 128 readers spent 70 ms
+//  per 5 MB file inside read(), 25 readers 4 ms)
+inline bool fasta_heavy_pool() { static const bool v = [] { const char *e = getenv("FA_FASTA_THREADS"); return e && std::string(e) == "all"; }(); return v; }
 
 // Many files at once: one task per file on the pool (a file never waits for the one before it).
 inline void read_fasta_packed_many(const char *const *paths, size_t n, bool protein, std::vector<PackedFasta> &out) {
   out.clear();
   out.resize(n);
-  HostPool::get().parallel_for(n, [&](size_t i) { read_fasta_packed(paths[i], protein, out[i]); });
+  // one arena for the packed words of all files, sized from the file sizes (a body holds at most as many bases as bytes; 3 % and
+  // a page per file for the padding of records -- a file of very many tiny records that outgrows its share allocates for itself)
+  std::shared_ptr<HostArena> arena;
+  if (n > 1) {
+    size_t need = 0;
+    for (size_t i = 0; i < n; i++) {
+      struct stat st;
+      const size_t sz = stat(paths[i], &st) == 0 && st.st_size > 0 ? (size_t)st.st_size : 0;
+      need += (protein ? sz : sz / 4) + sz / 32 + 4096;
+    }
+    arena = std::make_shared<HostArena>(need);
+  }
+  HostPool::get().parallel_for(n, [&](size_t i) { read_fasta_packed(paths[i], protein, out[i], arena); }, fasta_heavy_pool());
 }
 
 
@@ -410,11 +517,11 @@ inline void place_packed(HostStore &hs, const PackedRef *refs, int64_t n, uint32
     const int64_t len = r.use_len, padded = (len + 63) / 64 * 64, src0 = r.file->rec_off[r.rec];
     if (hs.protein) {
       uint8_t *d = dst8 + at[q];
-      memcpy(d, r.file->bytes.get() + src0, (size_t)len);
+      memcpy(d, r.file->bytes + src0, (size_t)len);
       memset(d + len, 0, (size_t)(padded - len));
     } else {
       uint32_t *d = dst32 + at[q] / 16;
-      const uint32_t *src = r.file->words.get() + src0 / 16;
+      const uint32_t *src = r.file->words + src0 / 16;
       const int64_t whole = len / 16, rest = len % 16;
       memcpy(d, src, (size_t)whole * 4);
       int64_t w = whole;

@@ -47,7 +47,7 @@ int main(int argc, char **argv) {
   std::vector<const char *> cp;
   for (auto &p : paths) cp.push_back(p.c_str());
   HostPool::get();
-  double t_old = 1e30, t_new = 1e30, t_read = 1e30;
+  double t_old = 1e30, t_new = 1e30, t_read = 1e30, t_new_first = 0;
   uint64_t sum_old = 0, sum_new = 0;
   for (int rep = 0; rep < 3; rep++) {
     {
@@ -73,6 +73,7 @@ int main(int argc, char **argv) {
       for (auto &f : files) for (size_t r = 0; r < f.rec_len.size(); r++) refs.push_back(PackedRef{&f, (int64_t)r, f.rec_len[r]});
       append_packed(hs, refs.data(), (int64_t)refs.size());
       const double t2 = now();
+      if (rep == 0) t_new_first = t2 - t0;                            // (the first call of the process: cold allocator, cold threads)
       if (t2 - t0 < t_new) { t_new = t2 - t0; t_read = t1 - t0; }
       sum_new = 0; for (uint32_t w : hs.packed) sum_new = sum_new * 1000003ULL + w;
     }
@@ -80,7 +81,8 @@ int main(int argc, char **argv) {
   for (auto &p : paths) unlink(p.c_str());
   rmdir(dir.c_str());
   printf("{\"files\": %d, \"bytes\": %zu, \"host_threads\": %d, \"one_by_one_s\": %.4f, \"one_by_one_GBps\": %.2f, \"concurrent_s\": %.4f, \"concurrent_GBps\": %.2f, "
-         "\"concurrent_read_pack_s\": %.4f, \"concurrent_place_s\": %.4f, \"stores_equal\": %s}\n",
-         n, bytes, host_threads(), t_old, bytes / t_old / 1e9, t_new, bytes / t_new / 1e9, t_read, t_new - t_read, sum_old == sum_new ? "true" : "false");
+         "\"concurrent_read_pack_s\": %.4f, \"concurrent_place_s\": %.4f, \"concurrent_first_call_s\": %.4f, \"concurrent_first_call_GBps\": %.2f, \"stores_equal\": %s}\n",
+         n, bytes, host_threads(), t_old, bytes / t_old / 1e9, t_new, bytes / t_new / 1e9, t_read, t_new - t_read, t_new_first, bytes / t_new_first / 1e9,
+         sum_old == sum_new ? "true" : "false");
   return sum_old == sum_new ? 0 : 1;
 }
