@@ -36,3 +36,15 @@ def test_fuzz_against_oracle():
     assert res.returncode == 0, f"seed {seed}\n" + res.stdout[-3000:] + res.stderr[-3000:]
     assert "0 mismatches" in res.stdout and f"seed {seed}" in res.stdout
     assert int(res.stdout.strip().splitlines()[-1].split()[0]) == cases, res.stdout[-500:]
+
+
+def test_fuzz_with_the_coordinate_filter_of_large_indices_forced_on():
+    """k_l1 skips the coordinate fetch of hits that cannot be an end of a candidate only on indices of 3 x 10^8 records and
+    more (where it pays); FA_L1_NEAR=1 forces it onto the small indices of the fuzzer, so that its loci are compared with the
+    oracle's mapping for mapping -- chance hits, repeats, tandem duplications, minimum hit counts from 1 up."""
+    seed = (source_seed() ^ 0x5A5A5A) & 0x7FFFFFFF
+    cases = 250
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), str(cases), str(seed)],
+                         env=dict(os.environ, FA_L1_NEAR="1"), capture_output=True, text=True, timeout=2400)
+    assert res.returncode == 0, f"seed {seed}\n" + res.stdout[-3000:] + res.stderr[-3000:]
+    assert "0 mismatches" in res.stdout and int(res.stdout.strip().splitlines()[-1].split()[0]) == cases, res.stdout[-500:]
