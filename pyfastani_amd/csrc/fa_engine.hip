@@ -835,6 +835,17 @@ static uint32_t build_frag_order(const fa_genomes &g, int32_t g0, int64_t f0, in
   out.clear();
   int32_t q = g0;
   while (g.genome_frag_lo[q + 1] <= f0) q++;
+  if (g.genome_frag_lo[q + 1] >= f1) {
+    // ONE genome (round 5): its fragments in eight contiguous runs, one per XCD.  The loci of neighbouring fragments overlap by
+    // two thirds on every reference (a locus spans ~2.6 fragment lengths), so the workgroups of a run read the same index
+    // stretches -- from their XCD's L2 instead of the memory side, where the identity order (fragment b on XCD b mod 8)
+    // had put every neighbour on another XCD.
+    if (F < 64) return 0;
+    const int64_t run = (F + 7) / 8;
+    out.assign((size_t)run * 8, -1);
+    for (int64_t i = 0; i < F; i++) out[(size_t)((i % run) * 8 + i / run)] = (int32_t)i;
+    return (uint32_t)out.size();
+  }
   // offset of every fragment inside its genome, counting sort by it (stable: genomes stay in order inside a group)
   std::vector<int32_t> off((size_t)F);
   int32_t max_off = 0;
@@ -1143,7 +1154,8 @@ struct QueryPass {
   void prepare_order(Part &p) {
     Workspace &ln = p.ln;
     static const bool order_on = !(getenv("FA_FRAG_ORDER") && atoi(getenv("FA_FRAG_ORDER")) == 0);
-    if (!(order_on && NQ >= 2 && p.F >= 64)) return;
+    static const bool order_one = !(getenv("FA_FRAG_ORDER_ONE") && atoi(getenv("FA_FRAG_ORDER_ONE")) == 0);   // (A/B of the one-genome order)
+    if (!(order_on && (NQ >= 2 || order_one) && p.F >= 64)) return;
     if (ln.order_batch != g.serial || ln.order_f0 != p.f0 || ln.order_f1 != p.f1) {
       std::vector<int32_t> ord;
       ln.order_len = build_frag_order(g, g0, p.f0, p.f1, ord);       // 0: the lists cannot be balanced, identity order

@@ -465,9 +465,9 @@ inline void read_fasta_packed(const char *path, bool protein, PackedFasta &out, 
   }
 }
 
-// (FA_FASTA_THREADS=all: every pool worker takes files; default: the pool's usual two dozen -- on tmpfs 128 readers spent 70 ms
-//  per 5 MB file inside read(), 25 readers 4 ms)
-inline bool fasta_heavy_pool() { static const bool v = [] { const char *e = getenv("FA_FASTA_THREADS"); return e && std::string(e) == "all"; }(); return v; }
+// (FA_FASTA_THREADS=<n>: pool workers that take files; default: the pool's usual two dozen -- on tmpfs 128 readers spent 70 ms
+//  per 5 MB file inside read(), 25 readers 3-4 ms)
+inline int fasta_pool_helpers() { static const int v = [] { const char *e = getenv("FA_FASTA_THREADS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 24; }(); return v; }
 
 // Many files at once: one task per file on the pool (a file never waits for the one before it).
 inline void read_fasta_packed_many(const char *const *paths, size_t n, bool protein, std::vector<PackedFasta> &out) {
@@ -485,7 +485,7 @@ inline void read_fasta_packed_many(const char *const *paths, size_t n, bool prot
     }
     arena = std::make_shared<HostArena>(need);
   }
-  HostPool::get().parallel_for(n, [&](size_t i) { read_fasta_packed(paths[i], protein, out[i], arena); }, fasta_heavy_pool());
+  HostPool::get().parallel_for(n, [&](size_t i) { read_fasta_packed(paths[i], protein, out[i], arena); }, fasta_pool_helpers());
 }
 
 

@@ -75,12 +75,14 @@ inline int host_threads() {
 class HostPool {
  public:
   static HostPool &get() { static HostPool *p = new HostPool(host_threads()); return *p; }
-  // `heavy`: every item is milliseconds of work (a FASTA file to read and pack), so every worker is worth waking
-  void parallel_for(size_t total, const std::function<void(size_t)> &f, bool heavy = false) {
+  // `want_helpers` > 0: every item is milliseconds of work (a FASTA file to read and pack) and the caller says how many workers
+  // are worth waking
+  void parallel_for(size_t total, const std::function<void(size_t)> &f, int want_helpers = 0) {
     // waking a thread costs about as much as a 64 Kbase chunk of packing: two chunks per helper at least
     // (measured on a 5 Mb query = 77 chunks: 16-32 helpers are fastest, 128 cost 15 % more); big jobs use every worker
-    const size_t cap = (heavy || total >= 4096) ? (size_t)nworkers_ : std::min<size_t>((size_t)nworkers_, 24);
-    const int helpers = (int)std::min<size_t>(cap, heavy ? (total > 0 ? total - 1 : 0) : total / 2);
+    const size_t cap = total >= 4096 ? (size_t)nworkers_ : std::min<size_t>((size_t)nworkers_, 24);
+    const int helpers = want_helpers > 0 ? (int)std::min<size_t>(std::min<size_t>((size_t)want_helpers, (size_t)nworkers_), total > 0 ? total - 1 : 0)
+                                         : (int)std::min<size_t>(cap, total / 2);
     if (helpers == 0 || total < 3) { for (size_t i = 0; i < total; i++) f(i); return; }
     auto job = std::make_shared<Job>();
     job->fn = &f; job->total = total;
