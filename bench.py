@@ -672,7 +672,8 @@ def config5_leg(ctx):
         full = (f, m, args.length) == (10, 20, 5_000_000)
         roof = (stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"], *(profiled_traffic("l2", f"config5_k{k}_f{frag}_traffic.json") if full else (None, None)))
                 if not degenerate and r["phases_ms"]["l2_ms"] > 0 else None)
-        cells.append({"k": k, "fragment_length": frag, "degenerate": degenerate, "roofline": roof, **r})
+        cells.append({"k": k, "fragment_length": frag, "degenerate": degenerate, "roofline": roof,
+                      **({"roofline_note": "no L2 stage: no window fits a fragment (SURVEY.md H7), nothing maps, the step is the sketch kernels alone"} if roof is None else {}), **r})
         del mapper
     n = len(genomes)
     return {"workload": f"{n} x {n} all-vs-all ({f} families x {m}) of {args.length / 1e6:g} Mb genomes per (k, fragment_length) cell", "generate_s": t_gen,
