@@ -1065,10 +1065,11 @@ cdef class Mapper(_Parameterized):
         """`query_draft` for a genome stored as a FASTA file (its records are the contigs)."""
         return self.upload_fasta([path]).query()[0]
 
-    def query_fasta_stream(self, paths, int chunk=24, rows=False, uintptr_t device_ptr=0, int64_t device_cap=0, stats=None):
-        """Map the genomes stored in `paths` (one FASTA file each) in chunks of `chunk` files, yielding ``(first, result)``
-        per chunk -- ``result`` is one hit list per genome, or the raw row array with ``rows=True`` (``query_id`` counts
-        from 0 inside the chunk).  With ``device_ptr`` / ``device_cap`` (a caller-owned HBM table of 20-byte rows, e.g. a
+    def query_fasta_stream(self, paths, chunk=None, rows=False, uintptr_t device_ptr=0, int64_t device_cap=0, stats=None):
+        """Map the genomes stored in `paths` (one FASTA file each) in chunks of `chunk` files (default: as many files as make
+        ~120 MB of FASTA -- two dozen 5 Mb genomes, one device pass -- and at most 4096), yielding ``(first, result)``
+        per chunk -- ``first`` is the number of the chunk's first genome in `paths`, ``result`` one hit list per genome, or the
+        raw row array with ``rows=True`` (``query_id`` counts from 0 inside the chunk).  With ``device_ptr`` / ``device_cap`` (a caller-owned HBM table of 20-byte rows, e.g. a
         torch tensor) the rows never leave the device: chunk after chunk is written behind the rows of the chunks before it
         and ``result`` is ``(row offset, row count)``.
 
@@ -1081,8 +1082,26 @@ cdef class Mapper(_Parameterized):
         import threading
         import time
         paths = list(paths)
-        chunk = max(1, chunk)
-        chunks = [paths[i:i + chunk] for i in range(0, len(paths), chunk)]
+        if chunk is None:
+            chunks, cur, cur_bytes = [], [], 0
+            for p in paths:
+                try:
+                    size = os.path.getsize(p)
+                except OSError:
+                    size = 0                          # (the reader reports a missing file when its chunk is loaded)
+                if cur and (cur_bytes + size > 120_000_000 or len(cur) >= 4096):
+                    chunks.append(cur)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += size
+            if cur:
+                chunks.append(cur)
+        else:
+            chunk = max(1, int(chunk))
+            chunks = [paths[i:i + chunk] for i in range(0, len(paths), chunk)]
+        firsts = [0]
+        for c in chunks:
+            firsts.append(firsts[-1] + len(c))
         if stats is None:
             stats = {}
         stats.update(ingest_s=0.0, map_s=0.0, wait_s=0.0, chunks=len(chunks))
@@ -1130,7 +1149,7 @@ cdef class Mapper(_Parameterized):
                     result = b.query_rows(0, b.n_genomes) if rows else b.query(0, b.n_genomes)
                 stats["map_s"] += time.perf_counter() - t0
                 free.put(slot)
-                yield i * chunk, result
+                yield firsts[i], result
         finally:
             free.put(False); free.put(False)
             t.join(timeout=60)

@@ -1092,7 +1092,7 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         streamed_refs = pf.Sketch().add_fasta_stream(range(len(files)), files, chunk=1, stats=stats)   # the device sketches chunk c while c + 1 is read
         assert all(np.array_equal(x, y) for x, y in zip(streamed_refs._read_minimizers(), a)) and stats["chunks"] == 3 and stats["sketch_s"] > 0
         m3 = many.index()
-        for chunk in (1, 2, 5):
+        for chunk in (1, 2, 5, None):                       # (None: chunks sized by the files' bytes)
             streamed = {}
             for first, hits in m3.query_fasta_stream(files * 2, chunk=chunk):
                 for i, h in enumerate(hits):
