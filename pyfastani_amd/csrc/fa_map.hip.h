@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       constexpr bool NARROW = sizeof(G) == 4;
       constexpr bool NEAR = decltype(near_tag)::value;
       // steps per batch (registers: one or two per step; the partner read of the near test takes one step's worth)
-      constexpr int CB = NEAR ? (NARROW ? 8 : 5) : (NARROW ? 9 : 6);
+      constexpr int CB = NEAR ? (NARROW ? 8 : 6) : (NARROW ? 9 : 6);
       // The coordinate of a hit is only fetched if the hit can be one end of a candidate (round 5).  Records are ordered by
       // (contig, window) and window positions grow by at least one per record, so the padded global coordinates of two hits
       // differ by at least their distance in RECORDS: hit i can START a candidate (`fwd`) only if its partner, m - 1 hits ahead,
