@@ -209,8 +209,7 @@ def build_mapper(ctx, names, refs):
     if mapper is None:
         t0 = time.time()
         sk = pf.Sketch()
-        for name, contigs in zip(names, refs):
-            sk.add_draft(name, contigs)
+        sk.add_drafts(names, refs)                 # (every genome as `add_draft` adds it, one run of the packer over all contigs)
         t_pack = time.time() - t0
         t0 = time.time()
         mapper = sk.index()
@@ -593,8 +592,7 @@ def resident_all_vs_all(ctx, genomes, fam, params, steps, warmup=1):
         warnings.simplefilter("ignore")                  # (short contigs of the drafts: the reference warns too)
         t0 = time.time()
         sk = pf.Sketch(**params)
-        for i, contigs in enumerate(genomes):
-            sk.add_draft(i, contigs)
+        sk.add_drafts(list(range(n)), genomes)
         t_pack = time.time() - t0
         t0 = time.time()
         mapper = sk.index()

@@ -183,6 +183,12 @@ void fa_fasta_close(fa_fasta *f);
 /* Parser + Sketch._add_draft (_fastani.pyx:610-690) in one native call: every record of the file is a contig of ONE
  * reference genome; records are split and upper-cased by host threads and packed without passing through Python. */
 int fa_sketch_add_fasta(fa_sketch *s, const char *path, int64_t *n_records, int64_t *n_short);
+/* n_genomes reference genomes from host buffers in ONE call: contig c belongs to genome contig_genome[c] (non-decreasing,
+ * < n_genomes; a genome may have no contig); equivalent to fa_sketch_add_contig for every contig and fa_sketch_end_genome
+ * for every genome (_fastani.pyx:610-690 per genome), with one run of the packer over all contigs.  n_short: [n_genomes]
+ * contigs skipped with the short-sequence warning, or NULL. */
+int fa_sketch_add_genomes(fa_sketch *s, const void *const *contigs, const int64_t *lengths, const int32_t *contig_genome,
+                          int64_t n_contigs, int32_t n_genomes, int char_width, int32_t *n_short);
 /* The same for n_paths reference genomes, one per file, in the order given: the files are read and 2-bit packed
  * concurrently (one host task per file, straight from the file's bytes to packed words), then added as n_paths
  * consecutive fa_sketch_add_fasta calls would have added them.  n_records / n_short: [n_paths] or NULL.  The host side

@@ -105,6 +105,7 @@ SIGNATURES = {
     "fa_sketch_add_fasta": (_i32, [_vp, C.c_char_p, _P(_i64), _P(_i64)]),
     "fa_genomes_upload_fasta": (_i32, [_vp, _P(C.c_char_p), _i32, _P(_vp)]),
     "fa_genomes_reload_fasta": (_i32, [_vp, _vp, _P(C.c_char_p), _i32]),
+    "fa_sketch_add_genomes": (_i32, [_vp, _P(_vp), _P(_i64), _P(_i32), _i64, _i32, _i32, _P(_i32)]),
     "fa_sketch_add_fasta_many": (_i32, [_vp, _P(C.c_char_p), _i32, _P(_i64), _P(_i64)]),
     "fa_debug_probe_occupancy": (_i32, [_i32, _P(_i32)]),
     "fa_mapper_debug_items": (_i32, [_vp, _vp, _i64]),

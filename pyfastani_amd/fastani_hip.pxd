@@ -68,6 +68,7 @@ cdef extern from "fastani_hip.h" nogil:
                                    int64_t counter, int64_t n_minimizers, const uint32_t* d_hash, const int32_t* d_seq_id,
                                    const int32_t* d_wpos)
     int fa_sketch_add_fasta(fa_sketch* s, const char* path, int64_t* n_records, int64_t* n_short)   # _fasta.pyx:41-103 + :610-690
+    int fa_sketch_add_genomes(fa_sketch* s, const void* const* contigs, const int64_t* lengths, const int32_t* contig_genome, int64_t n_contigs, int32_t n_genomes, int char_width, int32_t* n_short)
     int fa_sketch_add_fasta_many(fa_sketch* s, const char* const* paths, int32_t n_paths, int64_t* n_records, int64_t* n_short)
     int fa_sketch_index(fa_sketch* s, fa_mapper** out)                                        # :790-791 (+ ownership move :793-806)
 

@@ -337,8 +337,8 @@ def build_index_sharded(genomes, names=None, rank=0, world_size=1, group=None, d
     failure = None
     try:
         local = Sketch(**params)
-        for i in shard_indices(n, rank, world_size):
-            local.add_draft(i, genomes[i])
+        mine = shard_indices(n, rank, world_size)
+        local.add_drafts(mine, [genomes[i] for i in mine])
         rec, (lengths, sbf, counter) = local._export_records(dev)
     except Exception as e:                       # noqa: BLE001 -- reported to every rank below
         failure = e

@@ -110,3 +110,22 @@ def test_threads_argument_validation():
         mapper.query_draft([], threads=-1)
     with pytest.raises(ValueError):
         mapper.query_genome("ACGT", threads=-2)
+
+
+def test_add_drafts_is_add_draft_for_every_genome():
+    """`Sketch.add_drafts` (one run of the packer over all contigs, fa_sketch_add_genomes): names, the short-contig warnings and
+    the argument checks of n `add_draft` calls (host side only; the records are compared on the GPU, tests/test_gpu_parity.py)."""
+    import warnings
+    import pyfastani_amd as pf
+    sk = pf.Sketch()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert sk.add_drafts(["a", "b", "c"], [[b"ACGT" * 200, b"AC"], [], ["ACGT" * 100, bytearray(b"TTGA" * 50)]]) is sk
+    assert sk.names == ["a", "b", "c"] and len(w) == 1 and "short" in str(w[0].message)
+    with pytest.raises(ValueError):
+        sk.add_drafts(["x"], [[b"ACGT"], [b"ACGT"]])
+    with pytest.raises(TypeError):
+        sk.add_drafts(["x"], [[1234]])
+    assert sk.names == ["a", "b", "c"]
+    mixed = pf.Sketch().add_drafts(["m"], [[b"ACGT" * 100, "ACG\u0141" * 100]])     # bytes next to a UCS2 string: genome by genome
+    assert mixed.names == ["m"]

@@ -1494,3 +1494,26 @@ def test_device_pool_keeps_and_returns_memory():
         gc.collect()
     held = pf.device_trim()
     assert held > 0 and pf.device_trim() == 0
+
+
+def test_add_drafts_gives_the_records_of_add_draft():
+    """One run of the packer over the contigs of many genomes (Sketch.add_drafts) against a loop of add_draft: the same minimizer
+    records, genome lengths and hits -- drafts with short contigs, an empty genome, lower case and N runs."""
+    g = syn.rng(4242)
+    anc = syn.random_codes(g, 90_000)
+    genomes = []
+    for d in (0.0, 0.03, 0.09):
+        seq = bytearray(bytes(syn.to_ascii(syn.mutate_codes(g, anc, d) if d else anc)))
+        seq[5_000:5_200] = b"N" * 200
+        seq[20_000:20_500] = bytes(seq[20_000:20_500]).lower()
+        genomes.append(syn.split_contigs(g, np.frombuffer(bytes(seq), np.uint8), 4) + [b"ACG"])
+    genomes.insert(1, [])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        many, loop = pf.Sketch().add_drafts(range(len(genomes)), genomes), pf.Sketch()
+        for i, contigs in enumerate(genomes):
+            loop.add_draft(i, contigs)
+        assert all(np.array_equal(x, y) for x, y in zip(many._read_minimizers(), loop._read_minimizers()))
+        m1, m2 = many.index(), loop.index()
+        q = [bytes(syn.to_ascii(syn.mutate_codes(g, anc, 0.02)))]
+        assert hit_tuples(m1.query_draft(q)) == hit_tuples(m2.query_draft(q)) and len(m1.query_draft(q)) == 3
