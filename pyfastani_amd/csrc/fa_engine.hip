@@ -255,11 +255,12 @@ struct fa_sketch {
     store.upload(pending, stream);
     tr.mark("upload", stream);
     const int64_t nseq_all = (int64_t)pending.seq_off.size();
-    // staging is 8 B per k-mer position; a chunk takes an eighth of the free HBM at most (96 M positions = 768 MiB at least):
-    // a thousand genomes are a handful of chunks on a 288 GB device, not fifty with two synchronisations each
+    // staging is 8 B per k-mer position; a chunk takes an eighth of the free HBM at most, between 96 M positions (768 MiB) and
+    // 512 M (4 GiB: a thousand genomes are ten chunks, not fifty-two with two synchronisations each -- and not two chunks whose
+    // 34 GB of staging a fresh process has to map first)
     size_t hbm_free = 0, hbm_total = 0;
     if (hipMemGetInfo(&hbm_free, &hbm_total) != hipSuccess) { (void)hipGetLastError(); hbm_free = 0; }
-    const int64_t chunk_positions = std::max<int64_t>(96LL << 20, std::min<int64_t>((int64_t)(hbm_free / 8 / 8), 4LL << 30));
+    const int64_t chunk_positions = std::max<int64_t>(96LL << 20, std::min<int64_t>((int64_t)(hbm_free / 8 / 8), 512LL << 20));
     // the records are appended chunk by chunk: reserve for all of them once (2 / (w + 1) of the positions are minimizers, a
     // quarter of headroom; `ensure(keep)` below still grows the arrays if a sequence is denser) instead of regrowing -- and
     // copying -- them a dozen times
