@@ -900,6 +900,39 @@ def fasta_to_table_leg(ctx, genomes, chunk=24, ref_chunk=125):
             wall = time.perf_counter() - t0
         n_rows = sum(c for _, c in spans)
         rows = table[:n_rows].cpu().numpy().reshape(-1).view(ROW_DTYPE)
+        # ---- the same all-vs-all with every file read ONCE (the genomes that are sketched are the genomes that are mapped,
+        #      benches/mapping/bench.py:41-53): `PackedGenomes` -> `Sketch.add_packed` -> `index()` -> the query stream refilled from
+        #      the packed set (no second read) ----
+        del mapper, sk
+        table.zero_()
+        torch.cuda.synchronize()
+        once_stats, once_spans, once_dev_ms = {}, [], 0.0
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            t0 = time.perf_counter()
+            packed = pf.PackedGenomes(paths)
+            t_read = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            sk = pf.Sketch()
+            sk.add_packed(list(range(n)), packed)
+            mapper = sk.index()
+            t_once_index = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            for first, (off, cnt) in mapper.query_fasta_stream(packed, chunk=chunk, device_ptr=table.data_ptr(), device_cap=n * n, stats=once_stats):
+                if cnt:
+                    table[off: off + cnt, 0] += first
+                lib.fa_mapper_last_timings(mapper._h, ms, 16)
+                once_dev_ms += float(ms[4])
+                once_spans.append((off, cnt))
+            torch.cuda.synchronize()
+            t_once_stream = time.perf_counter() - t1
+            once_wall = time.perf_counter() - t0
+        once_rows = table[:sum(c for _, c in once_spans)].cpu().numpy().reshape(-1).view(ROW_DTYPE)
+        read_once = {"wall_s": once_wall, "pairs_per_s": n * n / once_wall, "read_pack_s": t_read, "read_pack_GBps": nbytes / t_read / 1e9,
+                     "add_packed_and_index_s": t_once_index, "stream_s": t_once_stream, "stream_refill_s": once_stats["ingest_s"],
+                     "stream_map_s": once_stats["map_s"], "device_pass_s": once_dev_ms * 1e-3, "table_sha256": _sha256_rows(once_rows)}
+        if read_once["table_sha256"] != _sha256_rows(rows):
+            raise SystemExit(f"FASTA-TO-TABLE FAILURE: the read-once table ({read_once['table_sha256']}) differs from the streamed one ({_sha256_rows(rows)})")
         # host side: reading + packing (references: the add calls, which also hold the wait for the sketch in flight; queries: the
         # loader thread); device side: reference sketching, index construction, the passes
         host_s = ref_stats["add_s"] + stats["ingest_s"]
@@ -912,7 +945,7 @@ def fasta_to_table_leg(ctx, genomes, chunk=24, ref_chunk=125):
             "stream_ingest_s": stats["ingest_s"], "stream_ingest_GBps": nbytes / max(stats["ingest_s"], 1e-9) / 1e9,
             "stream_map_s": stats["map_s"], "stream_wait_s": stats["wait_s"], "chunks": stats["chunks"], "chunk_files": chunk,
             "device_pass_s": dev_ms * 1e-3, "host_s": host_s, "device_s": device_s, "overlap": wall / max(host_s, device_s),
-            "ingest_GBps": 2 * nbytes / host_s / 1e9, "write_files_s": t_write, "host_threads": os.cpu_count(),
+            "ingest_GBps": 2 * nbytes / host_s / 1e9, "write_files_s": t_write, "host_threads": os.cpu_count(), "read_once": read_once,
         }
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -198,6 +198,18 @@ int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_p
 /* One query genome per FASTA file, packed and uploaded as a resident batch (fa_genomes_upload semantics); the files
  * are read concurrently, and the upload runs on a stream of the batch's own. */
 int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_paths, fa_genomes **out);
+/* FASTA files read and 2-bit packed ONCE (one genome per file, the files concurrently), to be used as references and as
+ * queries: an all-vs-all -- the reference benchmark's shape, benches/mapping/bench.py:41-53: the genomes that are sketched are
+ * the genomes that are mapped -- reads every file one time.  protein != 0: residue bytes are kept instead. */
+typedef struct fa_packed fa_packed;
+int fa_packed_read(const char *const *paths, int32_t n_paths, int protein, fa_packed **out);
+void fa_packed_free(fa_packed *p);
+/* per file: its size in bytes, its records, its bases (arrays of *n_files entries, any may be NULL) */
+int fa_packed_info(fa_packed *p, int32_t *n_files, uint64_t *file_bytes, int64_t *records, int64_t *bases);
+/* files [first, first + count) as that many reference genomes (fa_sketch_add_fasta_many without reading) */
+int fa_sketch_add_packed(fa_sketch *s, fa_packed *p, int32_t first, int32_t count, int64_t *n_records, int64_t *n_short);
+/* files [first, first + count) as the query genomes of a recycled batch (fa_genomes_reload_fasta without reading) */
+int fa_genomes_reload_packed(fa_mapper *m, fa_genomes *g, fa_packed *p, int32_t first, int32_t count);
 /* Refills a batch from other files, recycling its device buffers, its pinned staging image and its stream: the
  * double-buffered form for a stream of query chunks (while one batch is mapped by fa_mapper_query_genomes on one host
  * thread, another thread refills the other batch).  A failed refill leaves an empty batch. */

@@ -15,6 +15,7 @@ try:
         Mapper,
         MinimizerIndex,
         MinimizerInfo,
+        PackedGenomes,
         Minimizers,
         Position,
         Sketch,
@@ -31,6 +32,6 @@ except ImportError as exc:  # the compiled binding or libfastani_hip.so is missi
 
 __all__ = [
     "MAX_KMER_SIZE", "Hit", "Mapper", "MinimizerIndex", "MinimizerInfo", "Minimizers", "Position", "Sketch",
-    "GenomeBatch", "device_count", "device_trim", "set_device",
+    "GenomeBatch", "PackedGenomes", "device_count", "device_trim", "set_device",
 ]
 __version__ = "0.2.0"

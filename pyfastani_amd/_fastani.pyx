@@ -463,6 +463,52 @@ cdef tuple _download_minimizers_sketch(hip.fa_sketch* s):
     return h, q, w
 
 
+# --- FASTA files packed once (host ingest; no reference analogue) -----------------------------------------------------------------
+cdef class PackedGenomes:
+    """FASTA files (one genome each) read and 2-bit packed ONCE by the library's host threads, to be used as references
+    (`Sketch.add_packed`) and as queries (`Mapper.query_fasta_stream(packed)`): an all-vs-all reads every file one time."""
+    cdef hip.fa_packed* _hp
+    cdef readonly list paths
+    cdef readonly bint protein
+
+    def __cinit__(self):
+        self._hp = NULL
+
+    def __init__(self, paths, protein=False):
+        cdef vector[const char*] arr
+        cdef int code, prot = 1 if protein else 0
+        cdef int32_t n
+        self.paths = [os.fspath(p) for p in paths]
+        self.protein = bool(protein)
+        encoded = [os.fsencode(p) for p in self.paths]
+        for p in encoded:
+            arr.push_back(<const char*> p)
+        n = <int32_t> len(encoded)
+        if arr.empty():
+            arr.push_back(NULL)
+        with nogil:
+            code = hip.fa_packed_read(arr.data(), n, prot, &self._hp)
+        _check(code)
+
+    def __dealloc__(self):
+        if self._hp != NULL:
+            hip.fa_packed_free(self._hp)
+            self._hp = NULL
+
+    def __len__(self):
+        return len(self.paths)
+
+    def info(self):
+        """Per file: ``(bytes, records, bases)`` as three lists."""
+        cdef vector[uint64_t] fb
+        cdef vector[int64_t] rec, bases
+        cdef int32_t n = 0
+        cdef size_t k = max(len(self.paths), 1)
+        fb.resize(k); rec.resize(k); bases.resize(k)
+        _check(hip.fa_packed_info(self._hp, &n, fb.data(), rec.data(), bases.data()))
+        return [fb[i] for i in range(n)], [rec[i] for i in range(n)], [bases[i] for i in range(n)]
+
+
 # --- Sketch (_fastani.pyx:449-806) ------------------------------------------------------------------------------------
 cdef class Sketch(_Parameterized):
     """An index computing minimizers over the reference genomes.
@@ -784,6 +830,27 @@ cdef class Sketch(_Parameterized):
             self._names.extend(names)
             self._version += 1
         for i in range(n):
+            for _ in range(n_short[i]):
+                warnings.warn("Sketch received a short contig relative to parameters, minimizers will not be added.", UserWarning)
+        return self
+
+    def add_packed(self, names, PackedGenomes packed, int first=0, count=None):
+        """Files ``[first, first + count)`` of a `PackedGenomes` as that many reference genomes (`add_fasta_many` without
+        reading the files again)."""
+        cdef vector[int64_t] n_rec, n_short
+        cdef int code
+        cdef int32_t c = <int32_t> (len(packed) - first if count is None else count)
+        names = list(names)
+        if len(names) != c:
+            raise ValueError("names and the file range differ in length")
+        n_rec.resize(max(c, 1)); n_short.resize(max(c, 1))
+        with self._lock:
+            with nogil:
+                code = hip.fa_sketch_add_packed(self._hs, packed._hp, first, c, n_rec.data(), n_short.data())
+            _check(code)
+            self._names.extend(names)
+            self._version += 1
+        for i in range(c):
             for _ in range(n_short[i]):
                 warnings.warn("Sketch received a short contig relative to parameters, minimizers will not be added.", UserWarning)
         return self
@@ -1114,7 +1181,8 @@ cdef class Mapper(_Parameterized):
         return self.upload_fasta([path]).query()[0]
 
     def query_fasta_stream(self, paths, chunk=None, rows=False, uintptr_t device_ptr=0, int64_t device_cap=0, stats=None):
-        """Map the genomes stored in `paths` (one FASTA file each) in chunks of `chunk` files (default: as many files as make
+        """Map the genomes stored in `paths` (one FASTA file each; or a `PackedGenomes`: files that are packed already -- the
+        chunks are then refilled without reading anything) in chunks of `chunk` files (default: as many files as make
         ~120 MB of FASTA -- two dozen 5 Mb genomes, one device pass -- and at most 4096), yielding ``(first, result)``
         per chunk -- ``first`` is the number of the chunk's first genome in `paths`, ``result`` one hit list per genome, or the
         raw row array with ``rows=True`` (``query_id`` counts from 0 inside the chunk).  With ``device_ptr`` / ``device_cap`` (a caller-owned HBM table of 20-byte rows, e.g. a
@@ -1129,12 +1197,18 @@ cdef class Mapper(_Parameterized):
         import queue
         import threading
         import time
-        paths = list(paths)
+        packed = paths if isinstance(paths, PackedGenomes) else None     # (files packed already: chunks are refilled without reading)
+        sizes = None
+        if packed is not None:
+            sizes = packed.info()[0]
+            paths = list(packed.paths)
+        else:
+            paths = list(paths)
         if chunk is None:
             chunks, cur, cur_bytes = [], [], 0
-            for p in paths:
+            for j, p in enumerate(paths):
                 try:
-                    size = os.path.getsize(p)
+                    size = sizes[j] if sizes is not None else os.path.getsize(p)
                 except OSError:
                     size = 0                          # (the reader reports a missing file when its chunk is loaded)
                 if cur and (cur_bytes + size > 120_000_000 or len(cur) >= 4096):
@@ -1170,7 +1244,9 @@ cdef class Mapper(_Parameterized):
                         return
                     t0 = time.perf_counter()
                     if slot is None:
-                        slot = GenomeBatch.from_fasta(self, c, True)
+                        slot = GenomeBatch.from_fasta(self, [], True)       # an empty batch that is refilled from now on
+                    if packed is not None:
+                        slot.reload_packed(packed, firsts[i], len(c))
                     else:
                         slot.reload_fasta(c)
                     stats["ingest_s"] += time.perf_counter() - t0
@@ -1306,6 +1382,19 @@ cdef class GenomeBatch:
         with nogil:
             code = hip.fa_genomes_upload_fasta(mapper._hm, arr.data(), self.n_genomes, &self._hg)
         _check(code)
+        self._finish()
+        return self
+
+    def reload_packed(self, PackedGenomes packed, int first, int count):
+        """Replace the contents of the batch by files ``[first, first + count)`` of a `PackedGenomes` (`reload_fasta`
+        without reading the files again)."""
+        cdef int code
+        with nogil:
+            code = hip.fa_genomes_reload_packed(self._mapper._hm, self._hg, packed._hp, first, count)
+        if code != 0:
+            self.n_genomes = 0
+        _check(code)
+        self.n_genomes = count
         self._finish()
         return self
 

@@ -1873,9 +1873,8 @@ static std::unique_ptr<fa_genomes> upload_genomes(const fa_params &P, hipStream_
 
 // one genome per FASTA file, every file read + packed by its own task of the host pool (read_fasta_packed_many), then the
 // batch image assembled from the packed records and uploaded on the batch's own stream
-static void fill_genomes_from_fasta(fa_mapper *m, fa_genomes *g, const char *const *paths, int32_t n_paths, bool pinned) {
-  std::vector<PackedFasta> files;
-  read_fasta_packed_many(paths, (size_t)n_paths, m->P.alphabet_size != 4, files);
+// genomes [first, first + count) of files packed already (one genome per file) as the batch `g`
+static void fill_genomes_from_packed(fa_mapper *m, fa_genomes *g, const PackedFasta *files, int32_t n_paths, bool pinned) {
   std::vector<PackedRef> refs;
   std::vector<int64_t> lens;
   std::vector<int32_t> genome;
@@ -1886,6 +1885,56 @@ static void fill_genomes_from_fasta(fa_mapper *m, fa_genomes *g, const char *con
   if (!g->up_stream) FA_HIP(hipStreamCreateWithFlags(&g->up_stream, hipStreamNonBlocking));
   fill_genomes(g, m->P, g->up_stream, nullptr, lens.data(), genome.data(), (int64_t)refs.size(), n_paths, 1, nullptr,
                pinned ? &g->pin_image : nullptr, refs.data(), true);
+}
+static void fill_genomes_from_fasta(fa_mapper *m, fa_genomes *g, const char *const *paths, int32_t n_paths, bool pinned) {
+  std::vector<PackedFasta> files;
+  read_fasta_packed_many(paths, (size_t)n_paths, m->P.alphabet_size != 4, files);
+  fill_genomes_from_packed(m, g, files.data(), n_paths, pinned);
+}
+
+// FASTA files read and packed ONCE, to be used as references AND as queries (an all-vs-all reads every file one time)
+struct fa_packed {
+  bool protein = false;
+  std::vector<PackedFasta> files;
+};
+// the bookkeeping of fa_sketch_add_fasta_many over files that are packed already (s->mtx held by the caller)
+static void sketch_add_packed_files(fa_sketch *s, const PackedFasta *files, int32_t n_paths, int64_t *n_records, int64_t *n_short) {
+  std::vector<PackedRef> refs;
+  std::vector<int32_t> contig_ids;
+  std::vector<uint64_t> lengths;
+  std::vector<int32_t> by_file;
+  std::vector<int64_t> shorts((size_t)n_paths, 0);
+  int64_t counter = s->counter;
+  FA_REQUIRE(s->cur_total == 0 || n_paths == 0, FA_ERR_INVALID, "a genome is still open (add_contig without end_genome)");
+  for (int32_t i = 0; i < n_paths; i++) {
+    uint64_t total = 0;
+    for (size_t r = 0; r < files[i].rec_len.size(); r++) {
+      const int64_t length = files[i].rec_len[r];
+      FA_REQUIRE(length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
+      if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
+        refs.push_back(PackedRef{&files[i], (int64_t)r, length});
+        contig_ids.push_back((int32_t)counter);
+      } else {
+        shorts[(size_t)i]++;
+      }
+      total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
+      counter += 1;                                                                // :683
+    }
+    lengths.push_back(total);                            // :687
+    by_file.push_back((int32_t)counter);                 // :690
+  }
+  s->pending_contig.reserve(s->pending_contig.size() + contig_ids.size());
+  s->lengths.reserve(s->lengths.size() + lengths.size());
+  s->seqs_by_file.reserve(s->seqs_by_file.size() + by_file.size());
+  if (!refs.empty()) append_packed(s->pending, refs.data(), (int64_t)refs.size());
+  s->pending_contig.insert(s->pending_contig.end(), contig_ids.begin(), contig_ids.end());
+  s->counter = counter;
+  s->lengths.insert(s->lengths.end(), lengths.begin(), lengths.end());
+  s->seqs_by_file.insert(s->seqs_by_file.end(), by_file.begin(), by_file.end());
+  for (int32_t i = 0; i < n_paths; i++) {
+    if (n_records) n_records[i] = (int64_t)files[i].rec_len.size();
+    if (n_short) n_short[i] = shorts[(size_t)i];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2107,44 +2156,51 @@ int fa_sketch_add_fasta_many(fa_sketch *s, const char *const *paths, int32_t n_p
     }
     std::lock_guard<std::mutex> lock(s->mtx);
     bind_device(s->device);
-    // staged in locals, committed after the store has taken the records (as fa_sketch_add_fasta)
-    std::vector<PackedRef> refs;
-    std::vector<int32_t> contig_ids;
-    std::vector<uint64_t> lengths;
-    std::vector<int32_t> by_file;
-    std::vector<int64_t> shorts((size_t)n_paths, 0);
-    int64_t counter = s->counter;
-    FA_REQUIRE(s->cur_total == 0 || n_paths == 0, FA_ERR_INVALID, "a genome is still open (add_contig without end_genome)");
-    for (int32_t i = 0; i < n_paths; i++) {
-      uint64_t total = 0;
-      for (size_t r = 0; r < files[i].rec_len.size(); r++) {
-        const int64_t length = files[i].rec_len[r];
-        FA_REQUIRE(length < (1LL << 31), FA_ERR_INVALID, "contig length must be below 2^31");
-        if (length >= s->P.window_size && length >= s->P.kmer_size) {      // _fastani.pyx:648
-          refs.push_back(PackedRef{&files[i], (int64_t)r, length});
-          contig_ids.push_back((int32_t)counter);
-        } else {
-          shorts[i]++;
-        }
-        total += (uint64_t)(length / s->P.fragment_length) * s->P.fragment_length;   // :680
-        counter += 1;                                                                // :683
-      }
-      lengths.push_back(total);                            // :687
-      by_file.push_back((int32_t)counter);                 // :690
-    }
-    s->pending_contig.reserve(s->pending_contig.size() + contig_ids.size());
-    s->lengths.reserve(s->lengths.size() + lengths.size());
-    s->seqs_by_file.reserve(s->seqs_by_file.size() + by_file.size());
     tr.mark("bookkeeping", nullptr);
-    if (!refs.empty()) append_packed(s->pending, refs.data(), (int64_t)refs.size());
+    sketch_add_packed_files(s, files.data(), n_paths, n_records, n_short);
     tr.mark("place", nullptr);
-    s->pending_contig.insert(s->pending_contig.end(), contig_ids.begin(), contig_ids.end());
-    s->counter = counter;
-    s->lengths.insert(s->lengths.end(), lengths.begin(), lengths.end());
-    s->seqs_by_file.insert(s->seqs_by_file.end(), by_file.begin(), by_file.end());
-    for (int32_t i = 0; i < n_paths; i++) {
-      if (n_records) n_records[i] = (int64_t)files[i].rec_len.size();
-      if (n_short) n_short[i] = shorts[i];
+  });
+}
+// ---- files packed once, used many times (fa_packed) ----
+int fa_packed_read(const char *const *paths, int32_t n_paths, int protein, fa_packed **out) {
+  return guarded([&] {
+    FA_REQUIRE(paths && out && n_paths >= 0, FA_ERR_INVALID, "null argument or negative count");
+    std::unique_ptr<fa_packed> p(new fa_packed());
+    p->protein = protein != 0;
+    read_fasta_packed_many(paths, (size_t)n_paths, p->protein, p->files);
+    *out = p.release();
+  });
+}
+void fa_packed_free(fa_packed *p) { delete p; }
+int fa_packed_info(fa_packed *p, int32_t *n_files, uint64_t *file_bytes, int64_t *records, int64_t *bases) {
+  return guarded([&] {
+    if (n_files) *n_files = (int32_t)p->files.size();
+    for (size_t i = 0; i < p->files.size(); i++) {
+      if (file_bytes) file_bytes[i] = (uint64_t)p->files[i].file_bytes;
+      if (records) records[i] = (int64_t)p->files[i].rec_len.size();
+      if (bases) { int64_t b = 0; for (int64_t l : p->files[i].rec_len) b += l; bases[i] = b; }
+    }
+  });
+}
+int fa_sketch_add_packed(fa_sketch *s, fa_packed *p, int32_t first, int32_t count, int64_t *n_records, int64_t *n_short) {
+  return guarded([&] {
+    FA_REQUIRE(p && first >= 0 && count >= 0 && (size_t)first + (size_t)count <= p->files.size(), FA_ERR_INVALID, "file range outside the packed set");
+    FA_REQUIRE(p->protein == (s->P.alphabet_size != 4), FA_ERR_INVALID, "the files were packed for the other alphabet");
+    std::lock_guard<std::mutex> lock(s->mtx);
+    bind_device(s->device);
+    sketch_add_packed_files(s, p->files.data() + first, count, n_records, n_short);
+  });
+}
+int fa_genomes_reload_packed(fa_mapper *m, fa_genomes *g, fa_packed *p, int32_t first, int32_t count) {
+  return guarded([&] {
+    FA_REQUIRE(g && p && first >= 0 && count >= 0 && (size_t)first + (size_t)count <= p->files.size(), FA_ERR_INVALID, "file range outside the packed set");
+    FA_REQUIRE(p->protein == (m->P.alphabet_size != 4), FA_ERR_INVALID, "the files were packed for the other alphabet");
+    try {
+      fill_genomes_from_packed(m, g, p->files.data() + first, count, true);
+    } catch (...) {
+      g->n_genomes = 0; g->F = 0; g->ntiles = 0;
+      g->genome_frag_lo.assign(1, 0); g->total_fragments.clear(); g->total_length.clear(); g->n_short.clear();
+      throw;
     }
   });
 }

@@ -94,6 +94,13 @@ cdef extern from "fastani_hip.h" nogil:
     int fa_genomes_upload(fa_mapper* m, const void* const* contigs, const int64_t* lengths, const int32_t* contig_genome,
                           int64_t n_contigs, int32_t n_genomes, int char_width, fa_genomes** out)
     int fa_genomes_upload_fasta(fa_mapper* m, const char* const* paths, int32_t n_paths, fa_genomes** out)
+    ctypedef struct fa_packed:
+        pass
+    int fa_packed_read(const char* const* paths, int32_t n_paths, int protein, fa_packed** out)
+    void fa_packed_free(fa_packed* p)
+    int fa_packed_info(fa_packed* p, int32_t* n_files, uint64_t* file_bytes, int64_t* records, int64_t* bases)
+    int fa_sketch_add_packed(fa_sketch* s, fa_packed* p, int32_t first, int32_t count, int64_t* n_records, int64_t* n_short)
+    int fa_genomes_reload_packed(fa_mapper* m, fa_genomes* g, fa_packed* p, int32_t first, int32_t count)
     int fa_genomes_reload_fasta(fa_mapper* m, fa_genomes* g, const char* const* paths, int32_t n_paths)
     void fa_genomes_free(fa_genomes* g)
     int fa_genomes_info(fa_genomes* g, int32_t* n_genomes, uint64_t* total_fragments, uint64_t* total_length, int32_t* n_short)

@@ -124,3 +124,26 @@ def test_protein_fixture_matches_plain_python_reader(golden_dir):
             cur[1] += line.rstrip(b"\n").upper()
     got = [(r.id, r.seq) for r in Parser(path)]
     assert got == [tuple(w) for w in want] and len(got) > 10
+
+
+def test_packed_genomes_read_once_use_twice(tmp_path):
+    # PackedGenomes: files read + packed once (host only); as references they count like add_fasta_many
+    import warnings
+    import pyfastani_amd as pf
+    body = (b"ACGTTGCA" * 10 + b"\n") * 400
+    paths = [write(tmp_path, f"p{i}.fna", b">c1\n" + body + (b">c2 short\nACGT\n" if i == 1 else b"")) for i in range(4)]
+    packed = pf.PackedGenomes(paths)
+    sizes, records, bases = packed.info()
+    assert len(packed) == 4 and records == [1, 2, 1, 1] and bases[0] == 32_000 and bases[1] == 32_004 and sizes[0] == os.path.getsize(paths[0])
+    sk = pf.Sketch()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sk.add_packed(["b", "c"], packed, 1, 2)
+        sk.add_packed(["a"], packed, 0, 1)
+    assert sk.names == ["b", "c", "a"] and len(w) == 1
+    with pytest.raises(ValueError):
+        sk.add_packed(["x"], packed, 3, 2)                   # file range outside the set
+    with pytest.raises(ValueError):
+        pf.Sketch(protein=True, fragment_length=100).add_packed(["x"], packed, 0, 1)   # packed for the other alphabet
+    with pytest.raises(OSError):
+        pf.PackedGenomes([paths[0], str(tmp_path / "missing.fna")])

@@ -1100,6 +1100,17 @@ def test_fasta_ingest_matches_python_path(tmp_path):
             assert [streamed[i] for i in range(2 * len(files))] == want * 2
         rows = [r for _, r in m3.query_fasta_stream(files, chunk=2, rows=True)]
         assert sum(len(r) for r in rows) == 9
+        # ... and with every file read ONCE: a PackedGenomes as the references and as the query stream
+        packed = pf.PackedGenomes(files)
+        once = pf.Sketch().add_packed(range(len(files)), packed)
+        assert all(np.array_equal(x, y) for x, y in zip(once._read_minimizers(), a))
+        m4 = once.index()
+        for chunk in (1, 2, None):
+            got4 = {}
+            for first, hits in m4.query_fasta_stream(packed, chunk=chunk):
+                for i, h in enumerate(hits):
+                    got4[first + i] = hit_tuples(h)
+            assert [got4[i] for i in range(len(files))] == want
     with pytest.warns(UserWarning):
         pf.Sketch().add_fasta_many(["x"], files[:1])
     with pytest.raises(OSError):
