@@ -906,6 +906,10 @@ def fasta_to_table_leg(ctx, genomes, chunk=24, ref_chunk=125):
         del mapper, sk
         table.zero_()
         torch.cuda.synchronize()
+        # (the files written afresh, untimed: a first pass over files costs the reader three to four times its steady rate, and
+        # both variants are to be timed on files they have not read before)
+        shutil.rmtree(tmp, ignore_errors=True)
+        paths, nbytes = workloads.write_fasta_set(tmp, genomes)
         once_stats, once_spans, once_dev_ms = {}, [], 0.0
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
