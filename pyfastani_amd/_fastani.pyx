@@ -498,6 +498,24 @@ cdef class PackedGenomes:
     def __len__(self):
         return len(self.paths)
 
+    def extend(self, paths):
+        """Read and pack more files behind the ones the set holds (all of them, or none if one fails)."""
+        cdef vector[const char*] arr
+        cdef int code
+        cdef int32_t n
+        more = [os.fspath(p) for p in paths]
+        encoded = [os.fsencode(p) for p in more]
+        for p in encoded:
+            arr.push_back(<const char*> p)
+        n = <int32_t> len(encoded)
+        if arr.empty():
+            arr.push_back(NULL)
+        with nogil:
+            code = hip.fa_packed_append(self._hp, arr.data(), n)
+        _check(code)
+        self.paths.extend(more)
+        return self
+
     def info(self):
         """Per file: ``(bytes, records, bases)`` as three lists."""
         cdef vector[uint64_t] fb
@@ -866,12 +884,14 @@ cdef class Sketch(_Parameterized):
         _check(code)
         return self
 
-    def add_fasta_stream(self, names, paths, int chunk=128, stats=None):
+    def add_fasta_stream(self, names, paths, int chunk=128, stats=None, PackedGenomes keep=None):
         """`add_fasta_many` in chunks of `chunk` files with the device working behind the host: while the files of chunk c + 1 are
         read and packed by the host pool, a second thread has the device sketch chunk c (`flush`).  Same sketch as one
         `add_fasta_many` call; the reference-side half of a files-to-table run (``bench.py``: ``fasta_to_table``).  ``stats`` (a
         dict) receives ``add_s`` (the `add_fasta_many` calls: reading, packing and the wait for a sketch in flight before the
-        append) and ``sketch_s`` (the `flush` calls on the second thread)."""
+        append) and ``sketch_s`` (the `flush` calls on the second thread).  ``keep``: a `PackedGenomes` that receives the files as
+        they are read (`PackedGenomes.extend`), so that they can be mapped later without being read again
+        (``Mapper.query_fasta_stream(keep)``: an all-vs-all)."""
         import threading
         import time
         names, paths = list(names), list(paths)
@@ -893,7 +913,12 @@ cdef class Sketch(_Parameterized):
 
         for i in range(0, len(paths), chunk):
             t0 = time.perf_counter()
-            self.add_fasta_many(names[i:i + chunk], paths[i:i + chunk])      # (its append waits for a flush in flight)
+            if keep is None:
+                self.add_fasta_many(names[i:i + chunk], paths[i:i + chunk])      # (its append waits for a flush in flight)
+            else:
+                at = len(keep)
+                keep.extend(paths[i:i + chunk])
+                self.add_packed(names[i:i + chunk], keep, at, len(paths[i:i + chunk]))
             stats["add_s"] += time.perf_counter() - t0
             if worker is not None:
                 worker.join()

@@ -105,6 +105,7 @@ SIGNATURES = {
     "fa_sketch_add_fasta": (_i32, [_vp, C.c_char_p, _P(_i64), _P(_i64)]),
     "fa_genomes_upload_fasta": (_i32, [_vp, _P(C.c_char_p), _i32, _P(_vp)]),
     "fa_packed_read": (_i32, [_P(C.c_char_p), _i32, _i32, _P(_vp)]),
+    "fa_packed_append": (_i32, [_vp, _P(C.c_char_p), _i32]),
     "fa_packed_free": (None, [_vp]),
     "fa_packed_info": (_i32, [_vp, _P(_i32), _P(C.c_uint64), _P(_i64), _P(_i64)]),
     "fa_sketch_add_packed": (_i32, [_vp, _vp, _i32, _i32, _P(_i64), _P(_i64)]),

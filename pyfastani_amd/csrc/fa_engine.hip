@@ -2171,6 +2171,16 @@ int fa_packed_read(const char *const *paths, int32_t n_paths, int protein, fa_pa
     *out = p.release();
   });
 }
+// more files behind the ones the set holds (read + packed concurrently, like fa_packed_read); all or nothing
+int fa_packed_append(fa_packed *p, const char *const *paths, int32_t n_paths) {
+  return guarded([&] {
+    FA_REQUIRE(p && paths && n_paths >= 0, FA_ERR_INVALID, "null argument or negative count");
+    std::vector<PackedFasta> more;
+    read_fasta_packed_many(paths, (size_t)n_paths, p->protein, more);
+    p->files.reserve(p->files.size() + more.size());
+    for (auto &f : more) p->files.push_back(std::move(f));
+  });
+}
 void fa_packed_free(fa_packed *p) { delete p; }
 int fa_packed_info(fa_packed *p, int32_t *n_files, uint64_t *file_bytes, int64_t *records, int64_t *bases) {
   return guarded([&] {

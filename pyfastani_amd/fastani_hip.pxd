@@ -97,6 +97,7 @@ cdef extern from "fastani_hip.h" nogil:
     ctypedef struct fa_packed:
         pass
     int fa_packed_read(const char* const* paths, int32_t n_paths, int protein, fa_packed** out)
+    int fa_packed_append(fa_packed* p, const char* const* paths, int32_t n_paths)
     void fa_packed_free(fa_packed* p)
     int fa_packed_info(fa_packed* p, int32_t* n_files, uint64_t* file_bytes, int64_t* records, int64_t* bases)
     int fa_sketch_add_packed(fa_sketch* s, fa_packed* p, int32_t first, int32_t count, int64_t* n_records, int64_t* n_short)

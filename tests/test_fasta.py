@@ -147,3 +147,8 @@ def test_packed_genomes_read_once_use_twice(tmp_path):
         pf.Sketch(protein=True, fragment_length=100).add_packed(["x"], packed, 0, 1)   # packed for the other alphabet
     with pytest.raises(OSError):
         pf.PackedGenomes([paths[0], str(tmp_path / "missing.fna")])
+    grown = pf.PackedGenomes(paths[:1]).extend(paths[1:3])
+    assert len(grown) == 3 and grown.info()[1] == [1, 2, 1]
+    with pytest.raises(OSError):
+        grown.extend([str(tmp_path / "missing.fna")])
+    assert len(grown) == 3

@@ -1104,10 +1104,13 @@ def test_fasta_ingest_matches_python_path(tmp_path):
         packed = pf.PackedGenomes(files)
         once = pf.Sketch().add_packed(range(len(files)), packed)
         assert all(np.array_equal(x, y) for x, y in zip(once._read_minimizers(), a))
+        kept = pf.PackedGenomes([])
+        piped = pf.Sketch().add_fasta_stream(range(len(files)), files, chunk=2, keep=kept)      # read once, kept, sketched behind the reader
+        assert len(kept) == len(files) and all(np.array_equal(x, y) for x, y in zip(piped._read_minimizers(), a))
         m4 = once.index()
         for chunk in (1, 2, None):
             got4 = {}
-            for first, hits in m4.query_fasta_stream(packed, chunk=chunk):
+            for first, hits in m4.query_fasta_stream(packed if chunk != 2 else kept, chunk=chunk):
                 for i, h in enumerate(hits):
                     got4[first + i] = hit_tuples(h)
             assert [got4[i] for i in range(len(files))] == want
