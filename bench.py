@@ -936,7 +936,8 @@ def fasta_to_table_leg(ctx, genomes, chunk=24, ref_chunk=125):
         read_once = {"wall_s": once_wall, "pairs_per_s": n * n / once_wall, "refs_wall_s": t_read, "refs_add_s": once_ref["add_s"], "refs_sketch_s": once_ref["sketch_s"],
                      "read_pack_GBps": nbytes / max(once_ref["add_s"], 1e-9) / 1e9,
                      "index_s": t_once_index, "stream_s": t_once_stream, "stream_refill_s": once_stats["ingest_s"],
-                     "stream_map_s": once_stats["map_s"], "device_pass_s": once_dev_ms * 1e-3, "table_sha256": _sha256_rows(once_rows)}
+                     "stream_map_s": once_stats["map_s"], "stream_wait_s": once_stats["wait_s"], "device_pass_s": once_dev_ms * 1e-3,
+                     "table_sha256": _sha256_rows(once_rows)}
         if read_once["table_sha256"] != _sha256_rows(rows):
             raise SystemExit(f"FASTA-TO-TABLE FAILURE: the read-once table ({read_once['table_sha256']}) differs from the streamed one ({_sha256_rows(rows)})")
         # host side: reading + packing (references: the add calls, which also hold the wait for the sketch in flight; queries: the
