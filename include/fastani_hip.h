@@ -245,6 +245,10 @@ int fa_debug_probe_occupancy(int lds_bytes, int *peak_alive);
 /* raw bytes of the last call's event arena (two-kernel L2 form: the slide events; FA_FUSED_DEBUG=8: per-workgroup time
  * stamps of k_l2_fused) -- development aid */
 int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes);
+/* the query-independent slide geometry the index build derives per reference record: rec_prev,
+ * rec_fwd, rec_bwd (4 bytes each) and the flag byte, `cap` records at most; *n = records of the index.  Checked against the
+ * definitions by the parity tests (there is no counterpart in the reference: slidingMap.hpp keeps a std::map instead) */
+int fa_mapper_debug_links(fa_mapper *m, int32_t *prev, int32_t *fwd, int32_t *bwd, uint8_t *flags, int64_t cap, int64_t *n);
 /* slide events per L2 locus of the last call (two-kernel form), in locus order -- development aid */
 int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, int64_t *n);
 /* last-call statistics: [0] sketch ms (K1 + fragment sort/unique), [1] lookup + L1 ms, [2] L2 ms, [3] CGI ms,

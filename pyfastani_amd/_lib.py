@@ -116,6 +116,7 @@ SIGNATURES = {
     "fa_debug_probe_occupancy": (_i32, [_i32, _P(_i32)]),
     "fa_mapper_debug_items": (_i32, [_vp, _vp, _i64]),
     "fa_mapper_debug_locus_events": (_i32, [_vp, _vp, _i64, _vp]),
+    "fa_mapper_debug_links": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "fa_mapper_last_timings": (_i32, [_vp, _P(_f32), _i32]),
     "fa_mapper_set_stage_events": (_i32, [_vp, _i32]),
     "fa_mapper_stream": (_i32, [_vp, _P(_vp)]),

@@ -648,7 +648,7 @@ static void build_index(fa_mapper &m) {
   m.U = 0;
   m.freq_threshold = INT_MAX;
   if (N > 0) {
-    DevBuf<uint32_t> iota, sorted_hash, counts, counts_sorted;
+    DevBuf<uint32_t> iota, sorted_hash, counts, counts_sorted, blk_lo;
     DevBuf<int32_t> num_runs;
     iota.ensure((size_t)N); sorted_hash.ensure((size_t)N); counts.ensure((size_t)N + 1); num_runs.ensure(1);
     tr.mark("alloc", st);
@@ -700,10 +700,22 @@ static void build_index(fa_mapper &m) {
     m.table.ensure((size_t)1 << m.table_bits);
     FA_HIP(hipMemsetAsync(m.table.p, 0, ((size_t)1 << m.table_bits) * sizeof(uint4), st));
     hipLaunchKernelGGL(k_build_table, dim3(ceil_div(U, 256)), dim3(256), 0, st, m.uniq_hash.p, m.uniq_off.p, (int64_t)U, m.table_bits, m.table.p);
-    hipLaunchKernelGGL(k_link_duplicates, dim3(ceil_div(N, 256)), dim3(256), 0, st, sorted_hash.p, m.pos_ridx.p, N, m.rec_seq.p,
-                       m.rec_wpos.p, m.cmw, m.rec_prev.p, m.rec_flags.p);
-    hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, 256)), dim3(256), 0, st, m.rec_seq.p, m.rec_wpos.p, m.contig_rec.p, N, m.cmw,
-                       m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
+    tr.mark("table", st);
+    {
+      // window links first (they write the flag bytes whole), then the same-hash links OR their bits in
+      const int halo = (int)std::min<int64_t>(((int64_t)m.cmw + 2 + 63) / 64 * 64, WL_HALO_MAX);
+      hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, WL_TILE)), dim3(WL_THREADS), (size_t)(WL_TILE + 2 * halo) * sizeof(int32_t), st, m.rec_seq.p,
+                         m.rec_wpos.p, m.contig_rec.p, N, m.cmw, halo, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
+      // (FA_LINK_BLOCK_BITS: the tests shrink the blocks so that a small index has blocks inside a contig AND straddling ones)
+      const int shift = (int)std::min<uint64_t>(20, std::max<uint64_t>(2, env_u64("FA_LINK_BLOCK_BITS", 10)));
+      const int64_t blocks = (N + ((int64_t)1 << shift) - 1) >> shift;
+      blk_lo.ensure((size_t)blocks + 1);
+      hipLaunchKernelGGL(k_block_contig, dim3(ceil_div(blocks, 256)), dim3(256), 0, st, m.rec_seq.p, m.contig_rec.p, N, shift, blk_lo.p);
+      FA_HIP(hipMemsetAsync(m.rec_prev.p, 0xFF, (size_t)N * sizeof(int32_t), st));
+      hipLaunchKernelGGL(k_link_duplicates, dim3(ceil_div(N, 256)), dim3(256), 0, st, sorted_hash.p, m.pos_ridx.p, N, m.rec_seq.p, m.rec_wpos.p,
+                         m.contig_rec.p, blk_lo.p, shift, m.cmw, m.rec_prev.p, m.rec_flags.p);
+    }
+    tr.mark("links", st);
     {
       // padded global coordinate of every record (k_rec_gpos): spans of the contigs, their prefix sums, the low words
       DevBuf<unsigned long long> span, base;
@@ -747,7 +759,7 @@ static void build_index(fa_mapper &m) {
     }
     FA_HIP(hipGetLastError());
     FA_HIP(hipStreamSynchronize(st));
-    tr.mark("table_links", st);
+    tr.mark("geometry", st);
   } else {
     m.table_bits = 4;
     m.table.ensure(16);
@@ -2663,6 +2675,20 @@ int fa_mapper_debug_items(fa_mapper *m, void *out, int64_t bytes) {
     Workspace &w = m->ws[m->last_ws];
     FA_REQUIRE(bytes >= 0 && (size_t)bytes <= w.items.cap, FA_ERR_INVALID, "more bytes than the event arena holds");
     FA_HIP(hipMemcpy(out, w.items.p, (size_t)bytes, hipMemcpyDeviceToHost));
+  });
+}
+int fa_mapper_debug_links(fa_mapper *m, int32_t *prev, int32_t *fwd, int32_t *bwd, uint8_t *flags, int64_t cap, int64_t *n) {
+  return guarded([&] {
+    std::lock_guard<std::mutex> lock(m->mtx);
+    bind_device(m->device);
+    const size_t c = (size_t)std::max<int64_t>(0, std::min<int64_t>(m->N, cap));
+    if (c) {
+      FA_HIP(hipMemcpy(prev, m->rec_prev.p, c * 4, hipMemcpyDeviceToHost));
+      FA_HIP(hipMemcpy(fwd, m->rec_fwd.p, c * 4, hipMemcpyDeviceToHost));
+      FA_HIP(hipMemcpy(bwd, m->rec_bwd.p, c * 4, hipMemcpyDeviceToHost));
+      FA_HIP(hipMemcpy(flags, m->rec_flags.p, c, hipMemcpyDeviceToHost));
+    }
+    *n = m->N;
   });
 }
 int fa_mapper_debug_locus_events(fa_mapper *m, uint32_t *events, int64_t cap, int64_t *n) {

@@ -107,26 +107,40 @@ __global__ void k_contig_ranges(const int32_t *rec_seq, int64_t N, int C, int32_
 // position p for p in [a_i, b_i], a_i = wpos_i - cmw + 1, b_i = wpos_{i+1} - 1 (next record of the contig; +inf for
 // the last one).  Two consecutive same-hash records (j, i) are `linked` when b_j >= a_i - 1: the hash never leaves
 // the window between them, so admitting i / dropping j must not change the set (slidingMap.hpp REV / NOOP cases).
+//
+// The pass streams the sorted (hash, record) pairs and touches the records themselves only for a pair inside ONE contig, which
+// is the rare case (a repeat inside a contig; relatives in other genomes are the common one).  "Same contig" is p >= first
+// record of cur's contig (p < cur: the sort is stable), and that first record comes from a table with one entry per 2^shift
+// consecutive records (k_block_contig; 1.6 MB for 4 x 10^8 records -- it lives in L2) instead of two gathers behind the TLB;
+// blocks that straddle a contig boundary say so and take the gather.  rec_prev is pre-filled with -1 by the caller, rec_flags
+// hold FLAG_SAME_STEP or 0 (k_window_links runs first).
 constexpr uint8_t FLAG_INS_LINKED = 1, FLAG_DEL_LINKED = 2;
+constexpr uint32_t BLOCK_STRADDLES = 0xFFFFFFFFu;
+__global__ void k_block_contig(const int32_t *rec_seq, const int32_t *contig_rec, int64_t N, int shift, uint32_t *blk_lo) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t first = b << shift;
+  if (first >= N) return;
+  const int64_t last = min(N - 1, first + ((int64_t)1 << shift) - 1);
+  const int c = rec_seq[first];
+  blk_lo[b] = rec_seq[last] == c ? (uint32_t)contig_rec[c] : BLOCK_STRADDLES;
+}
 __global__ void k_link_duplicates(const uint32_t *sorted_hash, const uint32_t *pos_ridx, int64_t N, const int32_t *rec_seq,
-                                  const int32_t *rec_wpos, int cmw, int32_t *rec_prev, uint8_t *rec_flags) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  uint32_t cur = pos_ridx[i];
-  int32_t prev = -1;
-  if (i > 0 && sorted_hash[i - 1] == sorted_hash[i]) {
-    uint32_t p = pos_ridx[i - 1];
-    if (rec_seq[p] == rec_seq[cur]) prev = (int32_t)p;
-  }
-  rec_prev[cur] = prev;
-  if (prev >= 0) {
-    // prev + 1 <= cur exists and lies in the same contig (records of a contig are contiguous)
-    int64_t b_prev = (int64_t)rec_wpos[prev + 1] - 1;
-    int64_t a_cur = (int64_t)rec_wpos[cur] - cmw + 1;
-    if (b_prev >= a_cur - 1) {
-      atomicOr((unsigned int *)(rec_flags + (cur & ~3u)), (unsigned int)FLAG_INS_LINKED << (8 * (cur & 3u)));
-      atomicOr((unsigned int *)(rec_flags + ((uint32_t)prev & ~3u)), (unsigned int)FLAG_DEL_LINKED << (8 * ((uint32_t)prev & 3u)));
-    }
+                                  const int32_t *rec_wpos, const int32_t *contig_rec, const uint32_t *blk_lo, int shift, int cmw,
+                                  int32_t *rec_prev, uint8_t *rec_flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N || i == 0) return;
+  if (sorted_hash[i - 1] != sorted_hash[i]) return;
+  const uint32_t cur = pos_ridx[i], p = pos_ridx[i - 1];
+  uint32_t lo = blk_lo[cur >> shift];
+  if (lo == BLOCK_STRADDLES) lo = (uint32_t)contig_rec[rec_seq[cur]];
+  if (p < lo) return;                            // the earlier record with this hash lies in another contig
+  rec_prev[cur] = (int32_t)p;
+  // p + 1 <= cur exists and lies in the same contig (records of a contig are contiguous)
+  const int64_t b_prev = (int64_t)rec_wpos[p + 1] - 1;
+  const int64_t a_cur = (int64_t)rec_wpos[cur] - cmw + 1;
+  if (b_prev >= a_cur - 1) {
+    atomicOr((unsigned int *)(rec_flags + (cur & ~3u)), (unsigned int)FLAG_INS_LINKED << (8 * (cur & 3u)));
+    atomicOr((unsigned int *)(rec_flags + (p & ~3u)), (unsigned int)FLAG_DEL_LINKED << (8 * (p & 3u)));
   }
 }
 
@@ -136,34 +150,51 @@ __global__ void k_link_duplicates(const uint32_t *sorted_hash, const uint32_t *p
 //   FLAG_SAME_STEP on record r: the window position that drops r (wpos[r+1]) also admits a record
 // With these, the position of every admit / drop event in the time-ordered event stream of a locus is plain
 // arithmetic (no merge search per query).
+//
+// Three binary searches per record over the window positions of at most cmw records either side (wpos is strictly increasing
+// inside a contig).  A workgroup takes WL_TILE consecutive records and holds their window positions plus `halo` records either
+// side in LDS, so the ~36 dependent reads of a record are LDS reads; whatever a search needs outside (cmw > WL_HALO_MAX: the
+// caller passes the largest halo that fits) is read from memory -- `at()` is the only difference from a search over the array.
+// The flags are written as whole bytes (FLAG_SAME_STEP or 0): this kernel runs before k_link_duplicates ORs its bits in.
 constexpr uint8_t FLAG_SAME_STEP = 4;
-__global__ void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, const int32_t *contig_rec, int64_t N, int cmw,
-                               int32_t *rec_fwd, int32_t *rec_bwd, uint8_t *rec_flags) {
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const int c = rec_seq[i];
-  const int lo = contig_rec[c], hi = contig_rec[c + 1];
-  const int w = rec_wpos[i];
-  {
-    int x = (int)i + 1, y = min(hi, (int)i + 1 + cmw), key = w + cmw;   // wpos is strictly increasing: at most cmw records ahead
-    if (y < hi && rec_wpos[y - 1] < key) y = hi;
-    while (x < y) { int mid = (x + y) >> 1; if (rec_wpos[mid] < key) x = mid + 1; else y = mid; }
-    rec_fwd[i] = x;
+constexpr int WL_TILE = 4096, WL_THREADS = 512, WL_HALO_MAX = 5120;   // 56 KB of LDS at most
+__global__ __launch_bounds__(WL_THREADS) void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, const int32_t *contig_rec, int64_t N,
+                                                           int cmw, int halo, int32_t *rec_fwd, int32_t *rec_bwd, uint8_t *rec_flags) {
+  extern __shared__ int32_t wl_w[];
+  const int64_t t0 = (int64_t)blockIdx.x * WL_TILE;
+  const int64_t first = t0 - halo;                                      // record of wl_w[0]
+  const int held = WL_TILE + 2 * halo;
+  for (int j = threadIdx.x; j < held; j += WL_THREADS) {
+    const int64_t r = first + j;
+    wl_w[j] = r >= 0 && r < N ? rec_wpos[r] : 0;
   }
-  {
-    int x = max(lo, (int)i - cmw), y = (int)i + 1, key = w - cmw + 1;    // first index with wpos > key, minus one
-    if (x > lo && rec_wpos[x] > key) x = lo;
-    while (x < y) { int mid = (x + y) >> 1; if (rec_wpos[mid] <= key) x = mid + 1; else y = mid; }
-    rec_bwd[i] = x - 1;
-  }
-  if (i + 1 < hi) {
-    int key = rec_wpos[i + 1] + cmw - 1;
-    int x = (int)i + 1, y = hi;
-    int cap = min(hi, (int)i + 2 + cmw);
-    if (cap < hi && rec_wpos[cap - 1] >= key) y = cap;
-    while (x < y) { int mid = (x + y) >> 1; if (rec_wpos[mid] < key) x = mid + 1; else y = mid; }
-    if (x < hi && rec_wpos[x] == key)
-      atomicOr((unsigned int *)(rec_flags + ((uint32_t)i & ~3u)), (unsigned int)FLAG_SAME_STEP << (8 * ((uint32_t)i & 3u)));
+  __syncthreads();
+  const int64_t s_lo = max((int64_t)0, first), s_hi = min(N, first + held);
+  auto at = [&](int r) -> int { return r >= s_lo && r < s_hi ? wl_w[r - first] : rec_wpos[r]; };
+  for (int q = 0; q < WL_TILE / WL_THREADS; q++) {
+    const int64_t i = t0 + q * WL_THREADS + threadIdx.x;
+    if (i >= N) return;
+    const int c = rec_seq[i];
+    const int lo = contig_rec[c], hi = contig_rec[c + 1];
+    const int w = wl_w[i - first];
+    {
+      int x = (int)i + 1, y = min(hi, (int)i + 1 + cmw), key = w + cmw;   // wpos is strictly increasing: at most cmw records ahead
+      while (x < y) { int mid = (x + y) >> 1; if (at(mid) < key) x = mid + 1; else y = mid; }
+      rec_fwd[i] = x;
+    }
+    {
+      int x = max(lo, (int)i - cmw), y = (int)i + 1, key = w - cmw + 1;    // first index with wpos > key, minus one
+      while (x < y) { int mid = (x + y) >> 1; if (at(mid) <= key) x = mid + 1; else y = mid; }
+      rec_bwd[i] = x - 1;
+    }
+    uint8_t flag = 0;
+    if (i + 1 < hi) {
+      const int key = at((int)i + 1) + cmw - 1;
+      int x = (int)i + 1, y = min(hi, (int)i + 2 + cmw);                   // wpos[i + 1 + cmw] >= wpos[i + 1] + cmw > key
+      while (x < y) { int mid = (x + y) >> 1; if (at(mid) < key) x = mid + 1; else y = mid; }
+      if (x < hi && at(x) == key) flag = FLAG_SAME_STEP;
+    }
+    rec_flags[i] = flag;
   }
 }
 

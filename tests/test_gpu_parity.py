@@ -1531,3 +1531,67 @@ def test_add_drafts_gives_the_records_of_add_draft():
         m1, m2 = many.index(), loop.index()
         q = [bytes(syn.to_ascii(syn.mutate_codes(g, anc, 0.02)))]
         assert hit_tuples(m1.query_draft(q)) == hit_tuples(m2.query_draft(q)) and len(m1.query_draft(q)) == 3
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the slide geometry of the index build (rec_prev / rec_fwd / rec_bwd / flags) against its definitions
+# ----------------------------------------------------------------------------------------------------------------
+def _links_by_definition(h, s, w, cmw):
+    """DESIGN.md section 3 in numpy, contig by contig: what k_window_links and k_link_duplicates must produce."""
+    n = len(h)
+    fwd, bwd = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    prev, flags = np.full(n, -1, np.int32), np.zeros(n, np.uint8)
+    bounds = np.flatnonzero(np.diff(s)) + 1
+    for lo, hi in zip(np.r_[0, bounds], np.r_[bounds, n]):
+        wp = w[lo:hi].astype(np.int64)
+        fwd[lo:hi] = lo + np.searchsorted(wp, wp + cmw, "left")
+        bwd[lo:hi] = lo + np.searchsorted(wp, wp - cmw + 1, "right") - 1
+        same = np.isin(wp[1:] + cmw - 1, wp)                     # the position that drops r (wpos[r + 1]) also admits a record
+        flags[lo:hi - 1][same] |= 4
+        order = np.argsort(h[lo:hi], kind="stable")              # same hash, consecutive in record order, same contig
+        hs = h[lo:hi][order]
+        dup = np.flatnonzero(hs[1:] == hs[:-1])
+        cur, prv = lo + order[dup + 1], lo + order[dup]
+        prev[cur] = prv
+        linked = (w[prv + 1].astype(np.int64) - 1) >= (w[cur].astype(np.int64) - cmw)
+        flags[cur[linked]] |= 1
+        np.bitwise_or.at(flags, prv[linked], 2)
+    return prev, fwd, bwd, flags
+
+
+def _check_links(params, seed):
+    g = syn.rng(seed)
+    sk = pf.Sketch(**params)
+    frag, k = sk.fragment_length, sk.k
+    for i in range(5):
+        base = syn.random_codes(g, 120_000)
+        base[40_000:52_000] = base[10_000:22_000]                 # a repeat inside the contig: earlier records with the same hash
+        base[90_000:90_400] = 0                                   # a low-complexity run: same hash in consecutive windows
+        seq = syn.to_ascii(base)
+        sk.add_draft(f"g{i}", [seq[:70_000], seq[70_000:110_000], seq[110_000:], seq[:frag + 50]])
+    mapper = sk.index()
+    h, s, w = mapper.minimizers._arrays()
+    n = len(h)
+    prev, fwd, bwd = (np.empty(n, np.int32) for _ in range(3))
+    flags = np.empty(n, np.uint8)
+    got = C.c_int64(0)
+    check(lib.fa_mapper_debug_links(mapper._h, prev.ctypes.data, fwd.ctypes.data, bwd.ctypes.data, flags.ctypes.data, n, C.byref(got)))
+    assert got.value == n
+    cmw = max(1, frag - (mapper.window_size - 1) - (k - 1))
+    wprev, wfwd, wbwd, wflags = _links_by_definition(h, s, w, cmw)
+    assert (wprev >= 0).sum() > 100 and (wflags & 1).any() and (wflags & 2).any() and (wflags & 4).any()
+    assert np.array_equal(fwd, wfwd) and np.array_equal(bwd, wbwd)
+    assert np.array_equal(prev, wprev)
+    assert np.array_equal(flags, wflags)
+    return cmw
+
+
+@pytest.mark.parametrize("bits", ["2", "6", "10"])
+def test_index_links_match_their_definitions(bits, monkeypatch):
+    """Blocks of 4 and 64 records (inside one contig or straddling a boundary) and the default of 1 024 (every block of this
+    small index straddles: the gather path); default parameters (cmw = 2 962: halo inside LDS), a short fragment (cmw of a few
+    hundred) and a long one with w = 1 (cmw > the largest LDS halo: the searches leave the tile)."""
+    monkeypatch.setenv("FA_LINK_BLOCK_BITS", bits)
+    assert _check_links({}, 31) == 2962
+    assert _check_links({"fragment_length": 500, "k": 16}, 32) < 500
+    assert _check_links({"fragment_length": 7000, "percentage_identity": 60.0, "k": 12}, 33) > 5120
