@@ -31,6 +31,7 @@ import json
 import os
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -163,6 +164,45 @@ def fence(ctx):
     if ctx["dist_on"]:
         ctx["dist"].barrier()
     ctx["torch"].cuda.synchronize()
+
+
+def shared_workload(ctx, tag, make):
+    """`make()` -> (genomes as contig lists, family ids), generated ONCE per node: with several ranks, rank 0 writes the contigs
+    back to back into one file in /dev/shm (5 GB and ~30 s of numpy for config 3) and the others map it read-only; every rank
+    gets the same list-of-contig-lists shape (uint8 views into the mapping).  One rank: `make()` and nothing else."""
+    rank, world = ctx["rank"], ctx["world"]
+    if world == 1 or not ctx["dist_on"]:
+        return make()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    stem = os.path.join(base, f"fa_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{tag}")
+    if rank == 0:
+        genomes, fam = make()
+        lens = np.array([len(c) for contigs in genomes for c in contigs], np.int64)
+        counts = np.array([len(contigs) for contigs in genomes], np.int64)
+        with open(stem + ".bin", "wb") as f:
+            for contigs in genomes:
+                for c in contigs:
+                    f.write(c)
+        np.savez(stem + ".npz", lens=lens, counts=counts, fam=np.asarray(fam))
+    fence(ctx)
+    try:
+        meta = np.load(stem + ".npz")
+        flat = np.memmap(stem + ".bin", np.uint8, "r")
+        offs = np.concatenate([[0], np.cumsum(meta["lens"])])
+        genomes, q = [], 0
+        for k in meta["counts"]:
+            genomes.append([flat[offs[j]:offs[j + 1]] for j in range(q, q + int(k))])
+            q += int(k)
+        fam = meta["fam"]
+    finally:
+        fence(ctx)
+        if rank == 0:                       # (the mappings of the other ranks stay valid after the unlink)
+            for ext in (".bin", ".npz"):
+                try:
+                    os.unlink(stem + ext)
+                except OSError:
+                    pass
+    return genomes, fam
 
 
 def max_over_ranks(ctx, seconds):
@@ -774,7 +814,7 @@ def strong_core(ctx, steps, warmup):
     from pyfastani_amd import workloads, sharding
     from pyfastani_amd._lib import lib
     t0 = time.time()
-    genomes, fam = workloads.config3(args.families, args.members, args.length)
+    genomes, fam = shared_workload(ctx, "config3", lambda: workloads.config3(args.families, args.members, args.length))
     t_gen = time.time() - t0
     n = len(genomes)
     mapper, index_mode, t_pack, t_index = build_mapper(ctx, list(range(n)), genomes)
