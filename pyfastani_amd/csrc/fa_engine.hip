@@ -1060,7 +1060,12 @@ struct QueryPass {
     RowsArgs ra;
     ra.bins = w.bins.p; ra.genome_bin = m.genome_bin.p; ra.total_bins = m.total_bins; ra.G = m.G; ra.NQ = NQ;
     ra.row_count = w.row_count.p; ra.row_ident = w.row_ident.p;
-    ra.emit = npairs <= 16384;                     // small passes: the last workgroup of k_cgi_rows also forms the rows
+    // small passes: the last workgroup of k_cgi_rows also forms the rows and hands the pass over -- five launches less.  Every
+    // workgroup pays for it with a device-scope fence, which writes its XCD's L2 back: ~1 us each, one after another per XCD.
+    // Break-even at 400-800 pairs (profiles/r05_emit_threshold.txt); at the 12-14 000 pairs of a 24-genome chunk against 500
+    // references the fences were 0.44 of the 0.52 ms of the kernel.  (FA_ROWS_EMIT_MAX: the measurement's knob, <= 16384)
+    static const int64_t emit_max = (int64_t)env_u64("FA_ROWS_EMIT_MAX", 512);
+    ra.emit = npairs <= std::min<int64_t>(emit_max, 16384);
     ra.pub = pub;
     if (!ra.emit) ra.pub.seq = 0;
     ra.done = d_counters + 4; ra.query_total_frag = g.d_total_frag + g0; ra.query_id_base = g0;
@@ -1704,8 +1709,9 @@ static int64_t run_query(fa_mapper &m, Workspace &w, const fa_genomes &g, int32_
   }
   if (!rows_device && nrows) {
     const size_t bytes = (size_t)nrows * sizeof(fa_cgi_row);
-    if (!host_rows) {
+    if (!host_rows || nrows > ROWS_INLINE_MAX) {
       // through pinned memory: a device-to-pageable copy of a few KB costs more in staging than the copy itself
+      // (host_rows set: the publishing workgroup leaves more than ROWS_INLINE_MAX rows to this copy)
       w.pin_rows.ensure(std::max<size_t>(bytes, 4096));
       FA_HIP(hipMemcpyAsync(w.pin_rows.p, w.rows_dev.p, bytes, hipMemcpyDeviceToHost, w.stream));
       FA_HIP(hipStreamSynchronize(w.stream));

@@ -2433,6 +2433,7 @@ __global__ void k_cgi_bins(CgiArgs a) {
 // Hand-over of a pass to the host (fa_engine.hip, k_publish_status): the status block and, for a one-query call, the hit
 // rows are copied into pinned host memory, then the pass number is released for the host that polls it.  Run by one
 // workgroup: the last one of k_cgi_rows when that kernel also forms the rows, else a kernel of its own.
+constexpr int ROWS_INLINE_MAX = 256;    // rows the publishing workgroup writes into pinned host memory itself
 struct PublishArgs {
   uint32_t *status_dev;              // the device status block, as words
   uint32_t *status_host;             // its pinned mirror
@@ -2453,11 +2454,22 @@ __device__ __forceinline__ void publish_pass(const PublishArgs &p) {
   __syncthreads();
   for (int i = threadIdx.x; i < p.words; i += blockDim.x) p.status_host[i] = p.status_dev[i];
   if (p.rows_host) {
+    // every store to the mapped host buffer is a transaction over PCIe (~60 ns a piece, whatever its width): 16-byte pieces,
+    // and only for the few rows of a one-query call -- the host fetches more than ROWS_INLINE_MAX rows with one DMA copy
+    // (1 450 rows of a 29-genome chunk took 0.44 ms word by word)
     const int64_t n = min((int64_t)*p.total_rows, p.cap);
-    static_assert(sizeof(fa_cgi_row) % 4 == 0, "rows are copied word by word");
-    const uint32_t *rs = (const uint32_t *)p.rows_dev;
-    uint32_t *rd = (uint32_t *)p.rows_host;
-    for (int64_t i = threadIdx.x; i < n * (int64_t)(sizeof(fa_cgi_row) / 4); i += blockDim.x) rd[i] = rs[i];
+    static_assert(sizeof(fa_cgi_row) % 4 == 0, "rows are copied in words");
+    if (n <= ROWS_INLINE_MAX) {
+      const int64_t words = n * (int64_t)(sizeof(fa_cgi_row) / 4);
+      const bool aligned = ((((uintptr_t)p.rows_dev) | ((uintptr_t)p.rows_host)) & 15) == 0;
+      const int64_t quads = aligned ? words / 4 : 0;
+      const uint4 *qs = (const uint4 *)p.rows_dev;
+      uint4 *qd = (uint4 *)p.rows_host;
+      for (int64_t i = threadIdx.x; i < quads; i += blockDim.x) qd[i] = qs[i];
+      const uint32_t *rs = (const uint32_t *)p.rows_dev;
+      uint32_t *rd = (uint32_t *)p.rows_host;
+      for (int64_t i = quads * 4 + threadIdx.x; i < words; i += blockDim.x) rd[i] = rs[i];
+    }
   }
   __threadfence_system();
   __syncthreads();
@@ -2533,21 +2545,34 @@ __global__ __launch_bounds__(256) void k_cgi_rows(RowsArgs a) {
   __syncthreads();
   if (!sh_last) return;
   __threadfence();
-  if (threadIdx.x == 0) sh_run = 0;
-  __syncthreads();
+  // Ordered compaction of the non-empty pairs by this one workgroup: thread t owns `per` consecutive pairs (emit is only set
+  // for npairs <= 16384: per <= 64; 512 by default: per <= 2), counts its non-empty ones -- the loads of a thread do not depend
+  // on one another: one round trip to L2 --, one scan over the 256 counts gives its first row, then it writes its rows in order.
   const volatile int32_t *rc = a.row_count;
   const volatile float *ri = a.row_ident;
   const int n = (int)npairs;
-  for (int i0 = 0; i0 < n; i0 += 256) {
-    const int p = i0 + threadIdx.x;
-    const int c = p < n ? rc[p] : 0;
-    const bool keep = c != 0;
-    const uint64_t bal = __ballot(keep);
-    if (lane == 0) sh_wave[wv] = __popcll(bal);
-    __syncthreads();
-    int off = sh_run + __popcll(bal & ((1ULL << lane) - 1ULL));
-    for (int w = 0; w < wv; w++) off += sh_wave[w];
-    if (keep && off < a.cap) {
+  const int per = (n + 255) / 256;
+  const int p0 = min(n, (int)threadIdx.x * per), p1 = min(n, p0 + per);
+  int mine = 0;
+  for (int p = p0; p < p1; p += 8) {
+    int c[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) c[u] = p + u < p1 ? rc[p + u] : 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) mine += c[u] != 0;
+  }
+  int incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+  if (lane == 63) sh_wave[wv] = incl;
+  __syncthreads();
+  int off = incl - mine;
+  for (int w = 0; w < wv; w++) off += sh_wave[w];
+  if (threadIdx.x == 0) sh_run = sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+  for (int p = p0; p < p1 && mine; p++) {
+    const int c = rc[p];
+    if (c == 0) continue;
+    if (off < a.cap) {
       fa_cgi_row r;
       r.query_id = a.query_id_base + p / a.G;
       r.ref_genome_id = p % a.G;
@@ -2556,10 +2581,9 @@ __global__ __launch_bounds__(256) void k_cgi_rows(RowsArgs a) {
       r.identity = ri[p];
       a.rows[off] = r;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) sh_run += sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
-    __syncthreads();
+    off++; mine--;
   }
+  __syncthreads();
   if (threadIdx.x == 0) *a.total_rows = sh_run;
   if (a.pub.seq) {
     __threadfence();

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+export TMPDIR=/tmp
+OUT=gpurun_out/r05_cgi_tail
+mkdir -p $OUT
+for e in 16384 2048 256; do
+FA_ROWS_EMIT_MAX=$e python3 bench.py --leg config4 > $OUT/config4_$e.json 2> $OUT/config4_$e.err
+python3 - $e <<'PY'
+import json, sys
+d=json.loads(open(f"gpurun_out/r05_cgi_tail/config4_{sys.argv[1]}.json").read().strip().splitlines()[-1])
+print(sys.argv[1], {k: d[k] for k in ("value","ms_per_step","phases_ms","table_sha256") if k in d})
+PY
+done
