@@ -50,3 +50,43 @@ def test_default_arguments_are_one_gpu():
     finally:
         sys.argv = old
     assert args.gpus == 1 and args.steps > 0
+
+
+def test_the_strong_workload_is_generated_once_and_mapped_by_the_other_ranks(monkeypatch):
+    """`shared_workload`: rank 0 writes the contigs into one file, the other ranks map it; same genomes, same shape, the files
+    gone afterwards.  Two 'ranks' are two threads here, the barrier a threading.Barrier (no GPU, no process group)."""
+    import glob
+    import tempfile
+    import threading
+    import types
+
+    import numpy as np
+    bench = _load_bench()
+    barrier = threading.Barrier(2)
+    fake_dist = types.SimpleNamespace(barrier=barrier.wait)
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(synchronize=lambda: None))
+    monkeypatch.setenv("MASTER_PORT", "45678")
+    made, out = [], {}
+
+    def make():
+        made.append(1)
+        g = np.random.default_rng(5)
+        genomes = [[bytes(g.integers(65, 70, n, dtype=np.uint8)) for n in sizes] for sizes in ([100, 0, 7], [33], [5, 5])]
+        return genomes, np.array([0, 0, 1])
+
+    def rank(r):
+        ctx = {"rank": r, "world": 2, "dist_on": True, "dist": fake_dist, "torch": fake_torch}
+        out[r] = bench.shared_workload(ctx, "unit", make)
+    threads = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    [t.start() for t in threads]
+    [t.join(60) for t in threads]
+    assert len(made) == 1 and set(out) == {0, 1}
+    want, fam = make()
+    for r in range(2):
+        genomes, f = out[r]
+        assert [[bytes(c) for c in contigs] for contigs in genomes] == want and list(f) == list(fam)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    assert glob.glob(os.path.join(base, "fa_bench_45678_*_unit.*")) == []
+    # one rank: nothing is written
+    alone = bench.shared_workload({"rank": 0, "world": 1, "dist_on": False}, "unit", make)
+    assert [[bytes(c) for c in contigs] for contigs in alone[0]] == want
