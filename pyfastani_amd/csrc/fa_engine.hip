@@ -677,14 +677,43 @@ static void build_index(fa_mapper &m) {
     // frequency threshold (computeFreqHist): walk the distinct list lengths from the most frequent down
     int64_t to_ignore = (int64_t)((float)(int64_t)U * 0.001f / 100);
     int64_t M = std::min<int64_t>(U, to_ignore + 1);
-    counts_sorted.ensure((size_t)U);
-    bytes = 0;
-    FA_HIP(rocprim::radix_sort_keys_desc(nullptr, bytes, counts.p, counts_sorted.p, (size_t)U, 0u, 32u, st));
-    temp.ensure(bytes + 16);
-    FA_HIP(rocprim::radix_sort_keys_desc(temp.p, bytes, counts.p, counts_sorted.p, (size_t)U, 0u, 32u, st));
-    std::vector<uint32_t> top((size_t)M);
-    counts_sorted.download(top.data(), (size_t)M, st);
-    FA_HIP(hipStreamSynchronize(st));
+    // the M largest list lengths, in descending order: from a histogram of the short lists plus the long ones verbatim
+    // (k_length_histogram); only an index with more than 65 536 lists of 4 096 positions and more sorts all lengths instead
+    std::vector<uint32_t> top;
+    top.reserve((size_t)M);
+    {
+      // (FA_FREQ_OVER_CAP: the tests shrink the room for long lists -- 1 = none fits -- so that the sort is exercised too)
+      const uint32_t OVER_CAP = (uint32_t)std::min<uint64_t>(1u << 16, env_u64("FA_FREQ_OVER_CAP", 1u << 16));
+      DevBuf<unsigned long long> d_hist;
+      DevBuf<uint32_t> d_over;
+      d_hist.ensure(FREQ_BINS + 1); d_over.ensure(OVER_CAP);
+      FA_HIP(hipMemsetAsync(d_hist.p, 0, (FREQ_BINS + 1) * sizeof(unsigned long long), st));
+      uint32_t *d_over_n = (uint32_t *)(d_hist.p + FREQ_BINS);
+      hipLaunchKernelGGL(k_length_histogram, dim3((unsigned)std::min<int64_t>(ceil_div(U, 256), 4096)), dim3(256), 0, st, counts.p, (int64_t)U, d_hist.p,
+                         d_over.p, OVER_CAP, d_over_n);
+      std::vector<unsigned long long> h_hist(FREQ_BINS + 1);
+      d_hist.download(h_hist.data(), FREQ_BINS + 1, st);
+      FA_HIP(hipStreamSynchronize(st));
+      const uint32_t n_over = (uint32_t)(h_hist[FREQ_BINS] & 0xFFFFFFFFu);
+      if (n_over < OVER_CAP || n_over == 0) {
+        std::vector<uint32_t> h_over(n_over);
+        if (n_over) { d_over.download(h_over.data(), n_over, st); FA_HIP(hipStreamSynchronize(st)); }
+        std::sort(h_over.begin(), h_over.end(), std::greater<uint32_t>());
+        for (uint32_t i = 0; i < n_over && (int64_t)top.size() < M; i++) top.push_back(h_over[i]);
+        for (int b = FREQ_BINS - 1; b >= 0 && (int64_t)top.size() < M; b--)
+          for (unsigned long long c = h_hist[(size_t)b]; c > 0 && (int64_t)top.size() < M; c--) top.push_back((uint32_t)b);
+      } else {
+        counts_sorted.ensure((size_t)U);
+        bytes = 0;
+        FA_HIP(rocprim::radix_sort_keys_desc(nullptr, bytes, counts.p, counts_sorted.p, (size_t)U, 0u, 32u, st));
+        temp.ensure(bytes + 16);
+        FA_HIP(rocprim::radix_sort_keys_desc(temp.p, bytes, counts.p, counts_sorted.p, (size_t)U, 0u, 32u, st));
+        top.resize((size_t)M);
+        counts_sorted.download(top.data(), (size_t)M, st);
+        FA_HIP(hipStreamSynchronize(st));
+      }
+    }
+    FA_REQUIRE((int64_t)top.size() == M, FA_ERR_INTERNAL, "list-length histogram does not add up");
     for (int64_t i = 0; i < M;) {
       int64_t j = i;
       while (j < M && top[j] == top[i]) j++;
@@ -698,14 +727,20 @@ static void build_index(fa_mapper &m) {
     m.table_bits = std::max(4, floor_log2(std::max(U, 1)) + 2);
     FA_REQUIRE(m.table_bits <= 31, FA_ERR_UNSUPPORTED, "too many distinct minimizers for the lookup table");
     m.table.ensure((size_t)1 << m.table_bits);
+    tr.mark("table_alloc", st);
     FA_HIP(hipMemsetAsync(m.table.p, 0, ((size_t)1 << m.table_bits) * sizeof(uint4), st));
+    tr.mark("table_clear", st);
     hipLaunchKernelGGL(k_build_table, dim3(ceil_div(U, 256)), dim3(256), 0, st, m.uniq_hash.p, m.uniq_off.p, (int64_t)U, m.table_bits, m.table.p);
     tr.mark("table", st);
     {
       // window links first (they write the flag bytes whole), then the same-hash links OR their bits in
       const int halo = (int)std::min<int64_t>(((int64_t)m.cmw + 2 + 63) / 64 * 64, WL_HALO_MAX);
-      hipLaunchKernelGGL(k_window_links, dim3(ceil_div(N, WL_TILE)), dim3(WL_THREADS), (size_t)(WL_TILE + 2 * halo) * sizeof(int32_t), st, m.rec_seq.p,
-                         m.rec_wpos.p, m.contig_rec.p, N, m.cmw, halo, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
+      if (halo >= m.cmw + 2)
+        hipLaunchKernelGGL(k_window_links<true>, dim3(ceil_div(N, WL_TILE)), dim3(WL_THREADS), (size_t)(WL_TILE + 2 * halo) * sizeof(int32_t), st, m.rec_seq.p,
+                           m.rec_wpos.p, m.contig_rec.p, N, m.cmw, halo, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
+      else
+        hipLaunchKernelGGL(k_window_links<false>, dim3(ceil_div(N, WL_TILE)), dim3(WL_THREADS), (size_t)(WL_TILE + 2 * halo) * sizeof(int32_t), st, m.rec_seq.p,
+                           m.rec_wpos.p, m.contig_rec.p, N, m.cmw, halo, m.rec_fwd.p, m.rec_bwd.p, m.rec_flags.p);
       // (FA_LINK_BLOCK_BITS: the tests shrink the blocks so that a small index has blocks inside a contig AND straddling ones)
       const int shift = (int)std::min<uint64_t>(20, std::max<uint64_t>(2, env_u64("FA_LINK_BLOCK_BITS", 10)));
       const int64_t blocks = (N + ((int64_t)1 << shift) - 1) >> shift;

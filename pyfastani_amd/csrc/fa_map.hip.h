@@ -94,6 +94,27 @@ __global__ void k_list_lengths(const uint32_t *uniq_off, int64_t U, int32_t *cou
   if (u < U) counts[u] = (int32_t)(uniq_off[u + 1] - uniq_off[u]);
 }
 
+// computeFreqHist needs the largest list lengths only (the top 0.001 % of the distinct hashes): a histogram of the lengths
+// below FREQ_BINS (LDS per workgroup, then one atomic per occupied bin) and the few longer ones verbatim, instead of a
+// descending sort of all lengths.  `over_n` counts every long list; those beyond `over_cap` are not stored (the caller sorts then).
+constexpr int FREQ_BINS = 4096;
+__global__ __launch_bounds__(256) void k_length_histogram(const uint32_t *counts, int64_t U, unsigned long long *hist, uint32_t *over,
+                                                           uint32_t over_cap, uint32_t *over_n) {
+  __shared__ uint32_t sh[FREQ_BINS];
+  for (int i = threadIdx.x; i < FREQ_BINS; i += 256) sh[i] = 0;
+  __syncthreads();
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < U; u += (int64_t)gridDim.x * 256) {
+    const uint32_t c = counts[u];
+    if (c < (uint32_t)FREQ_BINS) atomicAdd(&sh[c], 1u);
+    else {
+      const uint32_t at = atomicAdd(over_n, 1u);
+      if (at < over_cap) over[at] = c;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < FREQ_BINS; i += 256) if (sh[i]) atomicAdd(&hist[i], (unsigned long long)sh[i]);
+}
+
 // contig_rec[c] = first record with rec_seq >= c
 __global__ void k_contig_ranges(const int32_t *rec_seq, int64_t N, int C, int32_t *contig_rec) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,6 +179,9 @@ __global__ void k_link_duplicates(const uint32_t *sorted_hash, const uint32_t *p
 // The flags are written as whole bytes (FLAG_SAME_STEP or 0): this kernel runs before k_link_duplicates ORs its bits in.
 constexpr uint8_t FLAG_SAME_STEP = 4;
 constexpr int WL_TILE = 4096, WL_THREADS = 512, WL_HALO_MAX = 5120;   // 56 KB of LDS at most
+// (ALL_LDS: the halo covers cmw + 2 records either side, every read of a search is an LDS read -- no range test per step: the
+//  kernel is bound by the vector instructions of its ~36 search steps per record, 15 each with the test and 6 without)
+template <bool ALL_LDS>
 __global__ __launch_bounds__(WL_THREADS) void k_window_links(const int32_t *rec_seq, const int32_t *rec_wpos, const int32_t *contig_rec, int64_t N,
                                                            int cmw, int halo, int32_t *rec_fwd, int32_t *rec_bwd, uint8_t *rec_flags) {
   extern __shared__ int32_t wl_w[];
@@ -170,7 +194,8 @@ __global__ __launch_bounds__(WL_THREADS) void k_window_links(const int32_t *rec_
   }
   __syncthreads();
   const int64_t s_lo = max((int64_t)0, first), s_hi = min(N, first + held);
-  auto at = [&](int r) -> int { return r >= s_lo && r < s_hi ? wl_w[r - first] : rec_wpos[r]; };
+  const int first32 = (int)first;                                       // (ALL_LDS: N < 2^31 and halo < 2^13, no wrap)
+  auto at = [&](int r) -> int { return ALL_LDS ? wl_w[r - first32] : (r >= s_lo && r < s_hi ? wl_w[r - first] : rec_wpos[r]); };
   for (int q = 0; q < WL_TILE / WL_THREADS; q++) {
     const int64_t i = t0 + q * WL_THREADS + threadIdx.x;
     if (i >= N) return;

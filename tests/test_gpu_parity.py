@@ -1595,3 +1595,31 @@ def test_index_links_match_their_definitions(bits, monkeypatch):
     assert _check_links({}, 31) == 2962
     assert _check_links({"fragment_length": 500, "k": 16}, 32) < 500
     assert _check_links({"fragment_length": 7000, "percentage_identity": 60.0, "k": 12}, 33) > 5120
+
+
+@pytest.mark.parametrize("over_cap", [None, "1"])
+def test_frequency_threshold_with_lists_beyond_the_histogram(over_cap, monkeypatch):
+    """computeFreqHist on the device takes the largest list lengths from a histogram of the lengths below 4 096 plus the longer
+    ones verbatim.  With room for no
+    long list (FA_FREQ_OVER_CAP=1) the build sorts all lengths instead: same threshold, same index as the oracle's.
+    (Two 45-mers planted 5 300 and 4 600 times: list lengths 4 569, 4 569, 3 689, ... and 2 lists to ignore -> threshold 4 569.)"""
+    if over_cap:
+        monkeypatch.setenv("FA_FREQ_OVER_CAP", over_cap)
+    g = syn.rng(77)
+    n = 3_200_000
+    m = syn.random_codes(g, n)
+    r1, r2 = syn.random_codes(g, 45), syn.random_codes(g, 45)
+    for p in range(1000, n - 1000, 600):
+        m[p: p + 45] = r1
+    for p in range(1300, n - 1000, 700):
+        m[p: p + 45] = r2
+    refs = [[syn.to_ascii(m)]]
+    sk, osk = pf.Sketch(), OracleSketch()
+    for i, r in enumerate(refs):
+        sk.add_draft(f"r{i}", r)
+        osk.add_draft(f"r{i}", r)
+    mapper = sk.index()
+    osk.index()
+    assert len(mapper.lookup_index) == osk.index_size
+    assert mapper.occurences_threshold == osk.freq_threshold
+    assert osk.freq_threshold > 4096                                # the threshold itself comes from a list beyond the histogram
