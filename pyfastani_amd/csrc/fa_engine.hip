@@ -598,7 +598,8 @@ static void build_index(fa_mapper &m) {
   const int64_t N = m.N;
   // record numbers are 32-bit throughout the mapping kernels (a seed hit IS a record number): 2^31 minimizers, about 5 000
   // genomes of 5 Mb, per index -- beyond that shard the references (sharding.build_ref_sharded_mapper)
-  FA_REQUIRE(N < (1LL << 31) - 1, FA_ERR_UNSUPPORTED, "more than 2^31 minimizers in one index (shard the references)");
+  // (k_window_links adds up to a fragment's windows + 2 to a record number in 32-bit arithmetic: that much headroom below 2^31)
+  FA_REQUIRE(N < (1LL << 31) - 1 - (int64_t)std::max(0, m.P.fragment_length) - 64, FA_ERR_UNSUPPORTED, "more than 2^31 minimizers in one index (shard the references)");
   m.C = m.seqs_by_file.empty() ? 0 : m.seqs_by_file.back();
   m.G = (int32_t)m.seqs_by_file.size();
   // minimizer windows per fragment.  When it is <= 0 no fragment holds a window, query sketches are empty and L2 never
