@@ -76,6 +76,28 @@ struct DevStore {
     v.packed = packed.p; v.bytes = bytes.p; v.exc_pos = exc_pos.p; v.exc_val = exc_val.p; v.n_exc = n_exc;
     return v;
   }
+  // upload in pieces (Sketch flush: the copy of chunk c + 1 runs while chunk c is hashed): `begin` sizes the buffers and sends
+  // the exception lists, `upload_bases` the packed words (or residue bytes) of the store offsets [lo, hi) -- sequences start on
+  // 64-base boundaries, so a range of whole sequences is a range of whole words
+  void begin(const HostStore &h, hipStream_t st) {
+    protein = h.protein;
+    total = h.total;
+    n_exc = (int64_t)h.exc_pos.size();
+    if (protein) bytes.ensure(h.bytes.size() + 64);
+    else {
+      packed.ensure(h.packed.size() + 16);
+      if (n_exc) { exc_pos.upload(h.exc_pos, st); exc_val.upload(h.exc_val, st); }
+    }
+  }
+  void upload_bases(const HostStore &h, int64_t lo, int64_t hi, hipStream_t st) {
+    if (hi <= lo) return;
+    if (protein) {
+      FA_HIP(hipMemcpyAsync(bytes.p + lo, h.bytes.data() + lo, (size_t)(std::min<int64_t>(hi, (int64_t)h.bytes.size()) - lo), hipMemcpyHostToDevice, st));
+    } else {
+      const int64_t w0 = lo / 16, w1 = std::min<int64_t>((hi + 15) / 16, (int64_t)h.packed.size());
+      FA_HIP(hipMemcpyAsync(packed.p + w0, h.packed.data() + w0, (size_t)(w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+  }
   void upload(const HostStore &h, hipStream_t st) {
     protein = h.protein;
     total = h.total;
