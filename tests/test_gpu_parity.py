@@ -1623,3 +1623,39 @@ def test_frequency_threshold_with_lists_beyond_the_histogram(over_cap, monkeypat
     assert len(mapper.lookup_index) == osk.index_size
     assert mapper.occurences_threshold == osk.freq_threshold
     assert osk.freq_threshold > 4096                                # the threshold itself comes from a list beyond the histogram
+
+
+def test_rows_of_a_pass_by_every_road():
+    """The rows of a pass are formed by the last workgroup of k_cgi_rows (below FA_ROWS_EMIT_MAX pairs, default 512) or by
+    kernels of their own, and reach the host written by the publishing workgroup (up to 256 rows) or by one DMA copy: a call of
+    12 queries x 40 references (480 pairs, 360 rows) with both formations, and one query x 40 (30 rows), must give the same rows."""
+    import subprocess
+    import textwrap
+    code = textwrap.dedent("""
+        import sys, os, json, hashlib
+        sys.path.insert(0, %r)
+        import numpy as np
+        import pyfastani_amd as pf
+        from pyfastani_amd import synthetic as syn
+        g = syn.rng(4242)
+        anc = syn.random_codes(g, 150_000)
+        refs = [[syn.to_ascii(syn.mutate_codes(g, anc, 0.01 + 0.004 * i))] for i in range(30)] + [[syn.to_ascii(syn.random_codes(g, 150_000))] for _ in range(10)]
+        sk = pf.Sketch()
+        sk.add_drafts([f"r{i}" for i in range(40)], refs)
+        mapper = sk.index()
+        batch = mapper.upload_genomes([[syn.to_ascii(syn.mutate_codes(g, anc, 0.02))] for _ in range(12)])
+        many = batch.query_rows(0, 12)
+        one = batch.query_rows(3, 1)
+        dig = lambda r: hashlib.sha256(np.ascontiguousarray(r).tobytes()).hexdigest()[:16]
+        print(json.dumps({"many": dig(many), "n_many": int(len(many)), "one": dig(one), "n_one": int(len(one))}))
+    """) % (ROOT,)
+    outs = []
+    for emit in ("16384", "1", None):
+        env = dict(os.environ)
+        if emit:
+            env["FA_ROWS_EMIT_MAX"] = emit
+        res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stdout + res.stderr
+        outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] == outs[2], outs
+    assert outs[0]["n_many"] == 12 * 30 and outs[0]["n_one"] == 30, outs
