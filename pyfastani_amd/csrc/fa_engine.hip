@@ -99,17 +99,21 @@ struct SketchWork {
 
 // FA_TRACE=1: wall-clock of the host-visible stages of sketching and index construction on stderr
 struct StageTrace {
-  bool on;
+  bool on, live = false;
   const char *what;
   std::chrono::steady_clock::time_point t0, t;
   std::vector<std::pair<std::string, double>> acc;
-  explicit StageTrace(const char *w) : on(getenv("FA_TRACE") != nullptr), what(w) { t0 = t = std::chrono::steady_clock::now(); }
+  explicit StageTrace(const char *w) : on(getenv("FA_TRACE") != nullptr), what(w) {
+    live = on && atoi(getenv("FA_TRACE")) >= 2;
+    t0 = t = std::chrono::steady_clock::now();
+  }
   void mark(const char *stage, hipStream_t st) {
     if (!on) return;
     (void)hipStreamSynchronize(st);
     auto now = std::chrono::steady_clock::now();
     double ms = std::chrono::duration<double, std::milli>(now - t).count();
     t = now;
+    if (live) { fprintf(stderr, "[fa trace] %s: %s done after %.1f ms\n", what, stage, ms); fflush(stderr); }   // FA_TRACE=2: as it happens
     for (auto &a : acc) if (a.first == stage) { a.second += ms; return; }
     acc.emplace_back(stage, ms);
   }

@@ -172,6 +172,8 @@ __global__ void k_link_duplicates(const uint32_t *sorted_hash, const uint32_t *p
 // With these, the position of every admit / drop event in the time-ordered event stream of a locus is plain
 // arithmetic (no merge search per query).
 //
+// (Midpoints as x + (y - x) / 2 throughout: record numbers reach 2^31 and x + y does not fit -- an index beyond 2^30 records
+// never came back from this kernel, nor from the prologue of k_l2_events, before round 5 tried one.)
 // Three binary searches per record over the window positions of at most cmw records either side (wpos is strictly increasing
 // inside a contig).  A workgroup takes WL_TILE consecutive records and holds their window positions plus `halo` records either
 // side in LDS, so the ~36 dependent reads of a record are LDS reads; whatever a search needs outside (cmw > WL_HALO_MAX: the
@@ -204,19 +206,19 @@ __global__ __launch_bounds__(WL_THREADS) void k_window_links(const int32_t *rec_
     const int w = wl_w[i - first];
     {
       int x = (int)i + 1, y = min(hi, (int)i + 1 + cmw), key = w + cmw;   // wpos is strictly increasing: at most cmw records ahead
-      while (x < y) { int mid = (x + y) >> 1; if (at(mid) < key) x = mid + 1; else y = mid; }
+      while (x < y) { int mid = x + ((y - x) >> 1); if (at(mid) < key) x = mid + 1; else y = mid; }
       rec_fwd[i] = x;
     }
     {
       int x = max(lo, (int)i - cmw), y = (int)i + 1, key = w - cmw + 1;    // first index with wpos > key, minus one
-      while (x < y) { int mid = (x + y) >> 1; if (at(mid) <= key) x = mid + 1; else y = mid; }
+      while (x < y) { int mid = x + ((y - x) >> 1); if (at(mid) <= key) x = mid + 1; else y = mid; }
       rec_bwd[i] = x - 1;
     }
     uint8_t flag = 0;
     if (i + 1 < hi) {
       const int key = at((int)i + 1) + cmw - 1;
       int x = (int)i + 1, y = min(hi, (int)i + 2 + cmw);                   // wpos[i + 1 + cmw] >= wpos[i + 1] + cmw > key
-      while (x < y) { int mid = (x + y) >> 1; if (at(mid) < key) x = mid + 1; else y = mid; }
+      while (x < y) { int mid = x + ((y - x) >> 1); if (at(mid) < key) x = mid + 1; else y = mid; }
       if (x < hi && at(x) == key) flag = FLAG_SAME_STEP;
     }
     rec_flags[i] = flag;
@@ -1969,7 +1971,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
         y = min(rfirst, a.ix.rec_bwd[rpart] + 1);
         x = max(x, y - (a.frag_len - a.cmw + 1));
       }
-      while (x < y) { int mid = (x + y) >> 1; if (wpos[mid] < target) x = mid + 1; else y = mid; }
+      while (x < y) { int mid = x + ((y - x) >> 1); if (wpos[mid] < target) x = mid + 1; else y = mid; }
       const int beg = x;
       const int end0 = a.ix.rec_fwd[beg];                  // searchIndex(seqId, first wpos + countMinimizerWindows)
       // the slide stops at the window position where the last record is admitted; the records dropped by then are
