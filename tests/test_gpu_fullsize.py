@@ -186,3 +186,30 @@ def test_config5_fullsize(config5_genomes, k, frag):
     if frag >= 3000 and k <= 16:
         assert r["hits_within_family"]
         assert r["asymmetric_pairs"] <= 4                               # d = 0.20 pairs straddle the minimum-fraction edge
+
+
+def test_index_beyond_two_to_the_thirty_records():
+    """An index holds up to 2^31 records; beyond 2^30 the sum of two record numbers no longer fits 32 bits, and until round 5 the
+    midpoints of the binary searches in k_window_links and in the prologue of k_l2_events were exactly that sum -- the build of
+    such an index never came back (profiles/r05_scale_probe_1600M_records.txt).  Three hundred generated genomes of 5 Mb added
+    twelve times each are 1.44 x 10^9 records (two minutes of generation saved; ~95 GB of HBM -- skipped on a device with less);
+    every query must find each of the twelve copies of itself at exactly 100.0, the copies in the upper half of the records included."""
+    import torch
+    free_b, _ = torch.cuda.mem_get_info()
+    if free_b < 150 * 2**30:
+        pytest.skip("needs ~95 GB of free HBM")
+    genomes, _ = workloads.families(2000, 6, 50, 5_000_000)
+    copies = 12
+    sk = pf.Sketch()
+    for c in range(copies):
+        sk.add_drafts([f"c{c}_{i}" for i in range(len(genomes))], genomes)
+    mapper = sk.index()
+    n = len(mapper.minimizers)
+    assert n > 2**30 + 2**28 and n < 2**31
+    batch = mapper.upload_genomes(genomes[:20])
+    rows = batch.query_rows(0, 20)
+    own = rows[rows["ref_genome_id"] % len(genomes) == rows["query_id"]]
+    assert len(own) == 20 * copies and np.all(own["identity"] == 100.0)
+    assert set(own["ref_genome_id"] // len(genomes)) == set(range(copies))
+    del batch, mapper, sk
+    pf.device_trim()
