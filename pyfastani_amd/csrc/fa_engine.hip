@@ -1328,7 +1328,8 @@ struct QueryPass {
       // FA_L1_NEAR = 0 / 1: never / always (the A/B of the HBM fetch: profiles/r05_l1_near_fetch.txt).
       static const int l1_near_env = getenv("FA_L1_NEAR") ? atoi(getenv("FA_L1_NEAR")) : -1;
       const bool l1_near_on = l1_near_env < 0 ? m.N >= 300000000LL : l1_near_env != 0;
-      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0);
+      // (bit 3, -DFA_EXPERIMENTS builds only: FA_L1_PREFILTER=1, dead hits dropped before the block sort -- not yet run on a GPU)
+      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0) | (exp_u64("FA_L1_PREFILTER", 0) ? 8 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut

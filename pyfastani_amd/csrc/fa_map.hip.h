@@ -825,9 +825,18 @@ __device__ __forceinline__ void bs_sizes(uint32_t (&k)[KPL], uint32_t pos0, bool
 }
 
 constexpr uint32_t BS_MAX_PROBES = 48;
+// (FA_EXPERIMENTS builds, FA_L1_PREFILTER=1 -- written at the end of round 5 and NOT yet run on a GPU: the pre-filter of
+//  profiles/EXPERIMENTS.md, "Design note for the block pre-filter", form (b).  A first sweep over the hits marks, per hit and for two
+//  staggered grids of cells twice a fragment length of records wide, "seen once" / "seen twice" bits over a hash of the cell number;
+//  the second sweep inserts only hits with a "seen twice" cell and counts them: `n_live` replaces n for everything behind the sort.
+//  tests/test_l1_prefilter_model.py holds the argument that this changes no candidate region.)
 template <int NT, int SPT, int KPL>
 __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n, uint32_t cap, uint32_t *A, const uint32_t *off, const uint32_t *qo,
-                                              uint32_t *Kk, uint32_t kl) {
+                                              uint32_t *Kk, uint32_t kl
+#ifdef FA_EXPERIMENTS
+                                              , uint32_t &n_live, int frag_len
+#endif
+                                              ) {
   __shared__ uint32_t bs_fail;
   __shared__ uint32_t bs_wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -843,7 +852,88 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   };
   for (uint32_t i = tid; i < capT; i += NT) { Tb[i] = 0ULL; Tk[i] = 0u; }
   if (tid == 0) bs_fail = 0;
+#ifdef FA_EXPERIMENTS
+  __shared__ uint32_t bs_live;
+  constexpr uint32_t PF_WORDS = 768, PF_BITS = PF_WORDS * 32;           // two arrays: 6 144 bytes, the locus-stage part of the region behind the table
+  const bool prefilter = (a.block_sort & 8) && kl >= 2u * PF_WORDS + 2u * (uint32_t)(a.lut_smax + 2) && frag_len > 0;
+  uint32_t *B1 = Kk + (kl - 2u * PF_WORDS), *B2 = B1 + PF_WORDS;
+  int cell_shift = 1;                                                    // cells of 2^cell_shift records, 2^(cell_shift - 1) >= frag_len
+  while ((1 << (cell_shift - 1)) < frag_len && cell_shift < 30) cell_shift++;
+  auto cell_bit = [&](uint32_t r, uint32_t g) __attribute__((always_inline)) {
+    const uint32_t c = (((r + (g << (cell_shift - 1))) >> cell_shift) << 1) | g;
+    return __umulhi(c * 0x9E3779B1u, PF_BITS);
+  };
+  n_live = n;
+  if (prefilter) {
+    for (uint32_t i = tid; i < 2u * PF_WORDS; i += NT) B1[i] = 0u;
+    if (tid == 0) bs_live = 0;
+  }
+#endif
   __syncthreads();
+#ifdef FA_EXPERIMENTS
+  if (prefilter) {
+    // the loop of step 1 below, twice: marks, then insertions of the live hits
+    constexpr int IB = 8;
+    uint32_t top = 1;
+    while (top * 2u < (uint32_t)s) top <<= 1;
+    if (s < 2) top = 0;
+    auto place = [&](uint32_t r) __attribute__((always_inline)) {
+      const uint32_t key1 = (r >> 6) + 1u;
+      const unsigned long long bit = 1ULL << (r & 63u);
+      uint32_t h = slot_of(r >> 6);
+      for (uint32_t probes = 0;; probes++) {
+        const uint32_t old = atomicCAS(&Tk[h], 0u, key1);
+        if (old == 0u || old == key1) { atomicOr(&Tb[h], bit); break; }
+        if (probes >= BS_MAX_PROBES) { bs_fail = 1; break; }
+        h = next_slot(h);
+      }
+    };
+    uint32_t mine_live = 0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 2; sweep++) {
+      for (uint32_t i0 = tid; i0 < n; i0 += IB * NT) {
+        uint32_t jj[IB], r[IB];
+#pragma unroll
+        for (int u = 0; u < IB; u++) jj[u] = 0;
+        for (uint32_t step = top; step; step >>= 1) {
+          uint32_t v[IB];
+#pragma unroll
+          for (int u = 0; u < IB; u++) v[u] = off[min(jj[u] + step, (uint32_t)s)];
+#pragma unroll
+          for (int u = 0; u < IB; u++) jj[u] += v[u] <= i0 + (uint32_t)u * NT ? step : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < IB; u++) {
+          const uint32_t i = i0 + (uint32_t)u * NT;
+          r[u] = i < n ? a.ix.pos_ridx[qo[jj[u]] + (i - off[jj[u]])] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < IB; u++) {
+          if (i0 + (uint32_t)u * NT >= n) continue;
+          const uint32_t b0 = cell_bit(r[u], 0u), b1 = cell_bit(r[u], 1u);
+          if (sweep == 0) {
+            const uint32_t o0 = atomicOr(&B1[b0 >> 5], 1u << (b0 & 31u));
+            if (o0 & (1u << (b0 & 31u))) atomicOr(&B2[b0 >> 5], 1u << (b0 & 31u));
+            const uint32_t o1 = atomicOr(&B1[b1 >> 5], 1u << (b1 & 31u));
+            if (o1 & (1u << (b1 & 31u))) atomicOr(&B2[b1 >> 5], 1u << (b1 & 31u));
+          } else if (((B2[b0 >> 5] >> (b0 & 31u)) | (B2[b1 >> 5] >> (b1 & 31u))) & 1u) {
+            place(r[u]);
+            mine_live++;
+          }
+        }
+        if (sweep == 1 && *(volatile uint32_t *)&bs_fail) break;
+      }
+      __syncthreads();
+    }
+    {
+      const uint32_t incl = wave_incl_scan(mine_live);
+      if (lane == 63 && incl) atomicAdd(&bs_live, incl);
+    }
+    __syncthreads();
+    n_live = bs_live;
+    n = n_live;                                                          // (everything below counts the live hits)
+  } else
+#endif
   // ---- 1. the hits, flat: hit i of the fragment is entry i - off[j] of list j (off = prefix sums of the list lengths, qo = where
   //      every list starts in the index; the caller left both in LDS).  Eight hits per thread and trip, so that eight index
   //      reads are in flight: the workgroup's time is a chain of memory round trips, not instructions ----
@@ -1025,7 +1115,11 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   __shared__ uint32_t sh_base, sh_gbase;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
+#ifdef FA_EXPERIMENTS
+  uint32_t n = a.n_seeds[f];                     // (FA_L1_PREFILTER: the live hits once the block sort has dropped the dead ones)
+#else
   const uint32_t n = a.n_seeds[f];
+#endif
   if (a.big_enabled && a.big_state[f]) return;   // more hits than LDS holds: cut into chunks by k_l1_big, which ran before
   if (tid == 0) { a.f_loci_lo[f] = 0; a.f_loci_n[f] = 0; }
   if (s == 0 || n == 0) return;
@@ -1075,7 +1169,13 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     bool block_sorted = false;
     if ((a.block_sort & 1) && cap >= 1024u) {
       const uint32_t kl = (uint32_t)((l1_lds_bytes(cap, a.lut_smax, NT) - l1_off_offset(cap)) / 4);
+#ifdef FA_EXPERIMENTS
+      uint32_t n_live = n;
+      block_sorted = l1_block_sort<NT, E / 2, 4>(a, s, n, cap, A, off, qo, off, kl, n_live, a.frag_len);
+      if (block_sorted) n = n_live;
+#else
       block_sorted = l1_block_sort<NT, E / 2, 4>(a, s, n, cap, A, off, qo, off, kl);
+#endif
       if (!block_sorted) list_offsets();                                // (the key buffer may have overwritten them)
     }
     if (l1_dbg) atomicAdd(&a.counters[block_sorted ? 5 : 6], 1u);   // FA_L1_STATS=1: which road the fragments took
