@@ -194,7 +194,9 @@ def test_index_beyond_two_to_the_thirty_records():
     such an index never came back (profiles/r05_scale_probe_1600M_records.txt).  Three hundred generated genomes of 5 Mb added
     twelve times each are 1.44 x 10^9 records (two minutes of generation saved; ~95 GB of HBM -- skipped on a device with less);
     every query must find each of the twelve copies of itself at exactly 100.0, the copies in the upper half of the records included."""
+    import gc
     import torch
+    gc.collect()                         # (mappers of earlier tests that only a reference cycle keeps alive)
     pf.device_trim()                     # (what the tests before this one left in the library's pool counts as used memory)
     free_b, _ = torch.cuda.mem_get_info()
     if free_b < 110 * 2**30:
