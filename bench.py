@@ -41,7 +41,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # committed rocprofv3 summaries (scripts/collect_profiles.sh): the newest round that holds a file wins
-PROFILE_TAGS = ("r05", "r04")
+PROFILE_TAGS = ("r06", "r05", "r04")
 TRAFFIC_PROFILE = "traffic.json"                         # the timed step (1 query per launch)
 TRAFFIC_PROFILE_BATCH16 = "batch16_traffic.json"         # `saturated.batch16`: 16 queries per launch
 TRAFFIC_PROFILE_CONFIG3 = "config3_traffic.json"         # `saturated.config3`: 1000 x 1000, two steps profiled
@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--no-fasta-leg", action="store_true", help="N=1: skip the files-to-table leg of config 3 (`saturated.config3.fasta_to_table`)")
     ap.add_argument("--config4", type=str, default="10x50", help="families x members of the config-4 leg (tests shrink it)")
     ap.add_argument("--config5", type=str, default="10x20", help="families x members of the config-5 leg (tests shrink it)")
+    ap.add_argument("--detail", type=str, default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file that receives the FULL result (every leg, every stage); stdout carries the contract line only")
     return ap.parse_args()
 
 
@@ -157,7 +159,124 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        emit(result, args.detail)
+
+
+LINE_LIMIT = 4096              # bytes of the contract line (the driver keeps an 8 KB tail of stdout and parses its last line)
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant figures, recursively (the line is read by people and by a size-bounded parser)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    if hasattr(x, "item"):
+        return _sig(x.item(), digits)
+    return x
+
+
+def _clip(x, width=200):
+    """Strings of the line cut to `width` characters (a workload description, not a document)."""
+    if isinstance(x, str):
+        return x if len(x) <= width else x[: width - 3] + "..."
+    if isinstance(x, dict):
+        return {k: _clip(v, width) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_clip(v, width) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _leg(d):
+    """One saturated leg as {pairs_per_s, ms_per_step, frac, traffic_over_algorithmic}."""
+    if not isinstance(d, dict):
+        return None
+    roof = d.get("roofline") or {}
+    t = roof.get("traffic_over_algorithmic")
+    if t is None and roof.get("traffic") and roof.get("algorithmic_bytes"):
+        t = roof["traffic"] / roof["algorithmic_bytes"]
+    return {"pairs_per_s": d.get("value"), "ms_per_step": d.get("ms_per_step"), "frac": roof.get("frac"), "traffic_over_algorithmic": t}
+
+
+def contract_line(detail, detail_path=None):
+    """The ONE stdout line of the bench contract, cut from the full result: metric/value/timing, the workload, the roofline of the
+    dominant kernel, the CPU baseline, the parity counts, and one number + roofline fraction per saturated leg.  Everything
+    else (per-stage tables of every leg, sources, notes) stays in the detail file.  Pure dict work: tests/test_bench_launch.py
+    bounds its size (LINE_LIMIT) and checks the keys without a GPU."""
+    d = detail
+    line = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_p50", "ms_per_step_p95",
+                     "ms_per_step_max", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    cfg = d.get("config", {})
+    line["config"] = _pick(cfg, ("workload", "timed_region", "pairs_per_step_per_gpu", "pairs_per_step", "rows_per_step", "hits_per_step",
+                                 "l2_loci", "l2_records", "index_minimizers", "parallelism", "fragments_per_rank", "self_rows_ok",
+                                 "table_sha256", "digest_matches_n1", "exchange_ms", "head"))
+    if "roofline" in d:
+        line["roofline"] = _pick(d["roofline"], ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms",
+                                                 "kernel_ms_hip_events", "algorithmic_bytes", "valu_frac"))
+    if "roofline_sketch" in d:
+        line["roofline_sketch"] = _pick(d["roofline_sketch"], ("kernel", "achieved", "unit", "frac", "kernel_ms", "gbases_per_s", "valu_frac"))
+    if "phases_ms" in d:
+        line["phases_ms"] = d["phases_ms"]
+    if "cpu_baseline" in d:
+        line["cpu_baseline"] = _pick(d["cpu_baseline"], ("value", "unit", "cores", "kind", "sample", "single_thread_value", "cpu_model"))
+    line.update(_pick(d, ("parity_checked", "rows_compared", "mappings_compared")))
+    if "boundary_call" in d:
+        line["boundary_call"] = _pick(d["boundary_call"], ("ms_per_call", "value", "hits_match_timed_rows"))
+    sat = d.get("saturated") or {}
+    legs = {k: _leg(v) for k, v in sat.items() if isinstance(v, dict)}
+    f2t = (sat.get("config3") or {}).get("fasta_to_table") or d.get("fasta_to_table")
+    if f2t:
+        legs["config3_from_fasta"] = {"pairs_per_s": f2t.get("pairs_per_s"), "wall_s": f2t.get("wall_s"), "overlap": f2t.get("overlap")}
+    if legs:
+        line["saturated"] = legs
+    cells = (d.get("config5_cells") or {}).get("cells")
+    if cells:
+        line["config5_cells"] = {"columns": ["k", "fragment_length", "pairs_per_s", "frac", "traffic_over_algorithmic"],
+                                 "cells": [[c.get("k"), c.get("fragment_length"), c.get("value"), (c.get("roofline") or {}).get("frac"),
+                                            (c.get("roofline") or {}).get("traffic_over_algorithmic")] for c in cells]}
+    if isinstance(d.get("genome_like"), dict):
+        line["genome_like"] = _pick(d["genome_like"], ("pairs_per_s", "ms_per_step", "off_fast_path_share", "vs_config5_k16_f3000", "frac"))
+    if isinstance(d.get("strong"), dict):
+        line["strong"] = _pick(d["strong"], ("value", "ms_per_step", "pairs_per_step", "digest_matches_n1", "exchange_ms", "fragments_per_rank"))
+    line.update(_pick(d, ("rccl_ranks", "backend")))
+    if detail_path:
+        line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path.startswith(ROOT + os.sep) else detail_path
+    line = _clip(_sig(line))
+    text = json.dumps(line, allow_nan=False)
+    if len(text) > LINE_LIMIT:                     # never lose the headline to a long string: drop the optional parts, widest first
+        for key in ("config5_cells", "saturated", "roofline_sketch", "boundary_call", "strong", "phases_ms"):
+            line.pop(key, None)
+            text = json.dumps(line, allow_nan=False)
+            if len(text) <= LINE_LIMIT:
+                break
+    return line
+
+
+def emit(result, detail_path):
+    """Full result -> the detail file (and stderr, for a log that keeps it); contract line -> the LAST line of stdout."""
+    full = json.dumps(_sig(result, 9), allow_nan=False)
+    written = None
+    try:
+        with open(detail_path, "w") as f:
+            f.write(full + "\n")
+        written = detail_path
+    except OSError as e:
+        print(f"[bench] could not write {detail_path}: {e}", file=sys.stderr)
+    if os.environ.get("FA_BENCH_DETAIL_STDERR", "1") == "1":
+        print("[bench detail] " + full, file=sys.stderr)
+    sys.stderr.flush()
+    print(json.dumps(contract_line(result, written), allow_nan=False))
+    sys.stdout.flush()
 
 
 def fence(ctx):
@@ -306,14 +425,18 @@ def weak_scaling(ctx):
     stage_ptr = [C.cast(stage_log[i].ctypes.data, C.POINTER(C.c_float)) for i in range(stage_log.shape[0])]
     handle = mapper._h
     n_last = 0
+    step_end = np.zeros(max(args.steps, 1))            # (a step's rows are complete when its call returns: one stamp per step)
+    clock = time.perf_counter
     fence(ctx)
-    t0 = time.perf_counter()
+    t0 = clock()
     for i in range(args.steps):
         n_last = step(i)
         lib.fa_mapper_last_timings(handle, stage_ptr[i], 8)
+        step_end[i] = clock()
     gathered = exchange(args.steps)
     fence(ctx)
-    elapsed = max_over_ranks(ctx, time.perf_counter() - t0)
+    elapsed = max_over_ranks(ctx, clock() - t0)
+    per_step_ms = np.diff(np.concatenate([[t0], step_end[: args.steps]])) * 1e3 if args.steps > 0 else np.zeros(1)
     # hits of one step over all ranks (every rank holds the whole table now)
     n_hits = int(gathered.reshape(-1, cap_rows + 1, 5)[:, 0, 0].sum().item()) // max(args.steps, 1) if ctx["dist_on"] else int(n_last)
     phase_ms = stage_log[: args.steps, :5].astype(np.float64).sum(axis=0) / max(args.steps, 1)
@@ -372,6 +495,9 @@ def weak_scaling(ctx):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
+        # the spread over the timed steps of rank 0 (the mean above is the contract's number: K steps / the whole bracket)
+        "ms_per_step_p50": float(np.percentile(per_step_ms, 50)), "ms_per_step_p95": float(np.percentile(per_step_ms, 95)),
+        "ms_per_step_max": float(per_step_ms.max()),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -27,12 +27,12 @@ esac
 OUT=gpurun_out/${NAME}_prof
 mkdir -p "$OUT"
 export FA_PROFILE_COMMAND="python3 bench.py $ARGS"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS $STATS > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $ARGS $PMC > /dev/null 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py $ARGS $PMC > /dev/null 2> "$OUT/write.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 bench.py $ARGS $STATS --detail "$OUT/bench_detail.json" > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py $ARGS $PMC --detail /dev/null > /dev/null 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py $ARGS $PMC --detail /dev/null > /dev/null 2> "$OUT/write.err"
 if [ "$MODE" = "default" ] || [ "$MODE" = "batch16" ]; then
-  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/sq_a" -- python3 bench.py $ARGS $PMC > /dev/null 2> "$OUT/sq_a.err"
-  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq_b" -- python3 bench.py $ARGS $PMC > /dev/null 2> "$OUT/sq_b.err"
+  rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/sq_a" -- python3 bench.py $ARGS $PMC --detail /dev/null > /dev/null 2> "$OUT/sq_a.err"
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d "$OUT/sq_b" -- python3 bench.py $ARGS $PMC --detail /dev/null > /dev/null 2> "$OUT/sq_b.err"
 fi
 cp "$OUT/bench_under_rocprof.json" "gpurun_out/${NAME}_bench_under_rocprof.json"
 python3 scripts/summarize_profiles.py "$OUT" "gpurun_out/${NAME}"

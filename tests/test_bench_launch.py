@@ -90,3 +90,78 @@ def test_the_strong_workload_is_generated_once_and_mapped_by_the_other_ranks(mon
     # one rank: nothing is written
     alone = bench.shared_workload({"rank": 0, "world": 1, "dist_on": False}, "unit", make)
     assert [[bytes(c) for c in contigs] for contigs in alone[0]] == want
+
+
+# ---- the contract line (the ONE stdout line the driver parses) ----
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _full_result_of_round_5():
+    """The 24 KB line round 5 printed (profiles/r05_bench_default.json): the largest result this bench has produced, the one the
+    driver could not parse."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r05_bench_default.json")) as f:
+        return json.load(f)
+
+
+def test_contract_line_is_small_strict_json_with_the_required_keys():
+    import json
+    bench = _load_bench()
+    full = _full_result_of_round_5()
+    assert len(json.dumps(full)) > 20000                      # (the input is the oversized one)
+    full.update(ms_per_step_p50=0.49, ms_per_step_p95=0.51, ms_per_step_max=0.6,
+                genome_like={"pairs_per_s": 1.0e6, "ms_per_step": 40.0, "off_fast_path_share": 0.01, "vs_config5_k16_f3000": 0.8, "frac": 0.3,
+                             "stages": {"x": list(range(1000))}})
+    line = bench.contract_line(full, os.path.join(ROOT, "bench_detail.json"))
+    text = json.dumps(line, allow_nan=False)
+    assert len(text) < bench.LINE_LIMIT <= 4096, len(text)
+    back = json.loads(text)
+    assert back == line
+    for k in REQUIRED:
+        assert k in back, k
+    assert back["value"] == float(f"{full['value']:.6g}") and back["ms_per_step"] > 0 and back["n_gpus"] == 1
+    assert back["config"]["workload"].startswith("1 query x 100") and back["config"]["l2_records"] > 0
+    r = back["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms", "algorithmic_bytes", "valu_frac")) <= set(r)
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5
+    c = back["cpu_baseline"]
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] == "port"
+    assert back["parity_checked"] is True and back["rows_compared"] > 0
+    assert back["boundary_call"]["ms_per_call"] > 0
+    assert set(back["saturated"]) >= {"batch16", "config3", "config4"} and back["saturated"]["config3"]["frac"] > 0
+    cells = back["config5_cells"]["cells"]
+    assert len(cells) == 9 and all(len(c) == 5 for c in cells)
+    assert back["genome_like"]["pairs_per_s"] == 1.0e6 and "stages" not in back["genome_like"]
+    assert back["detail"] == "bench_detail.json"
+
+
+def test_contract_line_survives_missing_legs_nan_and_an_overlong_string():
+    import json
+    bench = _load_bench()
+    minimal = {"metric": "m", "value": float("nan"), "unit": "pairs/s", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+               "config": {"workload": "w"}}
+    line = bench.contract_line(minimal)
+    assert json.loads(json.dumps(line, allow_nan=False))["value"] is None        # NaN never reaches the line
+    full = _full_result_of_round_5()
+    full["cpu_baseline"]["sample"] = "x" * 3000
+    line = bench.contract_line(full)
+    assert len(json.dumps(line, allow_nan=False)) <= bench.LINE_LIMIT and "roofline" in line and "cpu_baseline" in line
+
+
+def test_emit_prints_the_contract_line_last_and_writes_the_detail(tmp_path, capsys):
+    import json
+    bench = _load_bench()
+    full = _full_result_of_round_5()
+    path = str(tmp_path / "detail.json")
+    bench.emit(full, path)
+    out, err = capsys.readouterr()
+    last = out.strip().splitlines()[-1]
+    assert len(out.strip().splitlines()) == 1 and len(last) < bench.LINE_LIMIT
+    assert json.loads(last)["detail"] == path
+    with open(path) as f:
+        detail = json.load(f)
+    assert detail["saturated"]["config3"]["fasta_to_table"]["rows"] > 0 and len(detail["config5_cells"]["cells"]) == 9
+    assert "[bench detail]" in err

@@ -30,8 +30,25 @@ def _run_ranks(script_or_args, n, env=None, timeout=1200):
 STRONG_SMALL = ["--strong", "--families", "2", "--members", "5", "--length", "300000", "--steps", "2", "--warmup", "1"]
 
 
+def _line_and_detail(out):
+    """The contract line (LAST stdout line, bounded) and the full result it names (`detail`: a file next to bench.py or --detail)."""
+    text = out.strip().splitlines()[-1]
+    assert len(text) < 4096, len(text)
+    line = json.loads(text)
+    path = line["detail"] if os.path.isabs(line["detail"]) else os.path.join(ROOT, line["detail"])
+    with open(path) as f:
+        detail = json.load(f)
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype"):
+        assert line[k] == detail[k], k
+    for k in ("value", "ms_per_step"):
+        assert line[k] == pytest.approx(detail[k], rel=1e-5), k
+    assert line["config"]["workload"] == detail["config"]["workload"][:200]
+    return line, detail
+
+
 def _check_strong_line(out, n_gpus):
-    line = json.loads(out.strip().splitlines()[-1])
+    short, line = _line_and_detail(out)
+    assert short["scaling"] == "strong" and short["n_gpus"] == n_gpus and short["config"]["pairs_per_step"] == 100
     assert line["scaling"] == "strong" and line["n_gpus"] == n_gpus and line["unit"] == "pairs/s"
     assert line["config"]["pairs_per_step"] == 100 and line["config"]["self_rows_ok"] is True
     assert len(line["config"]["fragments_per_rank"]) == n_gpus and sum(line["config"]["fragments_per_rank"]) == 10 * 100
@@ -78,7 +95,8 @@ def test_bench_weak_two_ranks_sharing_one_gpu():
     args = ["--gpus", "2", "--refs", "6", "--length", "400000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-saturated"]
     res = _run_ranks([os.path.join(ROOT, "bench.py")] + args, 2, env={"FA_BENCH_SHARE_GPU": "1"})
     assert res.returncode == 0, res.stdout + res.stderr
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    short, line = _line_and_detail(res.stdout)
+    assert short["scaling"] == "weak" and short["n_gpus"] == 2 and short["value"] > 0 and short["ms_per_step_p50"] > 0
     assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["steps"] == 3 and line["value"] > 0
     assert line["config"]["pairs_per_step_per_gpu"] == 6 and "sharded sketching x2" in line["config"]["index_build"]
     assert line["config"]["hits_per_step"] >= 4 and "saturated" not in line and line["phases_ms"]["l2_ms"] > 0
@@ -97,7 +115,8 @@ def test_bench_launches_its_own_ranks_and_carries_the_strong_leg():
         env.pop(k, None)
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert res.returncode == 0, res.stdout + res.stderr
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    short, line = _line_and_detail(res.stdout)
+    assert short["strong"]["digest_matches_n1"] is True and short["strong"]["value"] > 0
     assert line["scaling"] == "weak" and line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["backend"].startswith("gloo")
     assert line["config"]["queries_rotated"] == 4 and line["value"] > 0
     s = line["strong"]
@@ -107,13 +126,16 @@ def test_bench_launches_its_own_ranks_and_carries_the_strong_leg():
 
 
 def test_bench_line_carries_configs_4_and_5():
-    """The N = 1 line at reduced size: `saturated.config4` (draft assemblies all-vs-all) and `config5_cells` (the nine
-    (k, fragment_length) cells) ride in it with pairs/s, per-stage ms, the sketch-stage form and the oracle-free properties."""
+    """The N = 1 run at reduced size: the contract line holds one number + roofline fraction per saturated leg and per config-5
+    cell; the detail file holds `saturated.config4` (draft assemblies all-vs-all) and `config5_cells` (the nine (k,
+    fragment_length) cells) with pairs/s, per-stage ms, the sketch-stage form and the oracle-free properties."""
     args = ["--refs", "6", "--length", "1500000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--clients", "0", "--no-boundary",
             "--families", "2", "--members", "4", "--saturated-steps", "1", "--config4", "2x4", "--config5", "2x3"]
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    short, line = _line_and_detail(res.stdout)
+    assert set(short["saturated"]) >= {"batch16", "config3", "config4"} and short["saturated"]["config4"]["pairs_per_s"] > 0
+    assert len(short["config5_cells"]["cells"]) == 9 and short["roofline"]["frac"] > 0
     c4 = line["saturated"]["config4"]
     assert c4["pairs"] == 64 and c4["value"] > 0 and c4["self_hits_exact"] and c4["contigs"] == 8 * 50 and c4["phases_ms"]["l2_ms"] > 0
     cells = line["config5_cells"]["cells"]
@@ -185,7 +207,7 @@ def test_bench_exchanges_through_rccl_at_world_size_one():
             "--clients", "0", "--families", "2", "--members", "5", "--saturated-steps", "2"]
     res = _run_ranks([os.path.join(ROOT, "bench.py")] + args, 1, env={"FA_BENCH_FORCE_DIST": "1"})
     assert res.returncode == 0, res.stdout + res.stderr
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    short, line = _line_and_detail(res.stdout)
     assert line["n_gpus"] == 1 and line["rccl_ranks"] == 1 and line["backend"].startswith("nccl")
     assert "sharded sketching x1" in line["config"]["index_build"] and line["value"] > 0
     s = line["strong"]
@@ -205,7 +227,7 @@ def test_bench_self_launch_rccl_two_gpus():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "FA_BENCH_SHARE_GPU")}
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
     assert res.returncode == 0, res.stdout + res.stderr
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    short, line = _line_and_detail(res.stdout)
     assert line["n_gpus"] == 2 and line["backend"].startswith("nccl") and line["strong"]["digest_matches_n1"] is True
 
 
