@@ -44,6 +44,40 @@
 #include <utility>
 #include <vector>
 
+// ---------------------------------------------------------------------------
+// OPEN RULES.  Every reading of the absent upstream C++ that no in-tree golden
+// with inputs present can tell from its alternatives sits behind a named
+// compile-time switch; value 0 is the reading SURVEY.md 8a wrote and the HIP
+// path follows.  scripts/oracle_sensitivity.py builds each alternative
+// (-DFO_...=1), checks it against the three in-tree pins (protein golden,
+// window_size == 24, self-query == exactly 100.0) and sizes what it moves on
+// BASELINE config 2: profiles/r06_open_rule_sensitivity.json, DESIGN.md 2.
+// ---------------------------------------------------------------------------
+#ifndef FO_L2_CI          // confidence interval at the L2 site (S8, md_lower_bound in doL2Mapping): 0.9f | 0.75f.
+#define FO_L2_CI 0.9f     // (the S6b site is pinned at 0.9 by window_size == 24 and stays there)
+#endif
+#ifndef FO_SLIDE_END      // where the slide ends: 0 = searchIndex(seqId, rangeEndPos + cmw)   
+#define FO_SLIDE_END 0    //                       1 = searchIndex(seqId, rangeEndPos + Q.len) (MashMap-style; (w-1)+(k-1) more positions)
+#endif
+#ifndef FO_SLIDE_ADVANCE  // 0 = active-minimizer super-window, one window position per step
+#define FO_SLIDE_ADVANCE 0 // 1 = records with wpos in [front.wpos, front.wpos + cmw), one RECORD per step (SURVEY 8a OPEN ii "naive")
+#endif
+#ifndef FO_SLIDE_EVAL     // a step that drops and admits: 0 = the counter is read once, after both
+#define FO_SLIDE_EVAL 0   //                               1 = read after the drop AND after the admit (SURVEY 8a OPEN ii residual doubt)
+#endif
+#ifndef FO_BEST_INIT      // the optimum: 0 = the first placement always sets it
+#define FO_BEST_INIT 0    //              1 = sharedSketchSize starts at 0 and only `>` resets it (identical by construction: see compute_l2)
+#endif
+#ifndef FO_CGI_BIN        // reference bin of computeCGI: 0 = refStartPos / (fragLen - 20) | 1 = refStartPos / fragLen
+#define FO_CGI_BIN 0
+#endif
+#ifndef FO_MD2J_EXP       // md2j: 0 = exp in float (expf, the pyfastani translation unit) | 1 = exp in double
+#define FO_MD2J_EXP 0
+#endif
+#ifndef FO_CGI_TIES       // equal-identity ties in computeCGI: 0 = smallest (refSeqId, refStartPos) / querySeqId | 1 = largest
+#define FO_CGI_TIES 0
+#endif
+
 namespace fo {
 
 typedef uint32_t hash_t;    // include/fastani/map/base_types.pxd:10
@@ -209,8 +243,12 @@ static inline float j2md(float j, int k) {
 
 static inline float md2j(float d, int k) {
   float kd = (float)k * d;
+#if FO_MD2J_EXP == 0
   float e = std::exp(kd);  // float overload
   double v = 1.0 / (2.0 * (double)e - 1.0);
+#else
+  double v = 1.0 / (2.0 * std::exp((double)kd) - 1.0);
+#endif
   return (float)v;
 }
 
@@ -243,6 +281,7 @@ static inline float md_lower_bound(float d, int s, int k, float ci) {
 }
 
 static const float CONFIDENCE_INTERVAL = 0.9f;  // [UPSTREAM]; 0.75 would give window 30, not the asserted 24
+static const float L2_CONFIDENCE_INTERVAL = FO_L2_CI;  // the doL2Mapping site: OPEN (i), unpinned
 
 // S6b  [UPSTREAM] Stat::estimateMinimumHits / estimateMinimumHitsRelaxed (map_stats.pxd:10-11)
 static inline int estimate_minimum_hits(int s, int k, float perc_identity) {
@@ -548,22 +587,45 @@ struct Mapper {
     size_t beg = ref.search_index(c.seqId, c.rangeStartPos);
     offset_t p = mi[beg].wpos;
     size_t end = ref.search_index(c.seqId, p + cmw);
+#if FO_SLIDE_END == 0
     size_t last = ref.search_index(c.seqId, c.rangeEndPos + cmw);
+#else
+    size_t last = ref.search_index(c.seqId, c.rangeEndPos + Q.len);
+#endif
     SlideMapper sm(Q);
     for (size_t i = beg; i < end; i++) sm.insert_ref(mi[i]);
     out.sharedSketchSize = 0; out.optimalStart = beg; out.optimalEnd = beg;
+#if FO_BEST_INIT == 0
     bool first = true;
-    while (true) {
+#else
+    bool first = false;   // (shared >= 0 = the initial value: the first placement then takes the `==` branch, which sets optimalEnd = beg
+#endif                    //  = the value it already holds -- the two readings cannot differ)
+    auto consider = [&]() {
       if (first || sm.shared > out.sharedSketchSize) {
         out.sharedSketchSize = sm.shared; out.optimalStart = beg; out.optimalEnd = beg;
         first = false;
       } else if (sm.shared == out.sharedSketchSize) {
         out.optimalEnd = beg;
       }
+    };
+    while (true) {
+      consider();
       if (end >= last) break;
+#if FO_SLIDE_ADVANCE == 0
       p += 1;
-      if (beg + 1 < mi.size() && mi[beg + 1].seqId == c.seqId && mi[beg + 1].wpos <= p) { sm.delete_ref(mi[beg]); beg++; }
+      if (beg + 1 < mi.size() && mi[beg + 1].seqId == c.seqId && mi[beg + 1].wpos <= p) {
+        sm.delete_ref(mi[beg]); beg++;
+#if FO_SLIDE_EVAL == 1
+        if (end < last && mi[end].wpos <= p + cmw - 1) consider();
+#endif
+      }
       if (end < last && mi[end].wpos <= p + cmw - 1) { sm.insert_ref(mi[end]); end++; }
+#else
+      // one record per step: the front record leaves, the window becomes the records with wpos in [front.wpos, front.wpos + cmw)
+      sm.delete_ref(mi[beg]); beg++;
+      if (beg >= end) { if (end < last) { sm.insert_ref(mi[end]); end++; } else break; }
+      while (end < last && mi[end].wpos < mi[beg].wpos + cmw) { sm.insert_ref(mi[end]); end++; }
+#endif
     }
     out.meanOptimalPos = (mi[out.optimalStart].wpos + mi[out.optimalEnd].wpos) / 2;
     out.seqId = c.seqId;
@@ -575,7 +637,7 @@ struct Mapper {
       L2Locus l2;
       compute_l2(Q, c, l2);
       float mash_dist = j2md((float)(1.0 * l2.sharedSketchSize / Q.sketchSize), param.kmerSize);
-      float lower = md_lower_bound(mash_dist, Q.sketchSize, param.kmerSize, CONFIDENCE_INTERVAL);
+      float lower = md_lower_bound(mash_dist, Q.sketchSize, param.kmerSize, L2_CONFIDENCE_INTERVAL);
       float nucIdentity = 100 * (1 - mash_dist);
       float upper = 100 * (1 - lower);
       if (upper >= param.percentageIdentity) {
@@ -605,7 +667,11 @@ static inline void compute_cgi(const Parameters &param, const std::vector<Mappin
                                uint64_t total_query_fragments, std::vector<CGIResult> &out) {
   struct R { seqno_t refSeq, genome, qseq, refStart, bin; float id; };
   std::vector<R> v; v.reserve(results.size());
+#if FO_CGI_BIN == 0
   const int bin_len = param.minReadLength - 20;
+#else
+  const int bin_len = param.minReadLength;
+#endif
   for (const auto &e : results) {
     R r; r.refSeq = e.refSeqId; r.qseq = e.querySeqId; r.refStart = e.refStartPos; r.id = e.nucIdentity;
     r.bin = bin_len != 0 ? e.refStartPos / bin_len : 0;
@@ -618,8 +684,13 @@ static inline void compute_cgi(const Parameters &param, const std::vector<Mappin
     if (a.genome != b.genome) return a.genome < b.genome;
     if (a.qseq != b.qseq) return a.qseq < b.qseq;
     if (a.id != b.id) return a.id > b.id;
+#if FO_CGI_TIES == 0
     if (a.refSeq != b.refSeq) return a.refSeq < b.refSeq;
     return a.refStart < b.refStart;
+#else
+    if (a.refSeq != b.refSeq) return a.refSeq > b.refSeq;
+    return a.refStart > b.refStart;
+#endif
   });
   for (const auto &e : v)
     if (one.empty() || !(e.genome == one.back().genome && e.qseq == one.back().qseq)) one.push_back(e);
@@ -628,7 +699,11 @@ static inline void compute_cgi(const Parameters &param, const std::vector<Mappin
     if (a.refSeq != b.refSeq) return a.refSeq < b.refSeq;
     if (a.bin != b.bin) return a.bin < b.bin;
     if (a.id != b.id) return a.id > b.id;
+#if FO_CGI_TIES == 0
     return a.qseq < b.qseq;
+#else
+    return a.qseq > b.qseq;
+#endif
   });
   for (const auto &e : one)
     if (two.empty() || !(e.refSeq == two.back().refSeq && e.bin == two.back().bin)) two.push_back(e);

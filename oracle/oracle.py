@@ -10,7 +10,14 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libfastani_oracle.so")
+# FA_ORACLE_DEFINES="FO_SLIDE_END=1,FO_L2_CI=0.75f": one of the alternative readings named at the top of fastani_oracle.hpp,
+# built into a library of its own (scripts/oracle_sensitivity.py).  Unset = the default reading, the one everything else uses.
+_DEFINES = [d.strip() for d in os.environ.get("FA_ORACLE_DEFINES", "").split(",") if d.strip()]
+for _d in _DEFINES:
+    if not _d.startswith("FO_") or not all(ch.isalnum() or ch in "_=." for ch in _d):
+        raise ValueError(f"FA_ORACLE_DEFINES: {_d!r} is not an FO_<RULE>=<value> switch")
+_TAG = "".join("__" + d.replace("=", "_").replace(".", "p") for d in _DEFINES)
+_SO = os.path.join(_HERE, "_build", f"libfastani_oracle{_TAG}.so")
 
 
 def build(force=False):
@@ -22,7 +29,11 @@ def build(force=False):
         with open(_SO + ".lock", "w") as lock:                 # several processes may ask at once: one runs make
             fcntl.flock(lock, fcntl.LOCK_EX)
             if force or stale():
-                subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+                if _DEFINES:
+                    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-pthread", "-shared"] + ["-D" + d for d in _DEFINES]
+                                          + ["-o", _SO, os.path.join(_HERE, "oracle_capi.cpp")])
+                else:
+                    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _SO
 
 

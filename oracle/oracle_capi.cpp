@@ -30,7 +30,7 @@ float fo_md_lower_bound(float d, int s, int k, float ci) { return md_lower_bound
 // identity and upper-bound identity of an L2 mapping with `shared` of `s` sketch elements
 void fo_identity(int shared, int s, int k, float *identity, float *upper) {
   float md = j2md((float)(1.0 * shared / s), k);
-  float lo = md_lower_bound(md, s, k, CONFIDENCE_INTERVAL);
+  float lo = md_lower_bound(md, s, k, L2_CONFIDENCE_INTERVAL);
   *identity = 100 * (1 - md);
   *upper = 100 * (1 - lo);
 }

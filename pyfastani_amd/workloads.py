@@ -65,6 +65,78 @@ def config5(n_families=10, n_members=20, length=5_000_000):
     return families(4000, n_families, n_members, length)
 
 
+def _plant(g, anc, element, copies, half_reversed, taken):
+    """Overwrite `copies` non-overlapping places of `anc` with `element` (every second copy reverse-complemented if asked)."""
+    n, m = len(anc), len(element)
+    placed = 0
+    while placed < copies:
+        at = int(g.integers(0, n - m))
+        if any(at < b and a < at + m for a, b in taken):
+            continue
+        taken.append((at, at + m))
+        anc[at: at + m] = syn.reverse_complement_codes(element) if (half_reversed and placed % 2) else element
+        placed += 1
+
+
+def genome_like_ancestor(g, length):
+    """A random ancestor with what real bacterial chromosomes have and i.i.d. sequence has not: 7 copies of a 5 kb element
+    (rRNA-operon-like), 30 copies of a 1.3 kb element, half of them on the other strand (IS-like), and three 300 bp
+    low-complexity tracts (a homopolymer, a dinucleotide whose k-mers are their own reverse complement, a trinucleotide)."""
+    anc = syn.random_codes(g, length)
+    taken = []
+    _plant(g, anc, syn.random_codes(g, 5000), 7, False, taken)
+    _plant(g, anc, syn.random_codes(g, 1300), 30, True, taken)
+    for unit in ([0], [0, 3], [1, 0, 2]):                     # A..., ATAT..., CAGCAG...
+        _plant(g, anc, np.resize(np.asarray(unit, np.uint8), 300), 1, False, taken)
+    return anc
+
+
+def indel_codes(g, codes, n_events, max_len=50):
+    """`n_events` insertions / deletions (equally likely) of length 1..max_len at random places."""
+    if n_events <= 0:
+        return codes
+    at = np.sort(g.integers(0, len(codes), n_events))
+    lens = g.integers(1, max_len + 1, n_events)
+    ins = g.random(n_events) < 0.5
+    pieces, a = [], 0
+    for p, l, i in zip(at.tolist(), lens.tolist(), ins.tolist()):
+        if p < a:
+            continue                                          # (inside the stretch the event before it deleted)
+        pieces.append(codes[a:p])
+        if i:
+            pieces.append(syn.random_codes(g, l))
+            a = p
+        else:
+            a = min(p + l, len(codes))
+    pieces.append(codes[a:])
+    return np.concatenate(pieces)
+
+
+def genome_like(seed, n_families, n_members, length, indel_share=0.01, inversion=100_000):
+    """Genome-LIKE families (the reference's benchmark runs on real assemblies, benches/mapping/bench.py:25-29; SURVEY.md 8d offers
+    "optional 1 % indel events of length 1-50 and one inversion of 100 kb"): every ancestor carries repeats and low-complexity
+    tracts (`genome_like_ancestor`); member 0 is the ancestor, the others are substituted at the usual divergences, then one
+    mutation event in a hundred (`indel_share` of the d x length substitutions) is an insertion or deletion of 1-50 bases, then
+    one `inversion`-long segment is reverse-complemented.  Returns (genomes as one-contig lists, family ids)."""
+    g = syn.rng(seed)
+    genomes, fam = [], []
+    for f in range(n_families):
+        anc = genome_like_ancestor(g, length)
+        for m in range(n_members):
+            d = 0.0 if m == 0 else syn.DIVERGENCES[m % len(syn.DIVERGENCES)]
+            codes = anc
+            if d:
+                codes = indel_codes(g, syn.mutate_codes(g, anc, d), int(round(d * length * indel_share)))
+                inv = min(inversion, len(codes) // 10)
+                if inv > 0:
+                    at = int(g.integers(0, len(codes) - inv))
+                    codes = codes.copy()
+                    codes[at: at + inv] = syn.reverse_complement_codes(codes[at: at + inv])
+            genomes.append([syn.to_ascii(codes)])
+            fam.append(f)
+    return genomes, np.asarray(fam)
+
+
 def write_fasta(path, contigs, width=60, prefix="contig"):
     """One genome as a FASTA file: a record per contig, `width`-column lines (numpy: no Python loop over lines)."""
     with open(path, "wb") as f:
