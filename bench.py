@@ -84,6 +84,8 @@ def parse_args():
     ap.add_argument("--no-fasta-leg", action="store_true", help="N=1: skip the files-to-table leg of config 3 (`saturated.config3.fasta_to_table`)")
     ap.add_argument("--config4", type=str, default="10x50", help="families x members of the config-4 leg (tests shrink it)")
     ap.add_argument("--config5", type=str, default="10x20", help="families x members of the config-5 leg (tests shrink it)")
+    ap.add_argument("--genome-like", type=str, default="10x20", help="families x members of the genome-like leg (tests shrink it)")
+    ap.add_argument("--no-genome-like", action="store_true", help="N=1: skip the genome-like leg")
     ap.add_argument("--detail", type=str, default=os.path.join(ROOT, "bench_detail.json"),
                     help="file that receives the FULL result (every leg, every stage); stdout carries the contract line only")
     return ap.parse_args()
@@ -150,9 +152,9 @@ def main():
     check(lib.fa_set_device(local_rank))
     ctx = dict(args=args, rank=rank, world=world, share_gpu=share_gpu, torch=torch, dist=dist, dist_on=dist_on)
     if args.leg:
-        if world != 1 or not (args.leg == "config4" or args.leg.startswith("config5:")):
-            raise SystemExit("--leg takes config4 or config5:k<k>f<fragment>, at N = 1")
-        print(json.dumps(config4_leg(ctx) if args.leg == "config4" else config5_leg(ctx)))
+        if world != 1 or not (args.leg in ("config4", "genome_like") or args.leg.startswith("config5:")):
+            raise SystemExit("--leg takes config4, genome_like or config5:k<k>f<fragment>, at N = 1")
+        print(json.dumps(_sig({"config4": config4_leg, "genome_like": genome_like_leg}.get(args.leg, config5_leg)(ctx), 9)))
         return
     result = strong_scaling(ctx) if args.strong else weak_scaling(ctx)
     if dist_on:
@@ -538,6 +540,12 @@ def weak_scaling(ctx):
             if not args.no_config45:
                 result["saturated"]["config4"] = config4_leg(ctx)
                 result["config5_cells"] = config5_leg(ctx)
+            if not args.no_genome_like:
+                gl = genome_like_leg(ctx)
+                same = [c for c in (result.get("config5_cells") or {}).get("cells", []) if (c["k"], c["fragment_length"]) == (16, 3000)]
+                # (per pair against the i.i.d. cell of the same parameters and the same shape, when both ran at the same size)
+                gl["vs_config5_k16_f3000"] = gl["pairs_per_s"] / same[0]["value"] if same and args.genome_like == args.config5 else None
+                result["genome_like"] = gl
         if not args.no_cpu_baseline:              # the CPU oracle legs are an N=1 measurement (rank 0 only)
             result.update(oracle_legs(args, anc, names, refs, mapper, [qs[0] for qs in rot_queries], timed_rows))
     return result
@@ -785,6 +793,8 @@ def resident_all_vs_all(ctx, genomes, fam, params, steps, warmup=1):
            "phases_ms": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in ph[:5]])),
            "sketch_stage": "k_query_fused (one launch)" if fused > 0 and apart == 0 else ("K1 + k_query_sketch (two launches)" if fused == 0 else "mixed"),
            "repeated_attempts_per_step": float(ph[9]), "l2_records_per_step": float(ph[5]), "host_pack_s": t_pack, "index_build_s": t_index,
+           "l2_loci_per_step": float(ph[6]), "wide_state_loci_per_step": float(ph[8]), "off_fast_l1_fragments_per_step": float(ph[22]),
+           "fragments": int(batch.total_fragments.sum()),
            "table_sha256": _sha256_rows(rows), **props}
     return out, mapper
 
@@ -807,6 +817,29 @@ def config4_leg(ctx):
             "generate_s": t_gen, "contigs": int(sum(len(c) for c in genomes)),
             "roofline": stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"],
                                        *(profiled_traffic("l2", TRAFFIC_PROFILE_CONFIG4) if (f, m, args.length) == (10, 50, 5_000_000) else (None, None))), **r}
+
+
+def genome_like_leg(ctx):
+    """The path timed on genome-LIKE inputs (the reference's benchmark maps real assemblies, benches/mapping/bench.py:25-29; every other
+    timed set here is i.i.d. ACGT with substitutions only -- one locus per related genome and fragment, the friendliest case):
+    `workloads.genome_like`, 200 x 200 x 5 Mb at the default parameters, with the share of fragments that left the fast forms
+    (k_l1's block sort -> merge / HBM road / k_l1_big; loci that needed the wide L2 state; repeated attempts)."""
+    args = ctx["args"]
+    from pyfastani_amd import workloads
+    f, m = (int(x) for x in args.genome_like.split("x"))
+    t0 = time.time()
+    genomes, fam = workloads.genome_like(6000, f, m, args.length)
+    t_gen = time.time() - t0
+    r, mapper = resident_all_vs_all(ctx, genomes, fam, {}, max(args.saturated_steps, 1))
+    if not (r["self_identity_min"] is not None and r["self_identity_min"] >= 99.999 and r["hits_within_family"]):
+        raise SystemExit(f"GENOME-LIKE FAILURE: the oracle-free properties do not hold: {r}")
+    n = len(genomes)
+    roof = stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"], None, None)
+    off = r["off_fast_l1_fragments_per_step"] / max(r["fragments"], 1)
+    return {"workload": f"{n} x {n} genome-like all-vs-all ({f} families x {m}) of {args.length / 1e6:g} Mb: 7 x 5 kb + 30 x 1.3 kb repeats (half reversed), 3 low-complexity "
+                        f"tracts, 1 % of the mutation events indels of 1-50 bases, one 100 kb inversion; k=16 frag=3000 w={r['window_size']}",
+            "generate_s": t_gen, "pairs_per_s": r["value"], "roofline": roof, "frac": roof["frac"],
+            "off_fast_path_share": off, "wide_state_loci_share": r["wide_state_loci_per_step"] / max(r["l2_loci_per_step"], 1.0), **r}
 
 
 def config5_leg(ctx):
@@ -951,15 +984,15 @@ def strong_core(ctx, steps, warmup):
     batch = mapper.upload_genomes([genomes[i] for i in owned])
     max_rows = max(len(o) for o in deal) * n
     exchange = sharding.ResidentHitTable(owned, max_rows, world, comm_device="cpu" if share_gpu else "cuda")
-    phase, rec, repeats = np.zeros(5), 0.0, 0.0
+    phase, rec, repeats, off_fast = np.zeros(5), 0.0, 0.0, 0.0
 
     def step(timed):
-        nonlocal phase, rec, repeats
+        nonlocal phase, rec, repeats, off_fast
         tables = exchange.step(batch)
         if timed:
-            ms = (C.c_float * 16)()
-            lib.fa_mapper_last_timings(mapper._h, ms, 16)     # sums over the passes of this call (device stamps)
-            phase += np.array(list(ms)[:5]); rec += float(ms[5]); repeats += float(ms[9])
+            ms = (C.c_float * 24)()
+            lib.fa_mapper_last_timings(mapper._h, ms, 24)     # sums over the passes of this call (device stamps)
+            phase += np.array(list(ms)[:5]); rec += float(ms[5]); repeats += float(ms[9]); off_fast += float(ms[22])
         return tables
 
     for _ in range(max(warmup, 1)):
@@ -1004,6 +1037,8 @@ def strong_core(ctx, steps, warmup):
         "fragments_per_rank": [int(sum(weights[i] for i in o)) for o in deal],
         "phases_ms_rank0": dict(zip(["sketch_ms", "lookup_l1_ms", "l2_ms", "cgi_ms", "total_ms"], [float(x) for x in phase])),
         "repeated_attempts_per_step": repeats / max(steps, 1),
+        # fragments of rank 0 that left k_l1's fast form (block sort -> merge, HBM road, k_l1_big), as a share of its fragments
+        "off_fast_path_share_rank0": off_fast / max(steps, 1) / max(sum(weights[i] for i in owned), 1),
         "roofline": stage_roofline(rec / max(steps, 1), float(phase[2]), traffic, src),
         "index_minimizers": len(mapper.minimizers), "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack,
         "generate_s": t_gen,  # (exactly 100.0 except for the end-of-contig effect the oracle shows too: the fragment that ends at the contig end)

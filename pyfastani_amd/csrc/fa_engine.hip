@@ -429,7 +429,7 @@ struct PassStatus {
   int32_t stats[4];                 // [0] largest query sketch
   int32_t total_rows, pad0[3];
   uint64_t totals[4];               // seeds, largest fragment, scratch words, reference records in L2 ranges
-  uint32_t counters[8];             // [0], [1] unused (the loci are counted per region, loci_region); [2] loci overflow, wide-state loci, finished row workgroups, k_l1 roads (2)
+  uint32_t counters[8];             // [0] fragments k_l1 merged instead of block-sorting, [1] fragments on the HBM road / cut by k_l1_big; [2] loci overflow, wide-state loci, finished row workgroups, k_l1 roads (2: FA_L1_STATS samples)
   unsigned long long pinfo[4];      // slide events reserved (fused L2 form), speculation flags
   unsigned long long ev_region[EV_REGIONS], rec_region[EV_REGIONS];   // k_l2_events: events reserved / records read per arena region
   uint32_t loci_region[LOCI_REGIONS];                                  // k_l1: loci reserved per region (LociRegions)
@@ -1670,6 +1670,7 @@ struct QueryPass {
     w.last_ms[7] += (float)events_total;  // slide events
     w.last_ms[8] += (float)h_counters[3]; // loci that needed the wide L2 state
     w.last_ms[20] += (float)h_counters[5]; w.last_ms[21] += (float)h_counters[6];   // FA_L1_STATS=1: fragments block-sorted / merged by k_l1
+    w.last_ms[22] += (float)(h_counters[0] + h_counters[1]);   // fragments that left k_l1's fast form (exact): merged in LDS, HBM road, k_l1_big
     if (h_counters[5] + h_counters[6] > 0) {
       const double nf = (double)(h_counters[5] + h_counters[6]);
       fprintf(stderr, "[fa] k_l1 phases, shader-clock ticks per fragment (thread 0):");

@@ -1179,6 +1179,8 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
       if (!block_sorted) list_offsets();                                // (the key buffer may have overwritten them)
     }
     if (l1_dbg) atomicAdd(&a.counters[block_sorted ? 5 : 6], 1u);   // FA_L1_STATS=1: which road the fragments took
+    // fragments that left the fast form (block sort -> gather + merge), counted exactly and always: one atomic on the rare road
+    if (!block_sorted && tid == 0) atomicAdd(&a.counters[0], 1u);
     phase(1);
     if (!block_sorted) {
     // flat gather, two elements per thread and trip so that two index reads are in flight
@@ -1259,7 +1261,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   } else {
     // ---- more seed hits than LDS holds: lists gathered into HBM scratch and sorted there ----
     seeds = a.ovf_buf + a.ovf_off[f];
-    if (tid == 0) sh_run = 0;
+    if (tid == 0) { sh_run = 0; atomicAdd(&a.counters[1], 1u); }         // (off the fast form: the HBM road)
     __syncthreads();
     for (int j0 = 0; j0 < s; j0 += blockDim.x) {
       int j = j0 + tid;
@@ -1896,6 +1898,7 @@ __global__ __launch_bounds__(L1_BIG_THREADS) void k_l1_big(L1Args a) {
     sh_base = base; sh_cnt = cnt;
     a.f_loci_lo[f] = base; a.f_loci_n[f] = cnt;
     a.big_state[f] = 1;
+    atomicAdd(&a.counters[1], 1u);                                       // (off the fast form: cut into LDS-sized chunks here)
   }
   __threadfence_block();
   __syncthreads();

@@ -1659,3 +1659,41 @@ def test_rows_of_a_pass_by_every_road():
         outs.append(json.loads(res.stdout.strip().splitlines()[-1]))
     assert outs[0] == outs[1] == outs[2], outs
     assert outs[0]["n_many"] == 12 * 30 and outs[0]["n_one"] == 30, outs
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# genome-LIKE inputs: repeats (7 x 5 kb, 30 x 1.3 kb on both strands), low-complexity tracts, indels, a 100 kb inversion
+# ----------------------------------------------------------------------------------------------------------------
+def test_genome_like_all_vs_all_matches_oracle_mapping_for_mapping():
+    """12 genome-like genomes of 1 Mb (3 families x 4: `workloads.genome_like`), every genome mapped against the index of all of
+    them: every L2 mapping, every CGI row and every hit equals the oracle's.  The inputs the reference's own benchmark uses are
+    real assemblies (benches/mapping/bench.py:25-29); these carry what i.i.d. sequence lacks -- several loci per fragment and
+    genome, exact ties between repeat copies, fragments broken by indels, the reverse strand over 100 kb."""
+    from pyfastani_amd import workloads
+    genomes, fam = workloads.genome_like(6000, 3, 4, 1_000_000)
+    n = len(genomes)
+    sk, osk = pf.Sketch(), OracleSketch()
+    sk.add_drafts(list(range(n)), genomes)
+    osk.add_drafts(list(range(n)), genomes)
+    mapper = sk.index()
+    osk.index()
+    assert len(mapper.minimizers) == len(osk.minimizers()[0]) and mapper.occurences_threshold == osk.freq_threshold
+    n_maps = multi = 0
+    for q, contigs in enumerate(genomes):
+        hits = mapper.query_draft([bytes(c) for c in contigs])
+        got = gpu_mappings(mapper)
+        ohits, det = osk.query_draft(contigs, threads=os.cpu_count() or 1, details=True)
+        want = oracle_mappings(det)
+        assert got == want, f"query {q}: {len(got)} mappings, oracle {len(want)}"
+        assert hit_tuples(hits) == ohits, f"query {q}"
+        n_maps += len(got)
+        per_frag_genome = {}
+        for qs, rs, *_ in got:
+            per_frag_genome[(qs, rs)] = per_frag_genome.get((qs, rs), 0) + 1
+        multi += sum(1 for v in per_frag_genome.values() if v > 1)
+        # a genome hits itself at exactly 100.0; the exact repeat copies cost it a few matches (fragments inside copies 2..n tie
+        # and land in the first copy's bin -- the reference's Shigella golden shows the same, 1600/1608: test_ani.py:86-91)
+        me = [h for h in hits if h.name == q][0]
+        assert me.identity == 100.0 and me.fragments - 12 <= me.matches <= me.fragments
+        assert all(fam[h.name] == fam[q] for h in hits)
+    assert n_maps > 8000 and multi > 50              # (fragments with several loci on one contig: what i.i.d. genomes never produce)

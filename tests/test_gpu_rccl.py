@@ -130,7 +130,7 @@ def test_bench_line_carries_configs_4_and_5():
     cell; the detail file holds `saturated.config4` (draft assemblies all-vs-all) and `config5_cells` (the nine (k,
     fragment_length) cells) with pairs/s, per-stage ms, the sketch-stage form and the oracle-free properties."""
     args = ["--refs", "6", "--length", "1500000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--clients", "0", "--no-boundary",
-            "--families", "2", "--members", "4", "--saturated-steps", "1", "--config4", "2x4", "--config5", "2x3"]
+            "--families", "2", "--members", "4", "--saturated-steps", "1", "--config4", "2x4", "--config5", "2x3", "--genome-like", "2x3"]
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
     short, line = _line_and_detail(res.stdout)
@@ -143,6 +143,11 @@ def test_bench_line_carries_configs_4_and_5():
     assert sum(c["degenerate"] for c in cells) == 1 and all(c["value"] > 0 and "sketch_stage" in c for c in cells)
     default = [c for c in cells if (c["k"], c["fragment_length"]) == (16, 3000)][0]
     assert default["window_size"] == 24 and default["sketch_stage"].startswith("k_query_fused")
+    # the genome-like leg (repeats, indels, an inversion): rate, its ratio to the i.i.d. cell of the same shape, and the share of
+    # fragments that left k_l1's fast form
+    gl = line["genome_like"]
+    assert gl["pairs"] == 36 and gl["pairs_per_s"] > 0 and 0.0 <= gl["off_fast_path_share"] <= 1.0 and gl["vs_config5_k16_f3000"] > 0
+    assert short["genome_like"]["pairs_per_s"] == pytest.approx(gl["pairs_per_s"], rel=1e-5)
 
 
 def test_every_collective_through_rccl_at_world_size_one(tmp_path):
