@@ -203,7 +203,9 @@ int fa_genomes_upload_fasta(fa_mapper *m, const char *const *paths, int32_t n_pa
  * the genomes that are mapped -- reads every file one time.  protein != 0: residue bytes are kept instead. */
 typedef struct fa_packed fa_packed;
 int fa_packed_read(const char *const *paths, int32_t n_paths, int protein, fa_packed **out);
-int fa_packed_append(fa_packed *p, const char *const *paths, int32_t n_paths);    /* more files behind the ones it holds */
+/* more files behind the ones it holds.  Thread-safe against the calls that read the set (info, add_packed, reload_packed): it
+ * grows the set under an exclusive lock they hold shared; fa_packed_free must not race with any of them. */
+int fa_packed_append(fa_packed *p, const char *const *paths, int32_t n_paths);
 void fa_packed_free(fa_packed *p);
 /* per file: its size in bytes, its records, its bases (arrays of *n_files entries, any may be NULL) */
 int fa_packed_info(fa_packed *p, int32_t *n_files, uint64_t *file_bytes, int64_t *records, int64_t *bases);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -42,9 +43,10 @@ class DevPool {
     const size_t q = (size_t)1 << (lg > 2 ? lg - 2 : 0);                 // a quarter of the octave
     return (bytes + q - 1) / q * q;
   }
-  void *alloc(size_t bytes, size_t &got) {
+  // `dev` receives the device the block lives on (the calling thread's current one): the owner hands it back to `free`
+  void *alloc(size_t bytes, size_t &got, int &dev) {
     got = class_of(std::max<size_t>(bytes, 1));
-    int dev = 0;
+    dev = 0;
     (void)hipGetDevice(&dev);
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -62,16 +64,23 @@ class DevPool {
     hip_check(e, "hipMalloc", __FILE__, __LINE__);
     return p;
   }
-  void free(void *p, size_t got) {
+  // `dev` = the device `alloc` reported.  A handle may be released from a thread that never entered the library (Python's garbage
+  // collector on a thread whose current device is 0): the barrier must be on the OWNING device and the block filed under it, so
+  // the thread is switched there for the duration and back afterwards.
+  void free(void *p, size_t got, int dev) {
     if (!p) return;
+    int cur = dev;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
     (void)hipDeviceSynchronize();                                     // (hipFree's implicit barrier: nothing in flight reads the block)
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    bool kept = false;
     {
       std::lock_guard<std::mutex> lk(mu_);
-      if (held_ + got <= max_held_) { free_[{dev, got}].push_back(p); held_ += got; return; }
+      if (max_held_ == SIZE_MAX) size_cap();
+      if (held_ + got <= max_held_) { free_[{dev, got}].push_back(p); held_ += got; kept = true; }
     }
-    (void)hipFree(p);
+    if (!kept) (void)hipFree(p);
+    if (cur != dev) (void)hipSetDevice(cur);
   }
   // everything the pool holds back to the runtime
   void trim() {
@@ -82,14 +91,24 @@ class DevPool {
   size_t held() { std::lock_guard<std::mutex> lk(mu_); return held_; }
 
  private:
-  DevPool() {
+  DevPool() {}
+  // FA_POOL_MAX_GB if set; else 30 % of the device's memory, 96 GB at most (decided at the first release: a device is current
+  // then).  Other allocators of the process (torch tensors, RCCL buffers) never make the pool trim, so it must not sit on most of
+  // a device; `fa_device_trim` gives everything back on request.
+  void size_cap() {
     const char *e = getenv("FA_POOL_MAX_GB");
-    const double gb = e ? atof(e) : 96.0;
+    double gb = 96.0;
+    if (e) gb = atof(e);
+    else {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) gb = std::min(96.0, 0.30 * (double)total_b / (1024.0 * 1024.0 * 1024.0));
+      else (void)hipGetLastError();
+    }
     max_held_ = gb <= 0 ? 0 : (size_t)(gb * 1024.0 * 1024.0 * 1024.0);
   }
   std::mutex mu_;
   std::map<std::pair<int, size_t>, std::vector<void *>> free_;
-  size_t held_ = 0, max_held_ = 0;
+  size_t held_ = 0, max_held_ = SIZE_MAX;                            // (SIZE_MAX: not sized yet)
 };
 
 // Owning device array with geometric growth; contents are preserved on growth only when asked.
@@ -98,31 +117,33 @@ struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
   size_t block = 0;      // bytes of the pool block behind p
+  int dev = 0;           // the device the block lives on
   DevBuf() = default;
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
-  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), block(o.block) { o.p = nullptr; o.cap = 0; o.block = 0; }
+  DevBuf(DevBuf &&o) noexcept : p(o.p), cap(o.cap), block(o.block), dev(o.dev) { o.p = nullptr; o.cap = 0; o.block = 0; }
   DevBuf &operator=(DevBuf &&o) noexcept {
-    if (this != &o) { release(); p = o.p; cap = o.cap; block = o.block; o.p = nullptr; o.cap = 0; o.block = 0; }
+    if (this != &o) { release(); p = o.p; cap = o.cap; block = o.block; dev = o.dev; o.p = nullptr; o.cap = 0; o.block = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
   void release() {
-    if (p) DevPool::get().free(p, block);
+    if (p) DevPool::get().free(p, block, dev);
     p = nullptr; cap = 0; block = 0;
   }
   void ensure(size_t n, bool keep = false, hipStream_t stream = nullptr, size_t used = 0) {
     if (n <= cap) return;
     size_t ncap = keep ? std::max(n, cap + cap / 2) : n;
     size_t got = 0;
-    T *np = (T *)DevPool::get().alloc(std::max<size_t>(ncap, 1) * sizeof(T), got);
+    int ndev = 0;
+    T *np = (T *)DevPool::get().alloc(std::max<size_t>(ncap, 1) * sizeof(T), got, ndev);
     if (keep && p && used) {
       hipError_t e = hipMemcpyAsync(np, p, used * sizeof(T), hipMemcpyDeviceToDevice, stream);
       if (e == hipSuccess) e = hipStreamSynchronize(stream);
-      if (e != hipSuccess) { DevPool::get().free(np, got); hip_check(e, "copy on growth", __FILE__, __LINE__); }
+      if (e != hipSuccess) { DevPool::get().free(np, got, ndev); hip_check(e, "copy on growth", __FILE__, __LINE__); }
     }
-    if (p) DevPool::get().free(p, block);
-    p = np; cap = got / sizeof(T); block = got;                    // (the whole block is usable: fewer regrowths)
+    if (p) DevPool::get().free(p, block, dev);
+    p = np; cap = got / sizeof(T); block = got; dev = ndev;        // (the whole block is usable: fewer regrowths)
   }
   void upload(const T *src, size_t n, hipStream_t stream) {
     ensure(n);

@@ -14,6 +14,7 @@
 #include <memory>
 #include <condition_variable>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -566,6 +567,8 @@ struct fa_mapper {
     bool fuse_off = false;
     int fuse_skip = 0, fuse_penalty = 0;
     int smax_misses = 0;      // times the largest sketch outgrew the bound (the first growth is tight, later ones are not)
+    // share of the fragments of the last accepted part in the two lower size classes of k_l1 (-1: not seen yet)
+    float l1_small_share = -1.0f, l1_mid_share = -1.0f;
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
   // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
@@ -1037,6 +1040,7 @@ struct QueryPass {
     ms.l_cap = std::max(ms.l_cap, sp.l_cap);
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
+    ms.l1_small_share = sp.l1_small_share; ms.l1_mid_share = sp.l1_mid_share;
     ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
   }
   // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
@@ -1152,8 +1156,10 @@ struct QueryPass {
     const int t0, ntiles;
     const int smax;
     const int64_t l_cap;
-    int l1_threads = 256, l1_nt = 256;
-    uint32_t seed_slots = 0;
+    struct L1Class { int nt; uint32_t slots, n_lo, n_hi; };   // one launch of k_l1: the fragments with n_lo <= hits <= n_hi
+    L1Class l1[3];
+    int n_l1 = 0;
+    uint32_t seed_slots = 0;                                  // slots of the last class
     bool wide = false;
     LociRegions loci{nullptr, 1, 0};          // regions of the locus numbering of this part
     const int32_t *frag_order = nullptr;      // workgroup order of the part (prepare_order), null = identity
@@ -1193,18 +1199,48 @@ struct QueryPass {
     const int smax = p.smax;
     const int64_t l_cap = p.l_cap;
     // LDS also holds smax list offsets; the in-place merge keeps at most 32 seeds per thread in registers
-    // threads per fragment in k_l1: 256 while 16 seeds per thread suffice (4-wave workgroups, eight per CU: a 5 Mb query
-    // is one round of workgroups), else 512; FA_L1_THREADS = 256 / 512 / 1024 forces one
     static const int l1_forced = (int)exp_u64("FA_L1_THREADS", 0);
-    p.l1_threads = l1_forced ? l1_forced : (std::min(sp.seed_slots, lds_seed_cap_max(sp.smax)) <= 16 * 256 ? 256 : 512);
-    p.l1_nt = p.l1_threads >= 1024 ? 1024 : (p.l1_threads >= 512 ? 512 : 256);
-    p.seed_slots = std::min(std::min(sp.seed_slots, lds_seed_cap_max(smax)), (uint32_t)(L1_INPLACE_MAX * p.l1_nt));
-    // (a 512-thread workgroup is eight waves: four of them fill a CU whatever their LDS up to 39 KB, so the block table of
-    // l1_block_sort -- a third as many entries as seed slots -- gets all the slots the 16-per-thread form can address)
-    // (7 936, not 8 192: the kilobyte goes to the key buffer behind the slots, which then holds the (key, place) pairs of 1 024
-    // blocks -- the 4 x 10^8-record index of config 3 adds ~500 chance hits, each a block of its own, to the ~250 blocks of a
-    // fragment's relatives -- and four workgroups still fill a CU)
-    if (p.l1_nt == 512 && p.seed_slots <= 16u * 512u) p.seed_slots = std::min<uint32_t>(16u * 512u - 256u, lds_seed_cap_max(smax));
+    // k_l1 runs once per size class of fragments (L1Args::n_lo / n_hi): up to 4 096 hits the 256-thread form with 16 hits per
+    // thread (4-wave workgroups, eight per CU: a 5 Mb query is one round of workgroups), up to 7 936 the 512-thread form with 16,
+    // beyond the 512-thread form with 32 (above 4 096 hits 512 threads measured best: fewer hits per thread shorten every thread's
+    // chain of dependent LDS round trips; 1 024 threads pay more for barriers than they gain).  A class the speculated bound
+    // (sp.seed_slots: the largest fragment seen, plus a quarter) does not reach is not launched; the last class takes everything
+    // above its lower bound, overflow into HBM scratch included.  FA_L1_THREADS = 256 / 512 / 1024 forces ONE launch of that form.
+    {
+      const uint32_t cap_max = lds_seed_cap_max(smax), need = std::min(sp.seed_slots, cap_max);
+      p.n_l1 = 0;
+      if (l1_forced) {
+        const int nt = l1_forced >= 1024 ? 1024 : (l1_forced >= 512 ? 512 : 256);
+        uint32_t slots = std::min(need, (uint32_t)(L1_INPLACE_MAX * nt));
+        if (nt == 512 && slots <= 16u * 512u) slots = std::min<uint32_t>(16u * 512u - 256u, cap_max);
+        p.l1[p.n_l1++] = Part::L1Class{nt, slots, 0u, 0xFFFFFFFFu};
+      } else {
+        const uint32_t s_slots = std::min<uint32_t>(need, L1_SMALL_HITS);
+        p.l1[p.n_l1++] = Part::L1Class{256, s_slots, 0u, need <= L1_SMALL_HITS ? 0xFFFFFFFFu : s_slots};
+        if (need > L1_SMALL_HITS) {
+          // (a 512-thread workgroup is eight waves: four of them fill a CU whatever their LDS up to 39 KB, so the block table of
+          // l1_block_sort -- a third as many entries as seed slots -- gets all the slots the 16-per-thread form can address)
+          // (7 936, not 8 192: the kilobyte goes to the key buffer behind the slots, which then holds the (key, place) pairs of 1 024
+          // blocks -- the 4 x 10^8-record index of config 3 adds ~500 chance hits, each a block of its own, to the ~250 blocks of a
+          // fragment's relatives -- and four workgroups still fill a CU)
+          const uint32_t m_slots = std::min<uint32_t>(L1_MID_HITS, cap_max);
+          p.l1[p.n_l1++] = Part::L1Class{512, m_slots, s_slots + 1u, need <= m_slots ? 0xFFFFFFFFu : m_slots};
+          if (need > m_slots)
+            p.l1[p.n_l1++] = Part::L1Class{512, std::min<uint32_t>(need, (uint32_t)(L1_INPLACE_MAX * 512)), m_slots + 1u, 0xFFFFFFFFu};
+        }
+      }
+      // a class that held under a twentieth of the fragments of the last accepted part is not worth a launch of its own (a launch
+      // walks every fragment: 1.7 million workgroups that return at once cost config 3 two milliseconds): its fragments go to the
+      // next class up, whose form handles fewer hits as well.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
+      static const float thin = getenv("FA_L1_THIN_CLASS") ? (float)atof(getenv("FA_L1_THIN_CLASS")) : 0.05f;
+      if (p.n_l1 == 3 && sp.l1_mid_share >= 0.0f && sp.l1_mid_share < thin) { p.l1[2].n_lo = p.l1[1].n_lo; p.l1[1] = p.l1[2]; p.n_l1 = 2; }
+      if (p.n_l1 >= 2 && sp.l1_small_share >= 0.0f && sp.l1_small_share < thin) {
+        p.l1[1].n_lo = 0u;
+        for (int c = 1; c < p.n_l1; c++) p.l1[c - 1] = p.l1[c];
+        p.n_l1--;
+      }
+      p.seed_slots = p.l1[p.n_l1 - 1].slots;                       // "fits LDS" for seed_totals and k_l1_big: the last class's slots
+    }
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
     ln.l_rfirst.ensure((size_t)l_cap); ln.l_rlast.ensure((size_t)l_cap + 4); ln.l_rpart.ensure((size_t)l_cap);
     ln.l_group.ensure((size_t)l_cap); ln.l_shared.ensure((size_t)l_cap); ln.l_pos.ensure((size_t)l_cap);
@@ -1299,7 +1335,6 @@ struct QueryPass {
     uint32_t *const d_counters = ln.status.p->counters;
     unsigned long long *const d_pinfo = ln.status.p->pinfo;
     const uint32_t seed_slots = p.seed_slots;
-    const int l1_threads = p.l1_threads, l1_nt = p.l1_nt;
     // ---- seed totals and speculation checks (the lookup itself is the tail of k_query_sketch).  A kernel of its own
     //      only where k_l1 / k_l1_big need the scratch offsets it produces; else workgroup F of k_l1's launch ----
     const bool fold_totals = sp.scratch_words == 0;
@@ -1317,7 +1352,7 @@ struct QueryPass {
       a.l_frag = ln.l_frag.p; a.l_seq = ln.l_seq.p; a.l_start = ln.l_start.p; a.l_end = ln.l_end.p; a.l_group = ln.l_group.p;
       a.l_rfirst = ln.l_rfirst.p; a.l_rlast = ln.l_rlast.p; a.l_rpart = ln.l_rpart.p;
       a.counters = d_counters; a.loci = p.loci; a.qcap = qcap; a.frag_len = m.P.fragment_length; a.l_cap = (int32_t)l_cap;
-      a.lds_seed_cap = seed_slots; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
+      a.lds_seed_cap = seed_slots; a.totals_seed_cap = seed_slots; a.n_lo = 0; a.n_hi = 0xFFFFFFFFu; a.pinfo = d_pinfo; a.lut_smax = smax; a.scratch_words = sp.scratch_words;
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       static const bool l1_block_sort_on = !(getenv("FA_L1_BLOCK_SORT") && atoi(getenv("FA_L1_BLOCK_SORT")) == 0);
       static const bool l1_stats = getenv("FA_L1_STATS") && atoi(getenv("FA_L1_STATS")) != 0;
@@ -1328,8 +1363,7 @@ struct QueryPass {
       // FA_L1_NEAR = 0 / 1: never / always (the A/B of the HBM fetch: profiles/r05_l1_near_fetch.txt).
       static const int l1_near_env = getenv("FA_L1_NEAR") ? atoi(getenv("FA_L1_NEAR")) : -1;
       const bool l1_near_on = l1_near_env < 0 ? m.N >= 300000000LL : l1_near_env != 0;
-      // (bit 3, -DFA_EXPERIMENTS builds only: FA_L1_PREFILTER=1, dead hits dropped before the block sort -- not yet run on a GPU)
-      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0) | (exp_u64("FA_L1_PREFILTER", 0) ? 8 : 0);
+      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
@@ -1345,25 +1379,29 @@ struct QueryPass {
         if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_l1_big, dim3((unsigned)F), dim3(L1_BIG_THREADS), lds, st, a);
       }
-      // (above 4096 seeds 512 threads measured best: fewer seeds per thread shorten every thread's chain of dependent
-      // LDS round trips; 1024 threads pay more for barriers than they gain)
-      auto go = [&](auto nt_tag) {
+      // one launch per size class (Part::L1Class); the seed totals ride in the first one
+      auto go = [&](auto nt_tag, const Part::L1Class &c, bool fold) {
         constexpr int NTT = decltype(nt_tag)::value;
-        const size_t lds = l1_lds_bytes(seed_slots, smax, l1_nt);
+        const size_t lds = l1_lds_bytes(c.slots, smax, NTT);
         FA_REQUIRE(lds + 1024 <= 160 * 1024, FA_ERR_UNSUPPORTED, "query sketch too large for the LDS tables of the L1 kernel");
         static const bool dbg = getenv("FA_DEBUG_L1") != nullptr;
-        if (dbg) fprintf(stderr, "k_l1: F=%lld seed_slots=%u smax=%d lds=%zu\n", (long long)F, seed_slots, smax, lds);
-        if (seed_slots <= 16 * (uint32_t)NTT) {
+        if (dbg) fprintf(stderr, "k_l1<%d>: F=%lld hits %u..%u seed_slots=%u smax=%d lds=%zu\n", NTT, (long long)F, c.n_lo, c.n_hi, c.slots, smax, lds);
+        L1Args b = a;
+        b.lds_seed_cap = c.slots; b.n_lo = c.n_lo; b.n_hi = c.n_hi; b.fold_totals = fold ? 1 : 0;
+        if (c.slots <= 16 * (uint32_t)NTT) {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3(l1_grid + (fold_totals ? 1u : 0u)), dim3(NTT), lds, st, a);
+          hipLaunchKernelGGL((k_l1<NTT, 16>), dim3(l1_grid + (fold ? 1u : 0u)), dim3(NTT), lds, st, b);
         } else {
           if (lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)k_l1<NTT, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3(l1_grid + (fold_totals ? 1u : 0u)), dim3(NTT), lds, st, a);
+          hipLaunchKernelGGL((k_l1<NTT, 32>), dim3(l1_grid + (fold ? 1u : 0u)), dim3(NTT), lds, st, b);
         }
       };
-      if (l1_threads >= 1024) go(std::integral_constant<int, 1024>());
-      else if (l1_threads >= 512) go(std::integral_constant<int, 512>());
-      else go(std::integral_constant<int, 256>());
+      for (int c = 0; c < p.n_l1; c++) {
+        const bool fold = fold_totals && c == 0;
+        if (p.l1[c].nt >= 1024) go(std::integral_constant<int, 1024>(), p.l1[c], fold);
+        else if (p.l1[c].nt >= 512) go(std::integral_constant<int, 512>(), p.l1[c], fold);
+        else go(std::integral_constant<int, 256>(), p.l1[c], fold);
+      }
     }
     debug_sync(st, "l1");
   }
@@ -1642,6 +1680,7 @@ struct QueryPass {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;
     }
+    if (F > 0) { sp.l1_small_share = (float)h_stats[1] / (float)F; sp.l1_mid_share = (float)h_stats[2] / (float)F; }
     publish_spec(sp);
     // ---- accepted ----
     {
@@ -1977,6 +2016,9 @@ static void fill_genomes_from_fasta(fa_mapper *m, fa_genomes *g, const char *con
 struct fa_packed {
   bool protein = false;
   std::vector<PackedFasta> files;
+  // fa_packed_append grows `files` (and moves every PackedFasta) under the exclusive lock; the calls that read them
+  // (fa_packed_info, fa_sketch_add_packed, fa_genomes_reload_packed -- all run without the GIL) hold it shared for their duration
+  std::shared_mutex mtx;
 };
 // the bookkeeping of fa_sketch_add_fasta_many over files that are packed already (s->mtx held by the caller)
 static void sketch_add_packed_files(fa_sketch *s, const PackedFasta *files, int32_t n_paths, int64_t *n_records, int64_t *n_short) {
@@ -2259,6 +2301,7 @@ int fa_packed_append(fa_packed *p, const char *const *paths, int32_t n_paths) {
     FA_REQUIRE(p && paths && n_paths >= 0, FA_ERR_INVALID, "null argument or negative count");
     std::vector<PackedFasta> more;
     read_fasta_packed_many(paths, (size_t)n_paths, p->protein, more);
+    std::unique_lock<std::shared_mutex> grow(p->mtx);
     p->files.reserve(p->files.size() + more.size());
     for (auto &f : more) p->files.push_back(std::move(f));
   });
@@ -2266,6 +2309,7 @@ int fa_packed_append(fa_packed *p, const char *const *paths, int32_t n_paths) {
 void fa_packed_free(fa_packed *p) { delete p; }
 int fa_packed_info(fa_packed *p, int32_t *n_files, uint64_t *file_bytes, int64_t *records, int64_t *bases) {
   return guarded([&] {
+    std::shared_lock<std::shared_mutex> hold(p->mtx);
     if (n_files) *n_files = (int32_t)p->files.size();
     for (size_t i = 0; i < p->files.size(); i++) {
       if (file_bytes) file_bytes[i] = (uint64_t)p->files[i].file_bytes;
@@ -2276,7 +2320,9 @@ int fa_packed_info(fa_packed *p, int32_t *n_files, uint64_t *file_bytes, int64_t
 }
 int fa_sketch_add_packed(fa_sketch *s, fa_packed *p, int32_t first, int32_t count, int64_t *n_records, int64_t *n_short) {
   return guarded([&] {
-    FA_REQUIRE(p && first >= 0 && count >= 0 && (size_t)first + (size_t)count <= p->files.size(), FA_ERR_INVALID, "file range outside the packed set");
+    FA_REQUIRE(p, FA_ERR_INVALID, "null packed set");
+    std::shared_lock<std::shared_mutex> hold(p->mtx);
+    FA_REQUIRE(first >= 0 && count >= 0 && (size_t)first + (size_t)count <= p->files.size(), FA_ERR_INVALID, "file range outside the packed set");
     FA_REQUIRE(p->protein == (s->P.alphabet_size != 4), FA_ERR_INVALID, "the files were packed for the other alphabet");
     std::lock_guard<std::mutex> lock(s->mtx);
     bind_device(s->device);
@@ -2285,7 +2331,9 @@ int fa_sketch_add_packed(fa_sketch *s, fa_packed *p, int32_t first, int32_t coun
 }
 int fa_genomes_reload_packed(fa_mapper *m, fa_genomes *g, fa_packed *p, int32_t first, int32_t count) {
   return guarded([&] {
-    FA_REQUIRE(g && p && first >= 0 && count >= 0 && (size_t)first + (size_t)count <= p->files.size(), FA_ERR_INVALID, "file range outside the packed set");
+    FA_REQUIRE(g && p, FA_ERR_INVALID, "null argument");
+    std::shared_lock<std::shared_mutex> hold(p->mtx);
+    FA_REQUIRE(first >= 0 && count >= 0 && (size_t)first + (size_t)count <= p->files.size(), FA_ERR_INVALID, "file range outside the packed set");
     FA_REQUIRE(p->protein == (m->P.alphabet_size != 4), FA_ERR_INVALID, "the files were packed for the other alphabet");
     try {
       fill_genomes_from_packed(m, g, p->files.data() + first, count, true);

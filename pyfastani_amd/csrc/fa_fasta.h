@@ -252,9 +252,20 @@ inline size_t slurp(const char *path, std::vector<char> &buf) {
   struct stat st;
   if (fstat(fd, &st) != 0) { const int e = errno; ::close(fd); throw Error(FA_ERR_IO, std::string(path) + ": " + strerror(e)); }
   if (S_ISDIR(st.st_mode)) { ::close(fd); throw Error(FA_ERR_IO, std::string(path) + ": is a directory"); }
-  size_t size = (size_t)st.st_size, got = 0;
+  // a regular file is read in one sweep of the size fstat reports; a FIFO, a process substitution or a procfs path reports
+  // size 0 and is read until end of file instead (it used to come back as a silently empty genome)
+  const bool regular = S_ISREG(st.st_mode);
+  size_t size = regular ? (size_t)st.st_size : (size_t)(1u << 20), got = 0;
+  // the buffer of a pool thread is reused from file to file; one that has grown beyond 256 MB (a multi-gigabase assembly) is
+  // given back before the next file, so that two dozen workers do not each pin the largest file they ever read
+  if (buf.capacity() > ((size_t)256 << 20) && size + 64 < buf.capacity() / 2) { std::vector<char>().swap(buf); }
   if (buf.size() < size + 64) buf.resize(std::max(size + 64, buf.size() + buf.size() / 2));
-  while (got < size) {
+  for (;;) {
+    if (got == size) {
+      if (regular) break;
+      size *= 2;                                                    // (not a regular file: keep reading until read() returns 0)
+      buf.resize(size + 64);
+    }
     const ssize_t r = ::read(fd, buf.data() + got, size - got);
     if (r < 0) { if (errno == EINTR) continue; const int e = errno; ::close(fd); throw Error(FA_ERR_IO, std::string(path) + ": read: " + strerror(e)); }
     if (r == 0) break;                                              // (shorter than fstat said: take what there is)

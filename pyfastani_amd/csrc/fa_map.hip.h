@@ -33,6 +33,9 @@ constexpr int MAP_THREADS = 256;
 // 3 KB of stage instead of 6 the kernel's 21.7 KB let seven workgroups share a CU, i.e. the 1666 fragments of a 5 Mb query run
 // in ONE resident round (85 -> 81 us; 928 -> 872 us at 16 queries per launch); a fragment has one locus per related contig
 constexpr int L1_STAGE = 128;
+// the size classes of k_l1 (hits of a fragment): up to 16 per thread of the 256-thread form; up to the slots the 512-thread,
+// 16-per-thread form is given (a kilobyte short of 16 x 512: see Part::L1Class); everything beyond
+constexpr uint32_t L1_SMALL_HITS = 16u * 256u, L1_MID_HITS = 16u * 512u - 256u;
 constexpr uint32_t SEED_PAD = 0xFFFFFFFFu;
 
 // ----------------------------------------------------------------------------------------------------------
@@ -589,16 +592,18 @@ __device__ __forceinline__ void seed_totals(const uint32_t *n_seeds, int64_t F, 
                                             uint32_t *ovf_off, int32_t *stats, int32_t spec_smax,
                                             uint64_t spec_scratch_words, unsigned long long *pinfo, const int32_t *q_size) {
   __shared__ unsigned long long sh_sum;
-  __shared__ unsigned int sh_max, sh_any;
+  __shared__ unsigned int sh_max, sh_any, sh_small, sh_mid;
   __shared__ int sh_smax, sh_qf;
-  if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; sh_smax = 0; sh_qf = 0; }
+  if (threadIdx.x == 0) { sh_sum = 0; sh_max = 0; sh_any = 0; sh_smax = 0; sh_qf = 0; sh_small = 0; sh_mid = 0; }
   __syncthreads();
   unsigned long long sum = 0;
   unsigned int mx = 0, any = 0;
   int smx = 0, qf = 0;
+  unsigned int c_small = 0, c_mid = 0;                                 // fragments per size class of k_l1 (L1_SMALL_HITS, L1_MID_HITS)
   for (int64_t f = threadIdx.x; f < F; f += blockDim.x) {
     const uint32_t n = n_seeds[f];
     sum += n; mx = max(mx, n); any |= n > lds_seed_cap;
+    c_small += n <= L1_SMALL_HITS ? 1u : 0u; c_mid += (n > L1_SMALL_HITS && n <= L1_MID_HITS) ? 1u : 0u;
     ovf_off[f] = 0;
     const int s = q_size[f];
     smx = max(smx, s); qf |= s < 0 ? 1 : 0;
@@ -606,8 +611,12 @@ __device__ __forceinline__ void seed_totals(const uint32_t *n_seeds, int64_t F, 
   for (int d = 32; d > 0; d >>= 1) {
     sum += __shfl_down(sum, d); mx = max(mx, (unsigned int)__shfl_down((int)mx, d)); any |= (unsigned int)__shfl_down((int)any, d);
     smx = max(smx, __shfl_down(smx, d)); qf |= __shfl_down(qf, d);
+    c_small += (unsigned int)__shfl_down((int)c_small, d); c_mid += (unsigned int)__shfl_down((int)c_mid, d);
   }
-  if ((threadIdx.x & 63) == 0) { atomicAdd(&sh_sum, sum); atomicMax(&sh_max, mx); atomicOr(&sh_any, any); atomicMax(&sh_smax, smx); atomicOr(&sh_qf, qf); }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&sh_sum, sum); atomicMax(&sh_max, mx); atomicOr(&sh_any, any); atomicMax(&sh_smax, smx); atomicOr(&sh_qf, qf);
+    atomicAdd(&sh_small, c_small); atomicAdd(&sh_mid, c_mid);
+  }
   __syncthreads();
   // scratch of the oversized fragments, in fragment order: exclusive prefix sum of their padded sizes
   __shared__ unsigned long long sh_words, sh_wave[16];
@@ -638,6 +647,7 @@ __device__ __forceinline__ void seed_totals(const uint32_t *n_seeds, int64_t F, 
     totals[2] = words;
     unsigned long long flags = 0;
     stats[0] = sh_smax;
+    stats[1] = (int32_t)sh_small; stats[2] = (int32_t)sh_mid;         // (what the host merges thin size classes of k_l1 by)
     if (sh_smax > spec_smax) flags |= SPEC_SMAX;
     if (sh_qf) flags |= SPEC_QFUSE;
     if (words > spec_scratch_words || words >= (1ULL << 32)) flags |= SPEC_SCRATCH;
@@ -706,6 +716,13 @@ struct L1Args {
   uint64_t scratch_words;        // capacity of ovf_buf
   int32_t qcap, frag_len, l_cap;
   uint32_t lds_seed_cap;
+  // k_l1 is launched once per SIZE CLASS of fragments (round 6): this launch takes the fragments with n_lo <= hits <= n_hi and
+  // leaves the others alone.  One launch sized for the largest fragment of the pass put every fragment of a genome-like
+  // workload -- where 3 % of the fragments touch a repeat and collect tens of thousands of hits -- through the 512-thread,
+  // 32-hits-per-thread form at two workgroups per CU: 15.2 ms of lookup + L1 per step where the i.i.d. cell of the same shape
+  // takes 5.1 (profiles/r06_genome_like_*).  totals_seed_cap: the slots of the LAST class -- what `seed_totals` (folded into
+  // the first launch) and k_l1_big mean by "more hits than LDS holds".
+  uint32_t n_lo, n_hi, totals_seed_cap;
   unsigned long long *dbg;       // [8] FA_L1_STATS=1: ticks of the phases of k_l1
   int32_t block_sort;            // k_l1: bit 0 = try l1_block_sort before the merge (FA_L1_BLOCK_SORT=0 switches it off), bit 1 = count the roads taken,
                                  // bit 2 = skip the coordinate fetch of hits that cannot be an end of a candidate (FA_L1_NEAR=0: off)
@@ -825,18 +842,9 @@ __device__ __forceinline__ void bs_sizes(uint32_t (&k)[KPL], uint32_t pos0, bool
 }
 
 constexpr uint32_t BS_MAX_PROBES = 48;
-// (FA_EXPERIMENTS builds, FA_L1_PREFILTER=1 -- written at the end of round 5 and NOT yet run on a GPU: the pre-filter of
-//  profiles/EXPERIMENTS.md, "Design note for the block pre-filter", form (b).  A first sweep over the hits marks, per hit and for two
-//  staggered grids of cells twice a fragment length of records wide, "seen once" / "seen twice" bits over a hash of the cell number;
-//  the second sweep inserts only hits with a "seen twice" cell and counts them: `n_live` replaces n for everything behind the sort.
-//  tests/test_l1_prefilter_model.py holds the argument that this changes no candidate region.)
 template <int NT, int SPT, int KPL>
 __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n, uint32_t cap, uint32_t *A, const uint32_t *off, const uint32_t *qo,
-                                              uint32_t *Kk, uint32_t kl
-#ifdef FA_EXPERIMENTS
-                                              , uint32_t &n_live, int frag_len
-#endif
-                                              ) {
+                                              uint32_t *Kk, uint32_t kl) {
   __shared__ uint32_t bs_fail;
   __shared__ uint32_t bs_wsum[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -852,88 +860,7 @@ __device__ __forceinline__ bool l1_block_sort(const L1Args &a, int s, uint32_t n
   };
   for (uint32_t i = tid; i < capT; i += NT) { Tb[i] = 0ULL; Tk[i] = 0u; }
   if (tid == 0) bs_fail = 0;
-#ifdef FA_EXPERIMENTS
-  __shared__ uint32_t bs_live;
-  constexpr uint32_t PF_WORDS = 768, PF_BITS = PF_WORDS * 32;           // two arrays: 6 144 bytes, the locus-stage part of the region behind the table
-  const bool prefilter = (a.block_sort & 8) && kl >= 2u * PF_WORDS + 2u * (uint32_t)(a.lut_smax + 2) && frag_len > 0;
-  uint32_t *B1 = Kk + (kl - 2u * PF_WORDS), *B2 = B1 + PF_WORDS;
-  int cell_shift = 1;                                                    // cells of 2^cell_shift records, 2^(cell_shift - 1) >= frag_len
-  while ((1 << (cell_shift - 1)) < frag_len && cell_shift < 30) cell_shift++;
-  auto cell_bit = [&](uint32_t r, uint32_t g) __attribute__((always_inline)) {
-    const uint32_t c = (((r + (g << (cell_shift - 1))) >> cell_shift) << 1) | g;
-    return __umulhi(c * 0x9E3779B1u, PF_BITS);
-  };
-  n_live = n;
-  if (prefilter) {
-    for (uint32_t i = tid; i < 2u * PF_WORDS; i += NT) B1[i] = 0u;
-    if (tid == 0) bs_live = 0;
-  }
-#endif
   __syncthreads();
-#ifdef FA_EXPERIMENTS
-  if (prefilter) {
-    // the loop of step 1 below, twice: marks, then insertions of the live hits
-    constexpr int IB = 8;
-    uint32_t top = 1;
-    while (top * 2u < (uint32_t)s) top <<= 1;
-    if (s < 2) top = 0;
-    auto place = [&](uint32_t r) __attribute__((always_inline)) {
-      const uint32_t key1 = (r >> 6) + 1u;
-      const unsigned long long bit = 1ULL << (r & 63u);
-      uint32_t h = slot_of(r >> 6);
-      for (uint32_t probes = 0;; probes++) {
-        const uint32_t old = atomicCAS(&Tk[h], 0u, key1);
-        if (old == 0u || old == key1) { atomicOr(&Tb[h], bit); break; }
-        if (probes >= BS_MAX_PROBES) { bs_fail = 1; break; }
-        h = next_slot(h);
-      }
-    };
-    uint32_t mine_live = 0;
-#pragma unroll 1
-    for (int sweep = 0; sweep < 2; sweep++) {
-      for (uint32_t i0 = tid; i0 < n; i0 += IB * NT) {
-        uint32_t jj[IB], r[IB];
-#pragma unroll
-        for (int u = 0; u < IB; u++) jj[u] = 0;
-        for (uint32_t step = top; step; step >>= 1) {
-          uint32_t v[IB];
-#pragma unroll
-          for (int u = 0; u < IB; u++) v[u] = off[min(jj[u] + step, (uint32_t)s)];
-#pragma unroll
-          for (int u = 0; u < IB; u++) jj[u] += v[u] <= i0 + (uint32_t)u * NT ? step : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < IB; u++) {
-          const uint32_t i = i0 + (uint32_t)u * NT;
-          r[u] = i < n ? a.ix.pos_ridx[qo[jj[u]] + (i - off[jj[u]])] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < IB; u++) {
-          if (i0 + (uint32_t)u * NT >= n) continue;
-          const uint32_t b0 = cell_bit(r[u], 0u), b1 = cell_bit(r[u], 1u);
-          if (sweep == 0) {
-            const uint32_t o0 = atomicOr(&B1[b0 >> 5], 1u << (b0 & 31u));
-            if (o0 & (1u << (b0 & 31u))) atomicOr(&B2[b0 >> 5], 1u << (b0 & 31u));
-            const uint32_t o1 = atomicOr(&B1[b1 >> 5], 1u << (b1 & 31u));
-            if (o1 & (1u << (b1 & 31u))) atomicOr(&B2[b1 >> 5], 1u << (b1 & 31u));
-          } else if (((B2[b0 >> 5] >> (b0 & 31u)) | (B2[b1 >> 5] >> (b1 & 31u))) & 1u) {
-            place(r[u]);
-            mine_live++;
-          }
-        }
-        if (sweep == 1 && *(volatile uint32_t *)&bs_fail) break;
-      }
-      __syncthreads();
-    }
-    {
-      const uint32_t incl = wave_incl_scan(mine_live);
-      if (lane == 63 && incl) atomicAdd(&bs_live, incl);
-    }
-    __syncthreads();
-    n_live = bs_live;
-    n = n_live;                                                          // (everything below counts the live hits)
-  } else
-#endif
   // ---- 1. the hits, flat: hit i of the fragment is entry i - off[j] of list j (off = prefix sums of the list lengths, qo = where
   //      every list starts in the index; the caller left both in LDS).  Eight hits per thread and trip, so that eight index
   //      reads are in flight: the workgroup's time is a chain of memory round trips, not instructions ----
@@ -1101,7 +1028,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   if (a.fold_totals) {
     stage_stamp(a.stamp);
     if ((int64_t)blockIdx.x == a.F) {
-      seed_totals(a.n_seeds, a.F, a.lds_seed_cap, a.totals, a.ovf_off, a.stats, a.spec_smax, a.spec_scratch_words, a.pinfo, a.q_size);
+      seed_totals(a.n_seeds, a.F, a.totals_seed_cap, a.totals, a.ovf_off, a.stats, a.spec_smax, a.spec_scratch_words, a.pinfo, a.q_size);
       return;
     }
   }
@@ -1115,11 +1042,8 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
   __shared__ uint32_t sh_base, sh_gbase;
   const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int s = a.q_size[f];
-#ifdef FA_EXPERIMENTS
-  uint32_t n = a.n_seeds[f];                     // (FA_L1_PREFILTER: the live hits once the block sort has dropped the dead ones)
-#else
   const uint32_t n = a.n_seeds[f];
-#endif
+  if (n < a.n_lo || n > a.n_hi) return;          // a fragment of another size class: another launch of this pass takes it
   if (a.big_enabled && a.big_state[f]) return;   // more hits than LDS holds: cut into chunks by k_l1_big, which ran before
   if (tid == 0) { a.f_loci_lo[f] = 0; a.f_loci_n[f] = 0; }
   if (s == 0 || n == 0) return;
@@ -1169,13 +1093,7 @@ __global__ __launch_bounds__(NT, (E == 16 ? 8 : 4)) void k_l1(L1Args a) {
     bool block_sorted = false;
     if ((a.block_sort & 1) && cap >= 1024u) {
       const uint32_t kl = (uint32_t)((l1_lds_bytes(cap, a.lut_smax, NT) - l1_off_offset(cap)) / 4);
-#ifdef FA_EXPERIMENTS
-      uint32_t n_live = n;
-      block_sorted = l1_block_sort<NT, E / 2, 4>(a, s, n, cap, A, off, qo, off, kl, n_live, a.frag_len);
-      if (block_sorted) n = n_live;
-#else
       block_sorted = l1_block_sort<NT, E / 2, 4>(a, s, n, cap, A, off, qo, off, kl);
-#endif
       if (!block_sorted) list_offsets();                                // (the key buffer may have overwritten them)
     }
     if (l1_dbg) atomicAdd(&a.counters[block_sorted ? 5 : 6], 1u);   // FA_L1_STATS=1: which road the fragments took
