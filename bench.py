@@ -1183,7 +1183,7 @@ def strong_scaling(ctx):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": config, "roofline": r["roofline"], "phases_ms": r["phases_ms_rank0"],
-        "repeated_attempts_per_step": r["repeated_attempts_per_step"],
+        "repeated_attempts_per_step": r["repeated_attempts_per_step"], "off_fast_path_share_rank0": r["off_fast_path_share_rank0"],
         **({"fasta_to_table": r["fasta_to_table"]} if "fasta_to_table" in r else {}),
         "rccl_ranks": ctx["dist"].get_world_size() if ctx["dist_on"] else 1,
         "backend": (ctx["dist"].get_backend() + (" (ranks share cuda:0: FA_BENCH_SHARE_GPU=1)" if ctx["share_gpu"] else " (RCCL over xGMI)")) if ctx["dist_on"] else "none (one rank)",

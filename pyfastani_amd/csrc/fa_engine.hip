@@ -1056,7 +1056,7 @@ struct QueryPass {
     if (lds_ev > 64 * 1024) return 0;
     int n_scan = 0, n_ev = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_scan, (const void *)k_l2_scan<uint16_t, uint8_t, 64>, L2_THREADS, lds_scan) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_ev, (const void *)k_l2_events<uint16_t, true>, EV_THREADS, lds_ev) != hipSuccess) {
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n_ev, (const void *)k_l2_events<uint16_t, true, 1>, EV_THREADS, lds_ev) != hipSuccess) {
       (void)hipGetLastError();
       return 0;
     }
@@ -1229,16 +1229,24 @@ struct QueryPass {
             p.l1[p.n_l1++] = Part::L1Class{512, std::min<uint32_t>(need, (uint32_t)(L1_INPLACE_MAX * 512)), m_slots + 1u, 0xFFFFFFFFu};
         }
       }
-      // a class that held under a twentieth of the fragments of the last accepted part is not worth a launch of its own (a launch
-      // walks every fragment: 1.7 million workgroups that return at once cost config 3 two milliseconds): its fragments go to the
-      // next class up, whose form handles fewer hits as well.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
-      static const float thin = getenv("FA_L1_THIN_CLASS") ? (float)atof(getenv("FA_L1_THIN_CLASS")) : 0.05f;
-      if (p.n_l1 == 3 && sp.l1_mid_share >= 0.0f && sp.l1_mid_share < thin) { p.l1[2].n_lo = p.l1[1].n_lo; p.l1[1] = p.l1[2]; p.n_l1 = 2; }
-      if (p.n_l1 >= 2 && sp.l1_small_share >= 0.0f && sp.l1_small_share < thin) {
+      // A class is only worth a launch of its own if the fragments it takes off the next form up gain more than the launch costs
+      // (a launch walks every fragment: 1.7 million workgroups that return at once cost config 3 two milliseconds of 67).  The
+      // 512-thread form with 16 hits per thread handles small fragments nearly as well as the 256-thread one, so the small class
+      // is kept only when it holds a good third of the fragments of the last accepted part; the 32-hits-per-thread form runs two
+      // workgroups per CU and is three times slower per fragment, so the middle class is kept from a twentieth on.  A merged
+      // class's fragments go to the next class up.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
+      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : 0.35f;
+      static const float thin_mid = getenv("FA_L1_THIN_MID") ? (float)atof(getenv("FA_L1_THIN_MID")) : 0.05f;
+      if (p.n_l1 == 3 && sp.l1_mid_share >= 0.0f && sp.l1_mid_share < thin_mid) { p.l1[2].n_lo = p.l1[1].n_lo; p.l1[1] = p.l1[2]; p.n_l1 = 2; }
+      if (p.n_l1 == 2 && p.l1[1].slots <= L1_MID_HITS && sp.l1_small_share >= 0.0f && sp.l1_small_share < thin_small) {
+        p.l1[1].n_lo = 0u; p.l1[0] = p.l1[1]; p.n_l1 = 1;         // (small into the middle form; never into the 32-per-thread form)
+      } else if (p.n_l1 >= 2 && sp.l1_small_share >= 0.0f && sp.l1_small_share < thin_mid) {
         p.l1[1].n_lo = 0u;
         for (int c = 1; c < p.n_l1; c++) p.l1[c - 1] = p.l1[c];
         p.n_l1--;
       }
+      static const bool dbg_l1 = getenv("FA_DEBUG_L1") != nullptr;
+      if (dbg_l1) fprintf(stderr, "k_l1 classes: need=%u small_share=%.3f mid_share=%.3f -> %d launch(es)\n", need, sp.l1_small_share, sp.l1_mid_share, p.n_l1);
       p.seed_slots = p.l1[p.n_l1 - 1].slots;                       // "fits LDS" for seed_totals and k_l1_big: the last class's slots
     }
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
@@ -1467,6 +1475,9 @@ struct QueryPass {
       const size_t lds8 = scan_lds(lanes8, 1) + scan_pad, lds16 = scan_lds(lanes16, 2);
       // (workgroup b of a scan takes chunk b / n of region b mod n: every region needs its chunks, however few loci it can hold)
       auto scan_grid = [&](int lanes) { return (unsigned)(p.loci.n * (uint32_t)ceil_div((int64_t)1 << p.loci.shift, lanes)); };
+      // the rank structure of k_l2_events (its template parameter RK): 1 = occupancy words (round 6), FA_EV_RANK=0 = the bucket
+      // table + four-entry probe of rounds 2-5 (kept for the A/B and for the unpacked record layout)
+      static const bool ev_rank_occ = !(getenv("FA_EV_RANK") && atoi(getenv("FA_EV_RANK")) == 0);
       auto launch = [&](auto ev_kernel, auto scan8, auto scan8_rt, auto scan16, auto scan16_rt) {
         if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
         hipLaunchKernelGGL(ev_kernel, dim3(ev_grid), dim3(EV_THREADS), ev_lds, st, a);
@@ -1549,11 +1560,13 @@ struct QueryPass {
         w.last_ms[14] = (float)smax; w.last_ms[15] = (float)fu_c;
 #endif
       } else if (wide) {
-        if (pk) launch(k_l2_events<uint32_t, true>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
-        else launch(k_l2_events<uint32_t, false>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+        if (pk && ev_rank_occ) launch(k_l2_events<uint32_t, true, 1>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+        else if (pk) launch(k_l2_events<uint32_t, true, 0>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
+        else launch(k_l2_events<uint32_t, false, 0>, k_l2_scan<uint32_t, uint8_t, 64>, k_l2_scan<uint32_t, uint8_t, 0>, k_l2_scan<uint32_t, uint16_t, 64>, k_l2_scan<uint32_t, uint16_t, 0>);
       } else {
-        if (pk) launch(k_l2_events<uint16_t, true>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
-        else launch(k_l2_events<uint16_t, false>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+        if (pk && ev_rank_occ) launch(k_l2_events<uint16_t, true, 1>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+        else if (pk) launch(k_l2_events<uint16_t, true, 0>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
+        else launch(k_l2_events<uint16_t, false, 0>, k_l2_scan<uint16_t, uint8_t, 64>, k_l2_scan<uint16_t, uint8_t, 0>, k_l2_scan<uint16_t, uint16_t, 64>, k_l2_scan<uint16_t, uint16_t, 0>);
       }
     }
     debug_sync(st, "l2 scan");

@@ -1950,13 +1950,25 @@ constexpr int EV_RPL = FA_EV_RPL;          // records per lane and trip of k_l2_
 static_assert(EV_RPL >= 1 && EV_RPL <= 4, "the last trip of a phase is dispatched on 1..4 records per lane");
 __host__ __device__ inline size_t ev_sketch_bytes(int cnt_slots) { return ((size_t)(cnt_slots - 1 + EV_PROBE) * 4 + 15) / 16 * 16; }   // + sentinels
 
-template <typename T, bool PACKED>
+// RK = the rank structure (round 6).  0: the bucket table above + EV_PROBE sketch entries per look-up (rounds 2-5: one table read,
+// four sketch reads, four compare-and-adds, a read of the entry at the final rank: seven LDS instructions with the store).
+// 1: an OCCUPANCY word per bucket -- 2^EV_OCC_BITS buckets of 64 sub-buckets over the same hash range, i.e. 16 times the resolution
+// in about the same LDS: OCC[b] bit j = some sketch hash falls into sub-bucket j of bucket b, R0[b] = sketch entries below
+// bucket b.  The rank of a reference hash is R0[b] + popcount(OCC[b] below its sub-bucket), exact unless a sketch hash shares its
+// sub-bucket: the TWO sketch entries from that rank on (one ds_read2) settle that case and the membership test in the same
+// step; only a hash with two sketch entries of its own sub-bucket below it walks on.  Four LDS instructions per record.
+constexpr int EV_OCC_BITS = 10;
+template <typename T, bool PACKED, int RK>
 __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2Args a) {
   extern __shared__ __align__(16) unsigned char lds[];
   stage_stamp(a.stamp);
   uint32_t *Q = (uint32_t *)lds;                                     // [s + EV_PROBE], staged once per fragment, with sentinels
-  constexpr int QT_BITS = EV_QT_BITS;
-  __shared__ uint16_t QT[(1 << QT_BITS) + 2];
+  constexpr int QT_BITS = RK ? EV_OCC_BITS + 6 : EV_QT_BITS;         // resolution of the table over the hash range, in bits
+  constexpr int OCC_N = (1 << EV_OCC_BITS) + 1;                      // (+ the bucket behind the range: rank s, nothing occupied)
+  __shared__ __align__(8) unsigned char rank_table[RK ? OCC_N * 8 + (OCC_N + 1) * 2 : ((1 << EV_QT_BITS) + 2) * 2];
+  uint16_t *const QT = (uint16_t *)rank_table;                       // RK == 0
+  unsigned long long *const OCC = (unsigned long long *)rank_table;  // RK == 1
+  uint16_t *const R0 = (uint16_t *)(rank_table + OCC_N * 8);
   const int f = a.frag_order ? a.frag_order[blockIdx.x] : (int)blockIdx.x;
   if (f < 0) return;
   const uint32_t l_lo = a.f_loci_lo[f], l_n = a.f_loci_n[f];
@@ -1965,7 +1977,8 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (a.counters[2] || s > a.cnt_slots - 1) return;                  // loci overflowed / sketch larger than speculated: void pass
   for (int i = threadIdx.x; i < s + EV_PROBE; i += EV_THREADS) Q[i] = i < s ? a.q_hash[(size_t)f * a.qcap + i] : 0xFFFFFFFFu;
-  for (int b = threadIdx.x; b <= (1 << QT_BITS) + 1; b += EV_THREADS) QT[b] = (uint16_t)s;
+  if constexpr (RK) { for (int b = threadIdx.x; b < OCC_N; b += EV_THREADS) { OCC[b] = 0ULL; R0[b] = (uint16_t)s; } }
+  else { for (int b = threadIdx.x; b <= (1 << QT_BITS) + 1; b += EV_THREADS) QT[b] = (uint16_t)s; }
   // ---- record range of every locus (the three searchIndex calls of computeL2MappedRegions) and its event count ----
   __shared__ uint32_t sh_wave[EV_THREADS / 64];
   __shared__ uint32_t sh_run, sh_base, sh_ok;
@@ -2034,8 +2047,15 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   const uint32_t hmax = s > 0 ? Q[s - 1] : 0u;
   const int qshift = max(0, (32 - __clz((int)(hmax | 1u))) - QT_BITS);   // hmax < 2^(qshift + QT_BITS)
   for (int i = threadIdx.x; i < s; i += EV_THREADS) {
-    const int bi = (int)(Q[i] >> qshift), bp = i ? (int)(Q[i - 1] >> qshift) : -1;
-    for (int b = bp + 1; b <= bi; b++) QT[b] = (uint16_t)i;
+    if constexpr (RK) {
+      const uint32_t sb = Q[i] >> qshift;                            // sub-bucket of sketch entry i (< 2^QT_BITS: hmax fits)
+      atomicOr(&OCC[sb >> 6], 1ULL << (sb & 63u));
+      const int bi = (int)(sb >> 6), bp = i ? (int)(Q[i - 1] >> qshift >> 6) : -1;
+      for (int b = bp + 1; b <= bi; b++) R0[b] = (uint16_t)i;         // first rank at or behind the start of bucket b
+    } else {
+      const int bi = (int)(Q[i] >> qshift), bp = i ? (int)(Q[i - 1] >> qshift) : -1;
+      for (int b = bp + 1; b <= bi; b++) QT[b] = (uint16_t)i;
+    }
   }
   __syncthreads();
   if (!sh_ok) {                                                      // the event buffer is too small: void pass
@@ -2101,7 +2121,36 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     // (membership is read off the entry AT the final rank -- the sketch is sorted and distinct, so that entry is the first
     // one >= the hash: one more LDS read instead of four equality tests whose results, kept as booleans across the walk,
     // the compiler packed into bytes at ten instructions per record)
-    int x[R]; uint32_t q[R][EV_PROBE], qx[R]; bool found[R], more = false;
+    int x[R]; bool found[R];
+    if constexpr (RK) {
+      unsigned long long occ[R]; uint32_t r0[R], q0[R], q1[R]; bool more = false;
+#pragma unroll
+      for (int u = 0; u < R; u++) {
+        const uint32_t b = min(t.h[u] >> (qshift + 6), (uint32_t)(1 << EV_OCC_BITS));   // the bucket behind the range: rank s
+        occ[u] = OCC[b]; r0[u] = R0[b];
+      }
+#pragma unroll
+      for (int u = 0; u < R; u++) {
+        // sketch entries of the bucket in sub-buckets BELOW the hash's own: shift its own bit to the top, count, take it off
+        const unsigned long long top = occ[u] << (63u - ((t.h[u] >> qshift) & 63u));
+        x[u] = (int)(r0[u] + (uint32_t)__popcll(top) - (uint32_t)(top >> 63));
+      }
+#pragma unroll
+      for (int u = 0; u < R; u++) { q0[u] = Q[x[u]]; q1[u] = Q[x[u] + 1]; }   // (one ds_read2_b32)
+#pragma unroll
+      for (int u = 0; u < R; u++) {
+        // the sketch is sorted and distinct: the hash ranks behind q0 if q0 is smaller, and is a sketch hash iff it equals the
+        // entry at its rank -- q0, or q1 when q0 is smaller
+        found[u] = q0[u] == t.h[u] || q1[u] == t.h[u];
+        x[u] += q0[u] < t.h[u] ? 1 : 0;
+        more = more || q1[u] < t.h[u];
+      }
+      if (__builtin_amdgcn_ballot_w64(more)) {                       // two sketch entries of its own sub-bucket below it: walk on
+#pragma unroll
+        for (int u = 0; u < R; u++) if (q1[u] < t.h[u]) { x[u]++; while (Q[x[u]] < t.h[u]) x[u]++; found[u] = Q[x[u]] == t.h[u]; }
+      }
+    } else {
+    uint32_t q[R][EV_PROBE], qx[R]; bool more = false;
 #pragma unroll
     for (int u = 0; u < R; u++) x[u] = QT[min(t.h[u] >> qshift, (uint32_t)(1 << QT_BITS))];   // the last bucket is [2^bits, inf): rank s
 #pragma unroll
@@ -2123,6 +2172,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     for (int u = 0; u < R; u++) qx[u] = Q[x[u]];
 #pragma unroll
     for (int u = 0; u < R; u++) found[u] = qx[u] == t.h[u];
+    }
     if constexpr (PACKED) {
       // Bit arithmetic instead of compare + select: this kernel runs seven waves per SIMD and IS its vector issue slots
       // (profiles/r03_valu_model.json), where v_and / v_or / v_add / v_sub / v_lshrrev cost 2.3 cycles and v_cmp, v_cndmask,

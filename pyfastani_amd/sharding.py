@@ -41,15 +41,19 @@ def shard_by_fragments(fragment_counts, world_size):
     """Deal query genomes to ``world_size`` ranks balanced by FRAGMENT count (a fragment is the unit of work
     of the path, _fastani.pyx:1099-1102, and draft assemblies differ in size), not by genome count.
 
-    Longest-processing-time rule: genomes in descending fragment count (ties by index) each go to the rank with the
-    fewest fragments so far (ties to the lowest rank).  Deterministic, so every rank computes the same partition without
-    a collective; each rank's list is returned in ascending genome order.  The maximum load exceeds the mean by less
-    than one genome."""
+    Longest-processing-time rule: genomes in descending fragment count each go to the rank with the fewest fragments so
+    far (ties to the lowest rank).  Genomes of EQUAL fragment count are taken in a fixed pseudo-random order of their
+    indices, not in index order: with equal counts the rule deals round-robin, and workloads list their genomes in a
+    regular pattern (config 3: the divergence of member m of a family is DIVERGENCES[m mod 6]), so a strided deal gave the
+    even ranks the close relatives and the odd ranks the distant ones -- equal fragments, 7 % apart in time
+    (profiles/r06_scale_model.json).  Deterministic, so every rank computes the same partition without a collective; each
+    rank's list is returned in ascending genome order.  The maximum load exceeds the mean by less than one genome."""
     import heapq
     w = [int(x) for x in fragment_counts]
     heap = [(0, r) for r in range(world_size)]
     owned = [[] for _ in range(world_size)]
-    for i in sorted(range(len(w)), key=lambda i: (-w[i], i)):
+    mix = lambda i: ((i + 1) * 0x9E3779B1) & 0xFFFFFFFF              # noqa: E731  (a fixed permutation of the indices)
+    for i in sorted(range(len(w)), key=lambda i: (-w[i], mix(i), i)):
         load, r = heapq.heappop(heap)
         owned[r].append(i)
         heapq.heappush(heap, (load + w[i], r))
