@@ -406,6 +406,7 @@ struct fa_genomes {
   int32_t n_genomes = 0;
   std::vector<int64_t> genome_frag_lo;      // [n_genomes + 1] fragment range of each genome
   std::vector<int32_t> frag_tile_lo;        // [F + 1]
+  std::vector<int64_t> contig_frag_lo;      // first fragment of every contig that holds fragments (ascending)
   std::vector<uint64_t> total_fragments, total_length;
   std::vector<int32_t> n_short;
   int64_t F = 0, ntiles = 0;
@@ -568,7 +569,7 @@ struct fa_mapper {
     int fuse_skip = 0, fuse_penalty = 0;
     int smax_misses = 0;      // times the largest sketch outgrew the bound (the first growth is tight, later ones are not)
     // share of the fragments of the last accepted part in the two lower size classes of k_l1 (-1: not seen yet)
-    float l1_small_share = -1.0f, l1_mid_share = -1.0f;
+    float l1_small_share = -1.0f, l1_mid_share = -1.0f, l1_tiny_share = -1.0f;   // (tiny: up to half the small class's bound)
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
   // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
@@ -1040,7 +1041,7 @@ struct QueryPass {
     ms.l_cap = std::max(ms.l_cap, sp.l_cap);
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
-    ms.l1_small_share = sp.l1_small_share; ms.l1_mid_share = sp.l1_mid_share;
+    ms.l1_small_share = sp.l1_small_share; ms.l1_mid_share = sp.l1_mid_share; ms.l1_tiny_share = sp.l1_tiny_share;
     ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
   }
   // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
@@ -1229,24 +1230,32 @@ struct QueryPass {
             p.l1[p.n_l1++] = Part::L1Class{512, std::min<uint32_t>(need, (uint32_t)(L1_INPLACE_MAX * 512)), m_slots + 1u, 0xFFFFFFFFu};
         }
       }
-      // A class is only worth a launch of its own if the fragments it takes off the next form up gain more than the launch costs
-      // (a launch walks every fragment: 1.7 million workgroups that return at once cost config 3 two milliseconds of 67).  The
-      // 512-thread form with 16 hits per thread handles small fragments nearly as well as the 256-thread one, so the small class
-      // is kept only when it holds a good third of the fragments of the last accepted part; the 32-hits-per-thread form runs two
-      // workgroups per CU and is three times slower per fragment, so the middle class is kept from a twentieth on.  A merged
-      // class's fragments go to the next class up.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
-      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : 0.35f;
+      // Which classes get a launch of their own is decided from the shares `seed_totals` counted in the last accepted part (a launch
+      // walks every fragment: 1.7 million workgroups that return at once cost config 3 two milliseconds of 67).  Measured (round 6,
+      // profiles/EXPERIMENTS.md): fragments of ~1 500 hits -- a genome-like index of 200 genomes -- take 7.5 ms per step in the
+      // 256-thread form and 10.3 in the 512-thread one; fragments of 3 000-4 000 hits -- config 3, nine in ten of them below the
+      // 4 096 bound -- take 69.2 against 67.7: twice the threads halve every thread's chain there.  So the small class is kept
+      // when half the fragments hold at most HALF its bound, else its fragments ride in the middle form; the middle class is kept
+      // from a twentieth of the fragments on (the 32-hits-per-thread form behind it runs two workgroups per CU and is three times
+      // slower per fragment), or to carry the small ones.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
+      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : 0.5f;
       static const float thin_mid = getenv("FA_L1_THIN_MID") ? (float)atof(getenv("FA_L1_THIN_MID")) : 0.05f;
-      if (p.n_l1 == 3 && sp.l1_mid_share >= 0.0f && sp.l1_mid_share < thin_mid) { p.l1[2].n_lo = p.l1[1].n_lo; p.l1[1] = p.l1[2]; p.n_l1 = 2; }
-      if (p.n_l1 == 2 && p.l1[1].slots <= L1_MID_HITS && sp.l1_small_share >= 0.0f && sp.l1_small_share < thin_small) {
-        p.l1[1].n_lo = 0u; p.l1[0] = p.l1[1]; p.n_l1 = 1;         // (small into the middle form; never into the 32-per-thread form)
-      } else if (p.n_l1 >= 2 && sp.l1_small_share >= 0.0f && sp.l1_small_share < thin_mid) {
-        p.l1[1].n_lo = 0u;
-        for (int c = 1; c < p.n_l1; c++) p.l1[c - 1] = p.l1[c];
-        p.n_l1--;
+      if (p.n_l1 >= 2) {
+        // S form for the small fragments, or do they ride in the middle form; the middle class stays if it has fragments of its
+        // own worth a launch, or small ones to carry
+        const bool keep_s = sp.l1_tiny_share < 0.0f || sp.l1_tiny_share >= thin_small;
+        const bool keep_m = !keep_s || p.n_l1 == 2 || sp.l1_mid_share < 0.0f || sp.l1_mid_share >= thin_mid;
+        Part::L1Class c[3];
+        int n = 0;
+        uint32_t lo = 0u;                                            // lower bound of the next class kept
+        if (keep_s) { c[n++] = p.l1[0]; lo = p.l1[0].n_hi + 1u; }
+        if (keep_m) { c[n] = p.l1[1]; c[n].n_lo = lo; lo = p.l1[1].n_hi == 0xFFFFFFFFu ? lo : p.l1[1].n_hi + 1u; n++; }
+        if (p.n_l1 == 3) { c[n] = p.l1[2]; c[n].n_lo = lo; n++; }
+        for (int i = 0; i < n; i++) p.l1[i] = c[i];
+        p.n_l1 = n;
       }
       static const bool dbg_l1 = getenv("FA_DEBUG_L1") != nullptr;
-      if (dbg_l1) fprintf(stderr, "k_l1 classes: need=%u small_share=%.3f mid_share=%.3f -> %d launch(es)\n", need, sp.l1_small_share, sp.l1_mid_share, p.n_l1);
+      if (dbg_l1) fprintf(stderr, "k_l1 classes: need=%u tiny=%.3f small=%.3f mid=%.3f -> %d launch(es)\n", need, sp.l1_tiny_share, sp.l1_small_share, sp.l1_mid_share, p.n_l1);
       p.seed_slots = p.l1[p.n_l1 - 1].slots;                       // "fits LDS" for seed_totals and k_l1_big: the last class's slots
     }
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
@@ -1371,7 +1380,13 @@ struct QueryPass {
       // FA_L1_NEAR = 0 / 1: never / always (the A/B of the HBM fetch: profiles/r05_l1_near_fetch.txt).
       static const int l1_near_env = getenv("FA_L1_NEAR") ? atoi(getenv("FA_L1_NEAR")) : -1;
       const bool l1_near_on = l1_near_env < 0 ? m.N >= 300000000LL : l1_near_env != 0;
-      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0);
+      // The pre-filter of the block sort (l1_block_sort: hits that cannot belong to a candidate are dropped before the sort, one more
+      // sweep over the position lists) pays where chance hits would otherwise push a fragment's blocks beyond what the register
+      // sort holds -- ~2 000 of them per fragment in an index of 1.6 x 10^9 records, ~500 at 4 x 10^8: on from 10^9 records.
+      // FA_L1_PREFILTER = 0 / 1: never / always.
+      static const int l1_pf_env = getenv("FA_L1_PREFILTER") ? atoi(getenv("FA_L1_PREFILTER")) : -1;
+      const bool l1_pf_on = l1_pf_env < 0 ? m.N >= 1000000000LL : l1_pf_env != 0;
+      a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0) | (l1_pf_on ? 8 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
       // fragments with more hits than LDS holds (seen before on this mapper: scratch is reserved for them) are cut
@@ -1693,7 +1708,7 @@ struct QueryPass {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;
     }
-    if (F > 0) { sp.l1_small_share = (float)h_stats[1] / (float)F; sp.l1_mid_share = (float)h_stats[2] / (float)F; }
+    if (F > 0) { sp.l1_small_share = (float)h_stats[1] / (float)F; sp.l1_mid_share = (float)h_stats[2] / (float)F; sp.l1_tiny_share = (float)h_stats[3] / (float)F; }
     publish_spec(sp);
     // ---- accepted ----
     {
@@ -1941,6 +1956,8 @@ static void fill_genomes(fa_genomes *g, const fa_params &P, hipStream_t st, cons
     g->total_bases += (uint64_t)(nfrag * frag);
   }
   g->frag_tile_lo.assign((size_t)F + 1, 0);
+  g->contig_frag_lo.clear();
+  for (const ContigJob &cj : jobs) g->contig_frag_lo.push_back(cj.nf0);
   HostPool::get().parallel_for(jobs.size(), [&](size_t j) {
     const ContigJob &cj = jobs[j];
     for (int64_t i = 0; i < cj.nfrag; i++) {
@@ -2877,10 +2894,16 @@ int fa_bench_sketch_kernel(fa_mapper *m, fa_genomes *g, int repeat, float *ms_pe
           cut.push_back(Tile{run_base, (int32_t)run_len, (int32_t)p0, (int32_t)std::min<int64_t>(tile_len, npos - p0), run_id, 0, 0});
         run_id++; run_base = -1; run_len = 0;
       };
+      // (a run ends where a contig ends, not only where the addresses break: a contig whose whole fragments fill a multiple of
+      // 64 bases is followed by the next one without a gap, and k-mers / windows across that seam are not what reference
+      // sketching hashes)
+      size_t next_contig = 0;
       for (const Tile &t : host) {
         if (t.seq == last_seq) continue;                               // (the other tiles of a fragment seen already)
         last_seq = t.seq;
-        if (run_base >= 0 && t.base == run_base + run_len && run_len + t.seq_len < (1LL << 31)) run_len += t.seq_len;
+        bool starts_contig = false;
+        while (next_contig < g->contig_frag_lo.size() && g->contig_frag_lo[next_contig] <= (int64_t)t.seq) { starts_contig = g->contig_frag_lo[next_contig] == (int64_t)t.seq; next_contig++; }
+        if (!starts_contig && run_base >= 0 && t.base == run_base + run_len && run_len + t.seq_len < (1LL << 31)) run_len += t.seq_len;
         else { close(); run_base = t.base; run_len = t.seq_len; }
       }
       close();

@@ -1699,3 +1699,49 @@ def test_genome_like_all_vs_all_matches_oracle_mapping_for_mapping():
         assert me.identity >= 99.999 and me.fragments - 12 <= me.matches <= me.fragments
         assert all(fam[h.name] == fam[q] for h in hits)
     assert n_maps > 8000 and multi > 50              # (fragments with several loci on one contig: what i.i.d. genomes never produce)
+
+
+def test_handles_released_from_a_thread_that_never_entered_the_library():
+    """A Sketch / Mapper / GenomeBatch may be garbage-collected on ANY thread (a torch worker, a finaliser): the device pool files
+    the blocks under -- and synchronises -- the device that owns them, not the releasing thread's current one (fa_common.h:
+    DevPool::free).  Release everything from a fresh thread, then build and query again: same hits, and the pool handed the
+    blocks out again instead of growing."""
+    import threading
+    from pyfastani_amd._lib import lib as L
+    g = syn.rng(4242)
+    anc = syn.random_codes(g, 200_000)
+    refs = [bytes(syn.to_ascii(syn.mutate_codes(g, anc, d))) for d in (0.02, 0.06)]
+    query = bytes(syn.to_ascii(syn.mutate_codes(g, anc, 0.04)))
+
+    def build():
+        sk = pf.Sketch()
+        for i, r in enumerate(refs):
+            sk.add_genome(i, r)
+        mp = sk.index()
+        return sk, mp, mp.upload_genomes([[query]]), hit_tuples(mp.query_genome(query))
+    box = list(build())
+    want = box.pop()
+    pf.device_trim()
+
+    def release():
+        box.clear()                                   # the last references die here, on this thread
+        import gc
+        gc.collect()
+    t = threading.Thread(target=release)
+    t.start()
+    t.join()
+    held = C.c_uint64(0)
+    check(L.fa_device_trim(C.byref(held)))            # what the pool held = the blocks the thread gave back
+    assert held.value > 0
+    sk, mp, batch, got = build()
+    assert got == want and len(got) == 2
+    import torch
+    if torch.cuda.device_count() >= 2:                # the owning device is NOT the releasing thread's current one
+        pf.set_device(1)
+        box2 = list(build())
+        assert box2.pop() == want
+        t = threading.Thread(target=lambda: (box2.clear(), __import__("gc").collect()))
+        t.start()
+        t.join()
+        assert hit_tuples(build()[1].query_genome(query)) == want
+        pf.set_device(0)
