@@ -834,7 +834,8 @@ def genome_like_leg(ctx):
     if not (r["self_identity_min"] is not None and r["self_identity_min"] >= 99.999 and r["hits_within_family"]):
         raise SystemExit(f"GENOME-LIKE FAILURE: the oracle-free properties do not hold: {r}")
     n = len(genomes)
-    roof = stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"], None, None)
+    roof = stage_roofline(r["l2_records_per_step"], r["phases_ms"]["l2_ms"],
+                          *(profiled_traffic("l2", "genome_like_traffic.json") if (f, m, args.length) == (10, 20, 5_000_000) else (None, None)))
     off = r["off_fast_l1_fragments_per_step"] / max(r["fragments"], 1)
     return {"workload": f"{n} x {n} genome-like all-vs-all ({f} families x {m}) of {args.length / 1e6:g} Mb: 7 x 5 kb + 30 x 1.3 kb repeats (half reversed), 3 low-complexity "
                         f"tracts, 1 % of the mutation events indels of 1-50 bases, one 100 kb inversion; k=16 frag=3000 w={r['window_size']}",

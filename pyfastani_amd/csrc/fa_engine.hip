@@ -570,6 +570,7 @@ struct fa_mapper {
     int smax_misses = 0;      // times the largest sketch outgrew the bound (the first growth is tight, later ones are not)
     // share of the fragments of the last accepted part in the two lower size classes of k_l1 (-1: not seen yet)
     float l1_small_share = -1.0f, l1_mid_share = -1.0f, l1_tiny_share = -1.0f;   // (tiny: up to half the small class's bound)
+    bool l1_prefilter = false;  // an accepted part saw fragments fall off k_l1's block sort: later passes drop dead hits before the sort (sticky)
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
   // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
@@ -1042,6 +1043,7 @@ struct QueryPass {
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
     ms.l1_small_share = sp.l1_small_share; ms.l1_mid_share = sp.l1_mid_share; ms.l1_tiny_share = sp.l1_tiny_share;
+    ms.l1_prefilter = ms.l1_prefilter || sp.l1_prefilter;
     ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
   }
   // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
@@ -1235,10 +1237,10 @@ struct QueryPass {
       // profiles/EXPERIMENTS.md): fragments of ~1 500 hits -- a genome-like index of 200 genomes -- take 7.5 ms per step in the
       // 256-thread form and 10.3 in the 512-thread one; fragments of 3 000-4 000 hits -- config 3, nine in ten of them below the
       // 4 096 bound -- take 69.2 against 67.7: twice the threads halve every thread's chain there.  So the small class is kept
-      // when half the fragments hold at most HALF its bound, else its fragments ride in the middle form; the middle class is kept
+      // when seven in ten fragments hold at most HALF its bound (config 3: 52 %), else its fragments ride in the middle form; the middle class is kept
       // from a twentieth of the fragments on (the 32-hits-per-thread form behind it runs two workgroups per CU and is three times
       // slower per fragment), or to carry the small ones.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
-      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : 0.5f;
+      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : 0.7f;
       static const float thin_mid = getenv("FA_L1_THIN_MID") ? (float)atof(getenv("FA_L1_THIN_MID")) : 0.05f;
       if (p.n_l1 >= 2) {
         // S form for the small fragments, or do they ride in the middle form; the middle class stays if it has fragments of its
@@ -1381,11 +1383,14 @@ struct QueryPass {
       static const int l1_near_env = getenv("FA_L1_NEAR") ? atoi(getenv("FA_L1_NEAR")) : -1;
       const bool l1_near_on = l1_near_env < 0 ? m.N >= 300000000LL : l1_near_env != 0;
       // The pre-filter of the block sort (l1_block_sort: hits that cannot belong to a candidate are dropped before the sort, one more
-      // sweep over the position lists) pays where chance hits would otherwise push a fragment's blocks beyond what the register
-      // sort holds -- ~2 000 of them per fragment in an index of 1.6 x 10^9 records, ~500 at 4 x 10^8: on from 10^9 records.
-      // FA_L1_PREFILTER = 0 / 1: never / always.
+      // sweep over the position lists) pays where chance hits push the blocks of a fragment beyond what the register sort holds, and
+      // costs where they do not (profiles/r06_l1_prefilter.txt: lookup + L1 211 -> 156 ms on 2000 x 2000 genomes, 38.9 -> 20.1 in the
+      // (k = 14, fragment 1000) cell, whose 28-bit hashes collide everywhere, 69.7 -> 67.5 on config 3; 52.8 -> 66.3 us on the
+      // one-query step, 5.4 -> 6.2 ms in the (16, 3000) cell).  So it follows the evidence: on once an accepted part of this mapper
+      // had one fragment in two hundred fall back to the merge (Spec::l1_prefilter, sticky), and from the start on indices of 10^9
+      // records, where nearly every fragment would.  FA_L1_PREFILTER = 0 / 1: never / always.
       static const int l1_pf_env = getenv("FA_L1_PREFILTER") ? atoi(getenv("FA_L1_PREFILTER")) : -1;
-      const bool l1_pf_on = l1_pf_env < 0 ? m.N >= 1000000000LL : l1_pf_env != 0;
+      const bool l1_pf_on = l1_pf_env < 0 ? (m.N >= 1000000000LL || sp.l1_prefilter) : l1_pf_env != 0;
       a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0) | (l1_pf_on ? 8 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
@@ -1709,6 +1714,9 @@ struct QueryPass {
       sp.seed_slots = want_slots;
     }
     if (F > 0) { sp.l1_small_share = (float)h_stats[1] / (float)F; sp.l1_mid_share = (float)h_stats[2] / (float)F; sp.l1_tiny_share = (float)h_stats[3] / (float)F; }
+    // fragments whose hits were too scattered for the block sort (they took the merge, at twice the time): from one in two hundred
+    // on, the passes that follow drop the hits that cannot belong to a candidate before the sort (launch_l1_stage)
+    if (F > 0 && (double)h_counters[0] > 0.005 * (double)F) sp.l1_prefilter = true;
     publish_spec(sp);
     // ---- accepted ----
     {

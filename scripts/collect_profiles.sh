@@ -5,6 +5,7 @@
 #   bash scripts/collect_profiles.sh r03 config3    `saturated.config3`: 1000 x 1000 (bench.py --strong, two steps summed)
 #   bash scripts/collect_profiles.sh r05 config4    `saturated.config4`: 500 x 500 draft assemblies (bench.py --leg config4)
 #   bash scripts/collect_profiles.sh r05 config5:k21f3000   one cell of `config5_cells` (bench.py --leg config5:k21f3000)
+#   bash scripts/collect_profiles.sh r06 genome_like        the genome-like leg (bench.py --leg genome_like)
 # writes gpurun_out/<tag>[_<mode>]_prof/{stats,fetch,write,sq_a,sq_b}/ and the summaries gpurun_out/<tag>[_<mode>]_*.{json,csv};
 # copy the summaries into profiles/ afterwards.  Counters are collected in their own passes (MI355X_MICROARCH.md, HBM /
 # rocprofv3 PMC slots: FETCH_SIZE and WRITE_SIZE do not fit one pass) and never together with a trace domain; the program
@@ -21,6 +22,7 @@ case "$MODE" in
   # (round 5) one leg of the line alone: BASELINE config 4, or one (k, fragment length) cell of config 5 -- `config5:k21f3000`;
   # a leg runs one warm-up step and N timed ones, every launch of every step is summed
   config4) NAME=${TAG}_config4; ARGS="--leg config4";      STATS="--saturated-steps 2";   PMC="--saturated-steps 1"; export FA_PROFILE_SUM_STEPS=2 ;;
+  genome_like) NAME=${TAG}_genome_like; ARGS="--leg genome_like"; STATS="--saturated-steps 2"; PMC="--saturated-steps 1"; export FA_PROFILE_SUM_STEPS=2 ;;
   config5:*) CELL=${MODE#config5:}; NAME=${TAG}_config5_$(echo $CELL | sed 's/k\([0-9]*\)f\([0-9]*\)/k\1_f\2/'); ARGS="--leg $MODE"; STATS=""; PMC=""; export FA_PROFILE_SUM_STEPS=3 ;;
   *) echo "unknown mode $MODE"; exit 2 ;;
 esac

@@ -28,7 +28,8 @@ KERNELS = {
     "k_sketch_fast<14, 0>": ("v_mad_u64_u32", 1, "k-mer position"),
     "k_sketch_fast<21, 0>": ("v_mad_u64_u32", 1, "k-mer position"),
     "k_l2_scan<unsigned short, unsigned char, 64>": ("ds_write_b8", 8, "slide event"),
-    "k_l2_events<unsigned short, true>": ("ds_write_b16", 4, "reference record behind the first window (staged stream)"),
+    "k_l2_events<unsigned short, true, 1>": ("ds_write_b16", 4, "reference record behind the first window (staged stream; occupancy-word ranks)"),
+    "k_l2_events<unsigned short, true, 0>": ("ds_write_b16", 4, "reference record behind the first window (staged stream; rounds 2-5: bucket table + four-entry probe)"),
     "k_l1<256, 16>": ("ds_write_b32", 0, "(merge level; informational)"),
 }
 

@@ -36,7 +36,9 @@ def main():
     # (k_query_fused and k_l1 are priced with the mix of their hot loops -- the hashing loop, the merge level: their other
     # phases are lane exchanges, LDS atomics and scans with a similar share of slow opcodes)
     alias = {"k_sketch_fast<16, 24>": "k_sketch_fast<16, 24>", "k_l2_scan<unsigned short, unsigned char, 64>": "k_l2_scan<unsigned short, unsigned char, 64>",
-             "k_l2_events<unsigned short, true>": "k_l2_events<unsigned short, true>", "k_l1<256, 16>": "k_l1<256, 16>", "k_l1<512, 16>": "k_l1<256, 16>",
+             "k_l2_events<unsigned short, true>": "k_l2_events<unsigned short, true>",
+             "k_l2_events<unsigned short, true, 1>": "k_l2_events<unsigned short, true, 1>", "k_l2_events<unsigned short, true, 0>": "k_l2_events<unsigned short, true, 0>",
+             "k_l1<256, 16>": "k_l1<256, 16>", "k_l1<512, 16>": "k_l1<256, 16>",
              "k_query_fused<16, 24>": "k_query_fused<16, 24>"}
     for regime, fname in (("step", f"{tag}_map_kernels_pmc.json"), ("batch16", f"{tag}_batch16_map_kernels_pmc.json")):
         pmc = load(fname)
@@ -44,7 +46,7 @@ def main():
             continue
         rows = {}
         for k, c in pmc["kernels"].items():
-            if k in alias and c.get("SQ_INSTS_VALU"):
+            if k in alias and alias[k] in slot and c.get("SQ_INSTS_VALU"):
                 n = c["SQ_INSTS_VALU"]
                 rows[k] = {"valu_wave_instructions": n, "mean_slot_cycles": slot[alias[k]],
                            "issue_floor_ms": n * slot[alias[k]] / (SIMDS * CLOCK_MHZ * 1e3)}
