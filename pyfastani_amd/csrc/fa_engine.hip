@@ -1162,6 +1162,7 @@ struct QueryPass {
     struct L1Class { int nt; uint32_t slots, n_lo, n_hi; };   // one launch of k_l1: the fragments with n_lo <= hits <= n_hi
     L1Class l1[3];
     int n_l1 = 0;
+    bool l1_prefilter = false;                                // this part drops dead hits before k_l1's block sort
     uint32_t seed_slots = 0;                                  // slots of the last class
     bool wide = false;
     LociRegions loci{nullptr, 1, 0};          // regions of the locus numbering of this part
@@ -1232,20 +1233,33 @@ struct QueryPass {
             p.l1[p.n_l1++] = Part::L1Class{512, std::min<uint32_t>(need, (uint32_t)(L1_INPLACE_MAX * 512)), m_slots + 1u, 0xFFFFFFFFu};
         }
       }
+      // The pre-filter of the block sort (l1_block_sort: hits that cannot belong to a candidate are dropped before the sort, one more
+      // sweep over the position lists) pays where chance hits push the blocks of a fragment beyond what the register sort holds, and
+      // costs where they do not (profiles/r06_l1_prefilter.txt: lookup + L1 70.4 -> 60.9 ms on config 3, 211 -> 156 on 2000 x 2000
+      // genomes, 38.9 -> 20.1 in the (k = 14, fragment 1000) cell, whose 28-bit hashes collide everywhere; 52.8 -> 66.3 us on the
+      // one-query step, 5.4 -> 6.2 ms in the (16, 3000) cell).  So it follows the evidence: on from 3 x 10^8 index records (~400
+      // chance hits per fragment), and on any index once an accepted part of this mapper had one fragment in two hundred fall back
+      // to the merge (Spec::l1_prefilter, sticky).  FA_L1_PREFILTER = 0 / 1: never / always.
+      static const int l1_pf_env = getenv("FA_L1_PREFILTER") ? atoi(getenv("FA_L1_PREFILTER")) : -1;
+      p.l1_prefilter = l1_pf_env < 0 ? (m.N >= 300000000LL || sp.l1_prefilter) : l1_pf_env != 0;
       // Which classes get a launch of their own is decided from the shares `seed_totals` counted in the last accepted part (a launch
       // walks every fragment: 1.7 million workgroups that return at once cost config 3 two milliseconds of 67).  Measured (round 6,
-      // profiles/EXPERIMENTS.md): fragments of ~1 500 hits -- a genome-like index of 200 genomes -- take 7.5 ms per step in the
-      // 256-thread form and 10.3 in the 512-thread one; fragments of 3 000-4 000 hits -- config 3, nine in ten of them below the
-      // 4 096 bound -- take 69.2 against 67.7: twice the threads halve every thread's chain there.  So the small class is kept
-      // when seven in ten fragments hold at most HALF its bound (config 3: 52 %), else its fragments ride in the middle form; the middle class is kept
-      // from a twentieth of the fragments on (the 32-hits-per-thread form behind it runs two workgroups per CU and is three times
-      // slower per fragment), or to carry the small ones.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
-      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : 0.7f;
+      // profiles/r06_l1_classes_ab.txt, r06_l1_prefilter.txt): fragments of ~1 500 hits -- a genome-like index of 200 genomes --
+      // take 7.5 ms per step in the 256-thread form and 10.3 in the 512-thread one; config 3's fragments of 3 000-4 000 hits, nine in
+      // ten below the 4 096 bound, take 69.2 in the 512-thread form against 70.4 WITHOUT the pre-filter (their ~500 chance hits are
+      // blocks of their own, and the 256-thread form sorts 1 024 blocks at most: what overflows takes the merge) and 60.9 against
+      // 70.2 WITH it.  So: with the pre-filter the small class is kept when it holds a third of the fragments; without, when half
+      // the fragments hold at most HALF its bound.  The middle class is kept from a twentieth of the fragments on (the
+      // 32-hits-per-thread form behind it runs two workgroups per CU and is three times slower per fragment), or to carry the
+      // small ones.  Ranges stay contiguous from 0: a wrong guess costs time, not results.
+      static const float thin_small = getenv("FA_L1_THIN_SMALL") ? (float)atof(getenv("FA_L1_THIN_SMALL")) : -1.0f;
       static const float thin_mid = getenv("FA_L1_THIN_MID") ? (float)atof(getenv("FA_L1_THIN_MID")) : 0.05f;
       if (p.n_l1 >= 2) {
         // S form for the small fragments, or do they ride in the middle form; the middle class stays if it has fragments of its
         // own worth a launch, or small ones to carry
-        const bool keep_s = sp.l1_tiny_share < 0.0f || sp.l1_tiny_share >= thin_small;
+        const bool keep_s = thin_small >= 0.0f ? (sp.l1_small_share < 0.0f || sp.l1_small_share >= thin_small)        // (forced: tests, A/B)
+                            : p.l1_prefilter ? (sp.l1_small_share < 0.0f || sp.l1_small_share >= 0.35f)
+                                             : (sp.l1_tiny_share < 0.0f || sp.l1_tiny_share >= 0.5f);
         const bool keep_m = !keep_s || p.n_l1 == 2 || sp.l1_mid_share < 0.0f || sp.l1_mid_share >= thin_mid;
         Part::L1Class c[3];
         int n = 0;
@@ -1257,7 +1271,7 @@ struct QueryPass {
         p.n_l1 = n;
       }
       static const bool dbg_l1 = getenv("FA_DEBUG_L1") != nullptr;
-      if (dbg_l1) fprintf(stderr, "k_l1 classes: need=%u tiny=%.3f small=%.3f mid=%.3f -> %d launch(es)\n", need, sp.l1_tiny_share, sp.l1_small_share, sp.l1_mid_share, p.n_l1);
+      if (dbg_l1) fprintf(stderr, "k_l1 classes: need=%u tiny=%.3f small=%.3f mid=%.3f prefilter=%d -> %d launch(es)\n", need, sp.l1_tiny_share, sp.l1_small_share, sp.l1_mid_share, (int)p.l1_prefilter, p.n_l1);
       p.seed_slots = p.l1[p.n_l1 - 1].slots;                       // "fits LDS" for seed_totals and k_l1_big: the last class's slots
     }
     ln.l_frag.ensure((size_t)l_cap); ln.l_seq.ensure((size_t)l_cap); ln.l_start.ensure((size_t)l_cap); ln.l_end.ensure((size_t)l_cap + 4);
@@ -1382,15 +1396,7 @@ struct QueryPass {
       // FA_L1_NEAR = 0 / 1: never / always (the A/B of the HBM fetch: profiles/r05_l1_near_fetch.txt).
       static const int l1_near_env = getenv("FA_L1_NEAR") ? atoi(getenv("FA_L1_NEAR")) : -1;
       const bool l1_near_on = l1_near_env < 0 ? m.N >= 300000000LL : l1_near_env != 0;
-      // The pre-filter of the block sort (l1_block_sort: hits that cannot belong to a candidate are dropped before the sort, one more
-      // sweep over the position lists) pays where chance hits push the blocks of a fragment beyond what the register sort holds, and
-      // costs where they do not (profiles/r06_l1_prefilter.txt: lookup + L1 211 -> 156 ms on 2000 x 2000 genomes, 38.9 -> 20.1 in the
-      // (k = 14, fragment 1000) cell, whose 28-bit hashes collide everywhere, 69.7 -> 67.5 on config 3; 52.8 -> 66.3 us on the
-      // one-query step, 5.4 -> 6.2 ms in the (16, 3000) cell).  So it follows the evidence: on once an accepted part of this mapper
-      // had one fragment in two hundred fall back to the merge (Spec::l1_prefilter, sticky), and from the start on indices of 10^9
-      // records, where nearly every fragment would.  FA_L1_PREFILTER = 0 / 1: never / always.
-      static const int l1_pf_env = getenv("FA_L1_PREFILTER") ? atoi(getenv("FA_L1_PREFILTER")) : -1;
-      const bool l1_pf_on = l1_pf_env < 0 ? (m.N >= 1000000000LL || sp.l1_prefilter) : l1_pf_env != 0;
+      const bool l1_pf_on = p.l1_prefilter;             // (decided with the size classes, when the part was planned)
       a.block_sort = (l1_block_sort_on ? 1 : 0) | (l1_stats ? 2 : 0) | (l1_near_on ? 4 : 0) | (l1_pf_on ? 8 : 0);
       const uint32_t l1_grid = (uint32_t)F;             // (the offset-major order of k_l2_events applied here measured nothing: 75.9 / 75.5 ms on config 3)
       a.dbg = ln.status.p->dbg;
