@@ -33,7 +33,8 @@ struct FastaFile {
   size_t size = 0;
   size_t pos = 0;          // start of the next header line
   bool started = false;    // the first line began with '>'
-  bool borrowed = false;   // `data` belongs to the caller (attach)
+  bool borrowed = false;   // `data` belongs to the caller (attach) or to `piped`
+  std::vector<char> piped; // the bytes of a path that is not a regular file (a FIFO, a process substitution), read to their end
   std::string id;
   std::vector<uint8_t> seq;
 
@@ -48,6 +49,22 @@ struct FastaFile {
     struct stat st;
     if (fstat(fd, &st) != 0) { int e = errno; close(); throw Error(FA_ERR_IO, std::string(path) + ": " + strerror(e)); }
     if (S_ISDIR(st.st_mode)) { close(); throw Error(FA_ERR_IO, std::string(path) + ": is a directory"); }
+    if (!S_ISREG(st.st_mode)) {
+      // no size to map: take the bytes until end of file (st_size is 0 for a pipe -- it used to come back as an empty genome)
+      size_t got = 0;
+      piped.resize((size_t)1 << 20);
+      for (;;) {
+        if (got == piped.size()) piped.resize(piped.size() * 2);
+        const ssize_t r = ::read(fd, piped.data() + got, piped.size() - got);
+        if (r < 0) { if (errno == EINTR) continue; const int e = errno; close(); throw Error(FA_ERR_IO, std::string(path) + ": read: " + strerror(e)); }
+        if (r == 0) break;
+        got += (size_t)r;
+      }
+      ::close(fd); fd = -1;
+      data = piped.data(); size = got; borrowed = true; pos = 0;
+      started = size > 0 && data[0] == '>';
+      return;
+    }
     size = (size_t)st.st_size;
     if (size > 0) {
       void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);

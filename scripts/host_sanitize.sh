@@ -2,10 +2,10 @@
 # The host-only pieces of libfastani_hip (fa_host.h packer + thread pool, fa_fasta.h, fa_stats.h, fa_lease.h) under
 # AddressSanitizer + UndefinedBehaviorSanitizer and, separately, ThreadSanitizer -- on the CPU, g++ only (no GPU sanitizer,
 # no XNACK).  Every build runs with the AVX2 packer and with FA_NO_AVX2=1 (the scalar paths), with 8 and with 3 host threads.
-#   bash scripts/host_sanitize.sh [log]        (default log: profiles/r05_host_sanitizers.txt)
+#   bash scripts/host_sanitize.sh [log]        (default log: profiles/r06_host_sanitizers.txt)
 set -u
 cd "$(dirname "$0")/.."
-LOG=${1:-profiles/r05_host_sanitizers.txt}
+LOG=${1:-profiles/r06_host_sanitizers.txt}
 OUT=build/host_sanitize
 mkdir -p "$OUT"
 SRC=scripts/host_sanitize/driver.cpp

@@ -152,3 +152,39 @@ def test_packed_genomes_read_once_use_twice(tmp_path):
     with pytest.raises(OSError):
         grown.extend([str(tmp_path / "missing.fna")])
     assert len(grown) == 3
+
+
+def test_add_fasta_reads_a_fifo_to_its_end(tmp_path):
+    # a path that is not a regular file (a FIFO, a process substitution) reports size 0: the reader takes it until end of file
+    # instead of returning an empty genome (fa_fasta.h: slurp).  Host-side only: the short record behind 2 MB of sequence is
+    # reported, so the reader got to the end of the pipe.
+    import threading
+    import warnings
+    import pyfastani_amd as pf
+    body = (b"ACGTTGCA" * 10 + b"\n") * 25000
+    data = b">c1\n" + body + b">c2 short\nACGT\n"
+    fifo = str(tmp_path / "genome.fifo")
+    os.mkfifo(fifo)
+
+    def feed():
+        with open(fifo, "wb") as f:
+            f.write(data)
+    t = threading.Thread(target=feed)
+    t.start()
+    sk = pf.Sketch()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sk.add_fasta("piped", fifo)
+    t.join(30)
+    assert sk.names == ["piped"] and len(w) == 1 and "short" in str(w[0].message)
+    # ... and the one-sweep reader behind add_fasta_many (read() into a buffer sized by fstat) does the same
+    os.unlink(fifo)
+    os.mkfifo(fifo)
+    t = threading.Thread(target=feed)
+    t.start()
+    sk = pf.Sketch()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sk.add_fasta_many(["piped"], [fifo])
+    t.join(30)
+    assert sk.names == ["piped"] and len(w) == 1 and "short" in str(w[0].message)
