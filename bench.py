@@ -507,7 +507,7 @@ def weak_scaling(ctx):
         "data": "synthetic",
         "config": {"workload": f"{args.batch} query x {args.refs} synthetic {args.length / 1e6:g} Mb refs per GPU, k=16 frag=3000 w={mapper.window_size}",
                    "timed_region": "device-resident pass (packed query in HBM -> hit rows in HBM); the host-bytes -> Hit-list call is `boundary_call`",
-                   "queries_rotated": ROTATE, "pairs_per_step_per_gpu": n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
+                   "queries_rotated": ROTATE, "pairs_per_step_per_gpu": n_pairs_step, "pairs_per_step": world * n_pairs_step, "hits_per_step": n_hits, "l2_loci": int(n_loci), "l2_records": int(l2_records), "parallelism": f"query-sharded x{world}",
                    "index_minimizers": n_min, "index_build": index_mode, "index_build_s": t_index, "host_pack_s": t_pack, "head": git_head()},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": roof[0], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": roof[0] / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": roof[1],

@@ -498,6 +498,7 @@ struct Workspace {
   int64_t last_F = 0, last_f0 = 0;
   uint32_t last_loci = 0;             // loci of the last accepted part (all regions)
   uint32_t loci_n = 1, loci_shift = 0;                    // regions of the locus numbering of the part in flight / last accepted
+  bool l1_pf = false, l1_small_class = false;             // the part in flight ran k_l1 with the pre-filter / with the 256-thread class next to others
   uint32_t last_region_count[LOCI_REGIONS] = {0};         // live loci per region of the last accepted part
   uint64_t last_items = 0;
   const fa_genomes *last_genomes = nullptr;
@@ -571,6 +572,7 @@ struct fa_mapper {
     // share of the fragments of the last accepted part in the two lower size classes of k_l1 (-1: not seen yet)
     float l1_small_share = -1.0f, l1_mid_share = -1.0f, l1_tiny_share = -1.0f;   // (tiny: up to half the small class's bound)
     bool l1_prefilter = false;  // an accepted part saw fragments fall off k_l1's block sort: later passes drop dead hits before the sort (sticky)
+    bool l1_no_small = false;   // ... and they still did with the pre-filter on and the 256-thread class in use: its table is too small for this index (sticky)
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
   // intermediate of the pipeline -- so calls from different host threads overlap on the device (their phases interleave,
@@ -1043,7 +1045,7 @@ struct QueryPass {
     ms.part_frags = std::min(ms.part_frags, sp.part_frags);
     ms.redo = ms.redo || sp.redo;
     ms.l1_small_share = sp.l1_small_share; ms.l1_mid_share = sp.l1_mid_share; ms.l1_tiny_share = sp.l1_tiny_share;
-    ms.l1_prefilter = ms.l1_prefilter || sp.l1_prefilter;
+    ms.l1_prefilter = ms.l1_prefilter || sp.l1_prefilter; ms.l1_no_small = ms.l1_no_small || sp.l1_no_small;
     ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
   }
   // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
@@ -1258,6 +1260,7 @@ struct QueryPass {
         // S form for the small fragments, or do they ride in the middle form; the middle class stays if it has fragments of its
         // own worth a launch, or small ones to carry
         const bool keep_s = thin_small >= 0.0f ? (sp.l1_small_share < 0.0f || sp.l1_small_share >= thin_small)        // (forced: tests, A/B)
+                            : sp.l1_no_small ? false
                             : p.l1_prefilter ? (sp.l1_small_share < 0.0f || sp.l1_small_share >= 0.35f)
                                              : (sp.l1_tiny_share < 0.0f || sp.l1_tiny_share >= 0.5f);
         const bool keep_m = !keep_s || p.n_l1 == 2 || sp.l1_mid_share < 0.0f || sp.l1_mid_share >= thin_mid;
@@ -1286,6 +1289,7 @@ struct QueryPass {
     p.loci.n = std::min<uint32_t>(LOCI_REGIONS, ev_regions_for(F));
     p.loci.shift = (uint32_t)floor_log2((int)std::max<int64_t>(1, l_cap / p.loci.n));
     ln.loci_n = p.loci.n; ln.loci_shift = p.loci.shift;
+    ln.l1_pf = p.l1_prefilter; ln.l1_small_class = p.n_l1 > 1 && p.l1[0].nt == 256;
     p.wide = smax + 1 >= (1 << EvBits<uint16_t>::RANK);        // slot = rank + 1 must fit the slot field of the 16-bit event
     ln.items.ensure(((size_t)sp.items_cap + 8) * (p.wide ? 4 : 2));
 
@@ -1722,7 +1726,10 @@ struct QueryPass {
     if (F > 0) { sp.l1_small_share = (float)h_stats[1] / (float)F; sp.l1_mid_share = (float)h_stats[2] / (float)F; sp.l1_tiny_share = (float)h_stats[3] / (float)F; }
     // fragments whose hits were too scattered for the block sort (they took the merge, at twice the time): from one in two hundred
     // on, the passes that follow drop the hits that cannot belong to a candidate before the sort (launch_l1_stage)
-    if (F > 0 && (double)h_counters[0] > 0.005 * (double)F) sp.l1_prefilter = true;
+    // (with the filter on and the 256-thread class in use they are fragments whose kept chance hits -- the hashed bits keep about a
+    // third of them -- still overfill that class's table of 1 365 entries: an index of 1.6 x 10^9 records leaves ~700 of 2 000, and
+    // 47 % of the fragments of the 4000 x 4000 run fell back; the class is folded into the 512-thread form from then on)
+    if (F > 0 && (double)h_counters[0] > 0.005 * (double)F) { if (ln.l1_pf && ln.l1_small_class) sp.l1_no_small = true; sp.l1_prefilter = true; }
     publish_spec(sp);
     // ---- accepted ----
     {
