@@ -95,7 +95,10 @@ def git_head():
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:                              # noqa: BLE001 -- the GPU box holds a snapshot without .git
-        return None
+        try:                                       # (scripts/r06/*.sh leave the commit of the snapshot here before a gpurun call)
+            return open(os.path.join(ROOT, "gpurun_head.txt")).read().strip() or None
+        except OSError:
+            return None
 
 
 def launch_ranks(n):
