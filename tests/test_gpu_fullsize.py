@@ -45,6 +45,33 @@ def test_config2_fullsize_index_matches_oracle(config2):
     assert mapper.window_size == osk.window_size == 24
 
 
+def test_genome_like_fullsize_rows_and_mappings_match_oracle():
+    """Genome-LIKE genomes at the full 5 Mb (2 families x 8 members: planted repeats on both strands, low-complexity tracts, indels,
+    a 100 kb inversion; `workloads.genome_like`, the generator of bench.py's `genome_like` leg): the index against the oracle's,
+    then three queries -- an ancestor, a close and a distant member -- every L2 mapping, every raw CGI row, the final hits.
+    The fragments that touch a repeat collect 10^4 seed hits: all three size classes of k_l1 run in these passes."""
+    genomes, fam = workloads.genome_like(6000, 2, 8, 5_000_000)
+    n = len(genomes)
+    sk, osk = pf.Sketch(), OracleSketch()
+    sk.add_drafts(list(range(n)), genomes)
+    osk.add_drafts(list(range(n)), genomes)
+    mapper = sk.index()
+    osk.index()
+    assert len(mapper.minimizers) == len(osk.minimizers()[0]) and len(mapper.lookup_index) == osk.index_size
+    assert mapper.occurences_threshold == osk.freq_threshold
+    for q in (0, 1, 13):
+        contigs = [bytes(c) for c in genomes[q]]
+        ohits, det = osk.query_draft(contigs, threads=os.cpu_count() or 1, details=True)
+        hits = mapper.query_draft(contigs)
+        assert gpu_mappings(mapper) == oracle_mappings(det), f"query {q}"
+        assert hit_tuples(hits) == ohits, f"query {q}"
+        rows = mapper.upload_genomes([contigs]).query_rows(0, 1)
+        o = det["rows"]
+        assert len(rows) == len(o["genome"]) >= 8
+        assert np.array_equal(rows["ref_genome_id"], o["genome"]) and np.array_equal(rows["count_seq"], o["count"])
+        assert np.array_equal(rows["identity"], o["identity"])              # float32, bit for bit
+
+
 @pytest.mark.parametrize("rank", [0, 1])
 def test_config2_fullsize_every_row_and_mapping(config2, rank):
     """The step bench.py times (rank 0's query; rank 1's is what a second GPU would map), compared with the oracle:
