@@ -482,6 +482,7 @@ struct Workspace {
   DevBuf<uint32_t> l_nev, l_ioff, f_loci_lo, f_loci_n;
   DevBuf<unsigned char> items;
   DevBuf<uint8_t> l_redo, big_state;
+  DevBuf<uint32_t> scan_hist, scan_order;   // k_l2_scan's loci by stream length: class counts + cursors, the order
   // workgroup order of k_l2_events for passes of several genomes (L2Args::frag_order), cached while the same part repeats
   DevBuf<int32_t> frag_order;
   PinnedBuf pin_order;
@@ -572,6 +573,7 @@ struct fa_mapper {
     // share of the fragments of the last accepted part in the two lower size classes of k_l1 (-1: not seen yet)
     float l1_small_share = -1.0f, l1_mid_share = -1.0f, l1_tiny_share = -1.0f;   // (tiny: up to half the small class's bound)
     bool l1_prefilter = false;  // an accepted part saw fragments fall off k_l1's block sort: later passes drop dead hits before the sort (sticky)
+    int64_t l2_loci_last = 0;   // loci of the last accepted part: k_l2_scan sorts its loci by stream length when there are waves to balance
     bool l1_no_small = false;   // ... and they still did with the pre-filter on and the 256-thread class in use: its table is too small for this index (sticky)
   } spec;
   // Queries are re-entrant (_fastani.pyx:1158-1161): every call takes one of NWS workspaces -- its own stream and every
@@ -1046,6 +1048,7 @@ struct QueryPass {
     ms.redo = ms.redo || sp.redo;
     ms.l1_small_share = sp.l1_small_share; ms.l1_mid_share = sp.l1_mid_share; ms.l1_tiny_share = sp.l1_tiny_share;
     ms.l1_prefilter = ms.l1_prefilter || sp.l1_prefilter; ms.l1_no_small = ms.l1_no_small || sp.l1_no_small;
+    ms.l2_loci_last = sp.l2_loci_last;
     ms.smax_misses = std::max(ms.smax_misses, sp.smax_misses);
   }
   // workgroups per CU of the two L2 kernels at a sketch bound (their LDS grows with it), as one number; 0 = not the usual
@@ -1165,6 +1168,7 @@ struct QueryPass {
     L1Class l1[3];
     int n_l1 = 0;
     bool l1_prefilter = false;                                // this part drops dead hits before k_l1's block sort
+    bool scan_sorted = false;                                 // k_l2_scan takes its loci sorted by stream length (k_l2_order)
     uint32_t seed_slots = 0;                                  // slots of the last class
     bool wide = false;
     LociRegions loci{nullptr, 1, 0};          // regions of the locus numbering of this part
@@ -1283,6 +1287,15 @@ struct QueryPass {
     ln.group_best.ensure((size_t)l_cap + 2);
     ln.l_beg.ensure((size_t)l_cap); ln.l_end0.ensure((size_t)l_cap); ln.l_last.ensure((size_t)l_cap); ln.l_ndrop.ensure((size_t)l_cap);
     ln.l_nev.ensure((size_t)l_cap); ln.l_ioff.ensure((size_t)l_cap); ln.l_redo.ensure((size_t)l_cap + 4);
+    // A wave of k_l2_scan lasts as long as the longest of its 64 slides, and in k_l1's numbering it holds the loci of one fragment --
+    // streams of every length the divergences of the index produce (lane utilisation 85 %).  When the last accepted part had loci
+    // for a wave per SIMD and more, the scan takes the loci of every region sorted by stream length (profiles/r06_scan_order.txt:
+    // L2 stage -8 % on config 3, -9 % on config 4, -10 % on genome-like inputs and in the (16, 1000) cell, -6 % at 16 queries per
+    // launch, -1 % on one 5 Mb query).  FA_L2_SCAN_ORDER = 0 / 1: never / always.
+    static const int scan_order_env = getenv("FA_L2_SCAN_ORDER") ? atoi(getenv("FA_L2_SCAN_ORDER")) : -1;
+    p.scan_sorted = scan_order_env < 0 ? sp.l2_loci_last >= 1024 * 64 : scan_order_env != 0;
+    ln.scan_hist.ensure((size_t)2 * LOCI_REGIONS * SCAN_CLASSES);
+    if (p.scan_sorted) ln.scan_order.ensure((size_t)l_cap + 64);
     ln.ovf_buf.ensure((size_t)sp.scratch_words + 4);
     // the locus numbering: one region per sixteen fragments (64 at most), each the largest power of two that fits its share
     p.loci.count = ln.status.p->loci_region;
@@ -1336,6 +1349,7 @@ struct QueryPass {
       cl.a.stamp = &ln.status.p->stamp[0];
       cl.add(ln.l_end.p, (size_t)l_cap * sizeof(int32_t)); cl.add(ln.l_rlast.p, (size_t)l_cap * sizeof(int32_t));
       cl.add(ln.group_best.p, (size_t)l_cap * sizeof(unsigned long long));
+      if (p.scan_sorted) cl.add(ln.scan_hist.p, (size_t)2 * LOCI_REGIONS * SCAN_CLASSES * sizeof(uint32_t));
       if (!bins_cleared) { cl.add(w.bins.p, (size_t)NQ * std::max(m.total_bins, 1) * sizeof(unsigned long long)); bins_cleared = true; }
       QuerySketchArgs a;
       a.frag_tile_lo = g.d_frag_tile_lo + f0;
@@ -1475,6 +1489,14 @@ struct QueryPass {
       a.region_cap = (sp.items_cap / a.n_regions) & ~7ULL;
       a.l_redo = ln.l_redo.p;
       a.redo_count = d_counters + 3;
+      {
+        // classes of the counting sort: the longest streams hold the records of ~2.6 windows twice (see ev_stage below), so six
+        // windows' worth of events over the classes
+        const int per_window_ev = std::max(1, 2 * m.P.fragment_length / (m.P.window_size + 1));
+        a.scan_class_div = p.scan_sorted ? std::max(8, (per_window_ev * 6 / SCAN_CLASSES + 7) & ~7) : 0;
+        a.scan_hist = ln.scan_hist.p; a.scan_cursor = ln.scan_hist.p + LOCI_REGIONS * SCAN_CLASSES;
+        a.scan_order = p.scan_sorted ? ln.scan_order.p : nullptr;
+      }
       a.f_loci_lo = ln.f_loci_lo.p; a.f_loci_n = ln.f_loci_n.p;
       // several genomes in the pass: the workgroups of k_l2_events in offset-major order (prepare_order)
       a.frag_order = p.frag_order;
@@ -1512,6 +1534,8 @@ struct QueryPass {
         if (ev_lds > 64 * 1024) FA_HIP(hipFuncSetAttribute((const void *)ev_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ev_lds));
         hipLaunchKernelGGL(ev_kernel, dim3(ev_grid), dim3(EV_THREADS), ev_lds, st, a);
         debug_sync(st, "l2 events");
+        if (p.scan_sorted)
+          hipLaunchKernelGGL(k_l2_order, dim3((unsigned)(p.loci.n * (uint32_t)ceil_div((int64_t)1 << p.loci.shift, 256))), dim3(256), 0, st, a);
         // the number of loci is only known on the device: launch for the capacity, surplus workgroups exit at once
         a.lanes = lanes8;
         if (lanes8 == L2_THREADS) {
@@ -1723,6 +1747,7 @@ struct QueryPass {
       // fragments that do not fit the LDS slots use HBM scratch, which must exist: size it for the new slot count lazily
       sp.seed_slots = want_slots;
     }
+    sp.l2_loci_last = (int64_t)loci_total;
     if (F > 0) { sp.l1_small_share = (float)h_stats[1] / (float)F; sp.l1_mid_share = (float)h_stats[2] / (float)F; sp.l1_tiny_share = (float)h_stats[3] / (float)F; }
     // fragments whose hits were too scattered for the block sort (they took the merge, at twice the time): from one in two hundred
     // on, the passes that follow drop the hits that cannot belong to a candidate before the sort (launch_l1_stage)

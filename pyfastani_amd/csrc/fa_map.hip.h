@@ -2004,6 +2004,13 @@ struct L2Args {
   // time and all but the first find them in the XCD's L2 / the memory-side cache instead of HBM.  nullptr: identity.
   const int32_t *frag_order;
   unsigned long long *stamp;         // stage_stamp: start of the L2 stage
+  // k_l2_scan takes its loci through `scan_order` when it is set (round 6): the loci of every region sorted by the length of their
+  // event streams, longest first (a counting sort over SCAN_CLASSES classes of `scan_class_div` events: k_l2_events counts,
+  // k_l2_order places).  A wave slides 64 loci and lasts as long as the longest; in the numbering of k_l1 a wave holds the loci of
+  // ONE fragment -- one per related genome, streams of every length the index's divergences produce (lane utilisation 85 %).
+  uint32_t *scan_hist, *scan_cursor; // [loci.n][SCAN_CLASSES] loci per class / placed so far
+  uint32_t *scan_order;              // [loci capacity] locus numbers, region by region (nullptr: the identity)
+  int32_t scan_class_div;            // events per class; 0 = no ordering
 #ifdef FA_EXPERIMENTS
   int32_t dbg;                       // FA_FUSED_DEBUG (timing experiments only, results are void): 1 = slider idles,
                                      // 2 = producer composes no events, 4 = producer issues no loads
@@ -2012,6 +2019,10 @@ struct L2Args {
 
 constexpr int L2_THREADS = 64;
 constexpr int EV_THREADS = 256;
+constexpr int SCAN_CLASSES = 32;
+__device__ __forceinline__ uint32_t scan_class(uint32_t nev, int32_t div) {   // 0 = the longest streams
+  return (uint32_t)(SCAN_CLASSES - 1) - min((uint32_t)(SCAN_CLASSES - 1), nev / (uint32_t)div);
+}
 constexpr int EV_REGIONS = 64;
 
 // Event word, from the low end: dM:2 | dW:2 | spare | drop | slot (= query rank + 1; 0 is the padding no-op) | no-eval
@@ -2083,7 +2094,9 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
   __shared__ uint32_t sh_wave[EV_THREADS / 64];
   __shared__ uint32_t sh_run, sh_base, sh_ok;
   __shared__ unsigned long long sh_records;
+  __shared__ uint32_t sh_class[SCAN_CLASSES];                          // loci of this fragment per length class (scan_order)
   if (threadIdx.x == 0) { sh_run = 0; sh_records = 0; }
+  if (threadIdx.x < SCAN_CLASSES) sh_class[threadIdx.x] = 0;
   __syncthreads();
   const int32_t *wpos = a.ix.rec_wpos;
   for (uint32_t c0 = 0; c0 < l_n; c0 += EV_THREADS) {
@@ -2116,6 +2129,7 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
       nev = (uint32_t)((((end0 - beg + 7) & ~7) + (last - end0) + ndrop + 7) & ~7);
       records = (uint32_t)(last - beg);
       a.l_nev[l] = nev;
+      if (a.scan_class_div) atomicAdd(&sh_class[scan_class(nev, a.scan_class_div)], 1u);
     }
     // exclusive scan of the event counts inside the workgroup
     uint32_t incl = nev;
@@ -2132,6 +2146,8 @@ __global__ __launch_bounds__(EV_THREADS, EV_WAVES_PER_SIMD) void k_l2_events(L2A
     if (threadIdx.x == 0) { uint32_t tot = 0; for (int q = 0; q < EV_THREADS / 64; q++) tot += sh_wave[q]; sh_run += tot; }
     __syncthreads();
   }
+  if (a.scan_class_div && threadIdx.x < SCAN_CLASSES && sh_class[threadIdx.x])      // (the loci of a fragment sit in ONE region of the numbering)
+    atomicAdd(&a.scan_hist[((uint32_t)f & (a.loci.n - 1u)) * SCAN_CLASSES + threadIdx.x], sh_class[threadIdx.x]);
   if (threadIdx.x == 0) {
     const uint32_t region = (uint32_t)f & (a.n_regions - 1);
     const unsigned long long base = atomicAdd(&a.ev_region[region], (unsigned long long)sh_run);   // order of fragments is irrelevant
@@ -2506,6 +2522,33 @@ struct Slide {
   }
 };
 
+// The loci of every region into `scan_order`, longest event stream first (second half of the counting sort k_l2_events began):
+// workgroup b takes 256 consecutive locus numbers of region b mod n; a locus is placed behind the loci of the longer classes
+// (prefix sums of the region's class counts) at the next free place of its class -- one returning atomic per class and workgroup.
+// The order inside a class is whatever the atomics make it: every locus is slid on its own, and the group maximum is an atomicMax.
+__global__ __launch_bounds__(256) void k_l2_order(L2Args a) {
+  __shared__ uint32_t sh_cnt[SCAN_CLASSES], sh_at[SCAN_CLASSES];
+  const uint32_t r = blockIdx.x & (a.loci.n - 1u), off = (blockIdx.x / a.loci.n) * 256u + threadIdx.x;
+  // (a pass that raised a speculation flag is void and will be repeated: its class counts may not match its stream lengths --
+  // k_l2_events zeroes the lengths of a fragment whose events found no room -- so nothing is ordered, and k_l2_scan does nothing)
+  if (a.counters[2] || a.pinfo[1]) return;
+  const uint32_t live = min(a.loci.count[r], 1u << a.loci.shift);
+  if ((blockIdx.x / a.loci.n) * 256u >= live) return;                  // (uniform: nothing of this chunk is live)
+  if (threadIdx.x < SCAN_CLASSES) sh_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t l = (r << a.loci.shift) + off;
+  uint32_t c = 0, rank = 0;
+  if (off < live) { c = scan_class(a.l_nev[l], a.scan_class_div); rank = atomicAdd(&sh_cnt[c], 1u); }
+  __syncthreads();
+  if (threadIdx.x < SCAN_CLASSES) {
+    uint32_t before = 0;
+    for (uint32_t q = 0; q < threadIdx.x; q++) before += a.scan_hist[r * SCAN_CLASSES + q];
+    sh_at[threadIdx.x] = before + (sh_cnt[threadIdx.x] ? atomicAdd(&a.scan_cursor[r * SCAN_CLASSES + threadIdx.x], sh_cnt[threadIdx.x]) : 0u);
+  }
+  __syncthreads();
+  if (off < live) a.scan_order[(r << a.loci.shift) + min(sh_at[c] + rank, (1u << a.loci.shift) - 1u)] = l;
+}
+
 // LNT = lanes per workgroup at compile time (64) or 0 for the run-time value used when a huge sketch forces fewer lanes
 // per workgroup.
 template <typename T, typename ST, int LNT>
@@ -2518,8 +2561,11 @@ __global__ __launch_bounds__(L2_THREADS) void k_l2_scan(L2Args a) {
   if (lane >= LN) return;
   // workgroup b takes chunk b / n of region b mod n (regions are filled from their start: the workgroups that have loci come
   // first in dispatch order, as they did with one dense numbering, and the empty ones behind them exit at once)
-  const uint32_t l = ((blockIdx.x & (a.loci.n - 1u)) << a.loci.shift) + (blockIdx.x / a.loci.n) * (uint32_t)LN + (uint32_t)lane;
-  if (a.counters[2] || (blockIdx.x / a.loci.n) * (uint32_t)LN + (uint32_t)lane >= (1u << a.loci.shift) || !locus_live(a.loci, l)) return;
+  const uint32_t region = blockIdx.x & (a.loci.n - 1u), off = (blockIdx.x / a.loci.n) * (uint32_t)LN + (uint32_t)lane;
+  if (a.counters[2] || off >= (1u << a.loci.shift) || off >= a.loci.count[region]) return;    // (locus_live of the identity order)
+  if (a.scan_order && a.pinfo[1]) return;                             // void pass: no order was made (k_l2_order)
+  // place `off` of the region: the locus of that number, or -- sorted by stream length -- the one k_l2_order put there
+  const uint32_t l = a.scan_order ? a.scan_order[(region << a.loci.shift) + off] : (region << a.loci.shift) + off;
   if (REDO) { if (!a.l_redo[l]) return; }
   else a.l_redo[l] = 0;
   const int s = a.q_size[a.l_frag[l]];

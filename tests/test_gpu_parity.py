@@ -1748,14 +1748,14 @@ def test_handles_released_from_a_thread_that_never_entered_the_library():
 
 
 @pytest.mark.parametrize("env", [{"FA_L1_PREFILTER": "1"}, {"FA_L1_PREFILTER": "1", "FA_L1_THIN_SMALL": "0", "FA_L1_THIN_MID": "0"},
-                                 {"FA_L1_THIN_SMALL": "2"}, {"FA_EV_RANK": "0"}],
-                         ids=["prefilter", "prefilter+every-class", "small-in-middle-form", "probe-ranks"])
+                                 {"FA_L1_THIN_SMALL": "2"}, {"FA_EV_RANK": "0"}, {"FA_L2_SCAN_ORDER": "1"}, {"FA_L2_SCAN_ORDER": "0"}],
+                         ids=["prefilter", "prefilter+every-class", "small-in-middle-form", "probe-ranks", "scan-sorted", "scan-identity"])
 def test_round6_kernel_forms_forced(env):
     """The forms of round 6 that the defaults only pick on large or unusual indices, forced onto the tests whose inputs reach them:
     the pre-filter of k_l1's block sort on every index (chance hits, planted repeats, the frequency threshold, seed counts across
     the merge tiers, the random-seed regime); every size class of k_l1 with a launch of its own / the small class folded into the
     512-thread form (the genome-like genomes hold fragments of all three classes); k_l2_events with the rank structure of rounds
-    2-5.  Same oracle, same bit-exact bar."""
+    2-5; k_l2_scan over loci sorted by stream length on passes of any size, and never.  Same oracle, same bit-exact bar."""
     import subprocess
     pick = ("test_genome_like or test_frequency_threshold_active or test_seed_counts_across_the_merge_tiers or test_random_seed_regime "
             "or test_l1_candidates or test_end_to_end_vs_oracle or test_seed_overflow_to_hbm_scratch or test_small_sketch_against_crowded_window "
