@@ -24,6 +24,8 @@ PATTERNS = [
     (r"ev_rank_ab\.txt$", "bash scripts/r06/ab_rank_and_classes.sh", "k_l2_events: bucket table + four-entry probe against occupancy words"),
     (r"l1_classes_ab\.txt$", "bash scripts/r06/ab_rank_and_classes.sh", "k_l1 launched per size class of fragments"),
     (r"l1_prefilter\.txt$", "bash scripts/r06/prefilter.sh", "the pre-filter of k_l1's block sort: parity, config 3, 2000 x 2000, 4000 x 4000"),
+    (r"scan_order\.txt$", "bash scripts/r06/scan_order.sh", "k_l2_scan over loci sorted by stream length: parity forced on, A/B on every saturated leg"),
+    (r"fasta_read_once\.txt$", "python bench.py --strong --steps 1 --warmup 1", "the files-to-table leg of config 3 repeated: the spread of the read-once variant"),
     (r"genome_like.*\.json$", "python bench.py --leg genome_like", "the genome-like leg (repeats, indels, inversion) alone"),
     (r"scale_\d+x\d+\.json$|scale_probe.*\.txt$", "python bench.py --strong --families F --members 50", "all-vs-all beyond config 3 (index of 8 x 10^8 / 1.6 x 10^9 records)"),
     (r"ingest.*\.(json|txt)$|fasta_read_once\.txt$", "python scripts/time_ingest.py", "FASTA files to packed words / to the hit table"),
