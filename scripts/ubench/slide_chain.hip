@@ -31,7 +31,9 @@ __global__ void k_clock(unsigned long long *out, int spin) {
 }
 
 int main(int argc, char **argv) {
-  const int S = 240, FILL = 240, EV = argc > 1 ? atoi(argv[1]) : 976, NSTREAM = 1024;
+  // argv[2]: sketch size (default 240).  A smaller sketch is a smaller LDS state per wave: what more waves per SIMD would buy the
+  // UNCHANGED instruction chain (round 6: the bound on any scheme that shrinks the state, e.g. four bits per rank)
+  const int S = argc > 2 ? atoi(argv[2]) : 240, FILL = 240, EV = argc > 1 ? atoi(argv[1]) : 976, NSTREAM = 1024;
   const int nev = FILL + EV;                                         // both multiples of 8
   hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
   const int cus = prop.multiProcessorCount, simds = cus * 4;
@@ -67,7 +69,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < EV; i++) e[FILL + i] = (i & 1) ? admit(false, false) : drop();
   }
   // ---- the arguments k_l2_scan reads ----
-  const int maxw = 4 * simds;
+  const int maxw = 8 * simds;
   const uint32_t max_loci = (uint32_t)maxw * 64;
   uint16_t *d_items; CHECK(hipMalloc(&d_items, items.size() * 2)); CHECK(hipMemcpy(d_items, items.data(), items.size() * 2, hipMemcpyHostToDevice));
   std::vector<int32_t> h_zero(max_loci, 0), h_end0(max_loci, FILL), h_wpos(8192);
@@ -89,7 +91,7 @@ int main(int argc, char **argv) {
   uint32_t *d_live; CHECK(hipMalloc(&d_live, 4)); a.loci.count = d_live; a.loci.n = 1; a.loci.shift = 24;
   uint8_t *d_redo; CHECK(hipMalloc(&d_redo, max_loci)); a.l_redo = d_redo;
   unsigned long long *d_gb; CHECK(hipMalloc(&d_gb, 64)); CHECK(hipMemset(d_gb, 0, 64)); a.group_best = d_gb;
-  a.items = d_items; a.cnt_slots = 257; a.lanes = 64; a.qcap = 0; a.cmw = 0;
+  a.items = d_items; a.cnt_slots = S + 17; a.lanes = 64; a.qcap = 0; a.cmw = 0;
   const size_t state = ((size_t)(a.cnt_slots + 1) * 64 + 15) / 16 * 16;
   unsigned long long *d_clk; CHECK(hipMalloc(&d_clk, (size_t)cus * 16));
   auto kernel = k_l2_scan<uint16_t, uint8_t, 64>;
@@ -98,9 +100,11 @@ int main(int argc, char **argv) {
   printf("# %-34s %9s %9s %12s %14s %16s\n", "launch", "waves", "us", "clock MHz", "ns per event", "cycles per event");
   struct Cfg { const char *name; int waves; int per_cu; };
   const Cfg cfgs[] = {{"1 wave per SIMD (4 per CU fit)", simds, 4}, {"2 waves per SIMD (8 per CU fit)", 2 * simds, 8}, {"bench-like 1428 waves (8 fit)", 1428, 8},
-                      {"1024 waves, 8 per CU fit", simds, 8}, {"3 waves per SIMD (12 per CU fit... LDS 8)", 3 * simds, 8}, {"4 waves per SIMD in two rounds", 4 * simds, 8}};
+                      {"1024 waves, 8 per CU fit", simds, 8}, {"3 waves per SIMD (12 per CU fit... LDS 8)", 3 * simds, 8}, {"4 waves per SIMD in two rounds", 4 * simds, 8},
+                      // (per_cu 0: the LDS request is the state alone -- with a small sketch as many waves per SIMD as the state allows)
+                      {"state-limited: 3 waves per SIMD", 3 * simds, 0}, {"state-limited: 4 waves per SIMD", 4 * simds, 0}, {"state-limited: 6 waves per SIMD", 6 * simds, 0}};
   for (const Cfg &c : cfgs) {
-    const size_t lds = std::max(state, (size_t)(c.per_cu == 4 ? 36 * 1024 : 19 * 1024));
+    const size_t lds = c.per_cu == 0 ? state : std::max(state, (size_t)(c.per_cu == 4 ? 36 * 1024 : 19 * 1024));
     const uint32_t loci = (uint32_t)c.waves * 64;
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     CHECK(hipMemcpy(d_counters, cnt, 32, hipMemcpyHostToDevice));
