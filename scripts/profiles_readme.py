@@ -30,7 +30,7 @@ PATTERNS = [
     (r"scale_\d+x\d+\.json$|scale_probe.*\.txt$", "python bench.py --strong --families F --members 50", "all-vs-all beyond config 3 (index of 8 x 10^8 / 1.6 x 10^9 records)"),
     (r"ingest.*\.(json|txt)$|fasta_read_once\.txt$", "python scripts/time_ingest.py", "FASTA files to packed words / to the hit table"),
     (r"trace_index.*\.txt$|time_index.*", "FA_TRACE=1 python scripts/time_index.py", "stages of the index build"),
-    (r"slide_chain.*\.txt$", "bash scripts/run_ubench.sh", "the slide on synthetic event streams (cycles per event)"),
+    (r"slide_chain.*\.txt$|slide_occupancy\.txt$", "bash scripts/run_ubench.sh; scripts/ubench/slide_chain <events> <sketch>", "the slide on synthetic event streams (cycles per event; at 2-6 resident waves per SIMD)"),
     (r"config5_cells\.json$|config[34].*\.json$", "python scripts/run_config45.py / run_config5_cells.py", "BASELINE configs 3-5 by the stand-alone runners"),
     (r"concurrent_clients\.json$|query_draft\.json$|many_relatives.*|two_streams\.json$|boundary_zero_copy\.txt$", "scripts/time_*.py", "one-off timings named by the file"),
 ]
